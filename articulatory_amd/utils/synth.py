@@ -1,0 +1,175 @@
+"""Deterministic synthetic checkpoints for the HiFi-GAN / HiFi-CAR generator.
+
+Trained checkpoints of the reference are Google-Drive links (reference README.md:36)
+and unreachable offline, so every parity test, golden fixture and benchmark in this
+repo runs on *synthesised* weights.  The generator here is numpy-only and keyed by
+tensor name, so that
+
+  * the golden-vector script (oracle/make_golden.py, which imports the real reference),
+  * the CPU oracle (oracle/hificar_oracle.py),
+  * the HIP path (articulatory_amd.models.HiFiGANGenerator) and
+  * bench.py
+
+all regenerate bit-identical fp32 tensors from (seed, name, shape) without shipping
+the 54 MB state_dict.  The tensors are produced in the reference's *checkpoint*
+layout: ``*.weight_g`` / ``*.weight_v`` / ``*.bias`` for every Conv1d/ConvTranspose1d
+(old-style ``torch.nn.utils.weight_norm``; reference articulatory/models/hifigan.py:268-278)
+and plain ``weight`` / ``bias`` for the PastFCEncoder Linear layers
+(reference articulatory/layers/pytorch_layers.py:438-449).
+"""
+
+from collections import OrderedDict
+
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _fnv1a64(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """Vectorised splitmix64 finaliser on a uint64 array (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed: int, name: str, n: int) -> np.ndarray:
+    """n float64 samples in [0, 1), a pure function of (seed, name, index)."""
+    base = (_fnv1a64(name) ^ (int(seed) * 0xD1342543DE82EF95)) & 0xFFFFFFFFFFFFFFFF
+    with np.errstate(over="ignore"):
+        ctr = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(base)) & _MASK
+    bits = _splitmix64(_splitmix64(ctr))
+    return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def uniform(seed: int, name: str, shape, lo: float, hi: float) -> np.ndarray:
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = uniform01(seed, name, n)
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def default_paddings(upsample_scales):
+    """Reference padding rule (articulatory/models/hifigan.py:82-103)."""
+    pads = [s // 2 + s % 2 for s in upsample_scales]
+    opads = [s % 2 for s in upsample_scales]
+    return pads, opads
+
+
+def generator_param_spec(
+    in_channels=80,
+    out_channels=1,
+    channels=512,
+    kernel_size=7,
+    upsample_scales=(8, 8, 2, 2),
+    upsample_kernel_sizes=(16, 16, 4, 4),
+    resblock_kernel_sizes=(3, 7, 11),
+    resblock_dilations=((1, 3, 5), (1, 3, 5), (1, 3, 5)),
+    use_additional_convs=True,
+    bias=True,
+    use_weight_norm=True,
+    use_ar=False,
+    ar_input=512,
+    ar_hidden=256,
+    ar_output=128,
+    **_ignored,
+):
+    """Ordered {state_dict key: shape} of the reference generator for these kwargs.
+
+    Key names and shapes follow what ``HiFiGANGenerator(**kwargs).state_dict()`` yields in the
+    reference (articulatory/models/hifigan.py:108-175; verified key-for-key by
+    tests/test_oracle_golden.py against the fixture written by oracle/make_golden.py).
+    ConvTranspose1d weights are (Cin, Cout, K) and their weight_g is per-*Cin* (dim 0).
+    """
+    spec = OrderedDict()
+
+    def conv(prefix, w_shape, n_bias, has_bias=True):
+        if has_bias:
+            spec[prefix + ".bias"] = (n_bias,)
+        if use_weight_norm:
+            spec[prefix + ".weight_g"] = (w_shape[0], 1, 1)
+            spec[prefix + ".weight_v"] = tuple(w_shape)
+        else:
+            spec[prefix + ".weight"] = tuple(w_shape)
+
+    # torch orders a weight-normed module's params as bias, weight_g, weight_v
+    conv("input_conv", (channels, in_channels, kernel_size), channels)
+    n_up = len(upsample_kernel_sizes)
+    n_blocks = len(resblock_kernel_sizes)
+    ups = []
+    blocks = []
+    for i in range(n_up):
+        cin = channels // (2 ** i)
+        cout = channels // (2 ** (i + 1))
+        ups.append((f"upsamples.{i}.1", (cin, cout, upsample_kernel_sizes[i]), cout))
+        for j in range(n_blocks):
+            k = resblock_kernel_sizes[j]
+            b = i * n_blocks + j
+            c1 = [(f"blocks.{b}.convs1.{d}.1", (cout, cout, k), cout) for d in range(len(resblock_dilations[j]))]
+            c2 = [(f"blocks.{b}.convs2.{d}.1", (cout, cout, k), cout) for d in range(len(resblock_dilations[j]))]
+            blocks.append((c1, c2 if use_additional_convs else []))
+    for p, s, nb in ups:
+        conv(p, s, nb)
+    # only the ResidualBlock convs honour the `bias` flag (residual_block.py:172-205); the input,
+    # upsample and output convs are built without one and so always carry a bias (hifigan.py:108-159)
+    for c1, c2 in blocks:
+        for p, s, nb in c1:
+            conv(p, s, nb, bias)
+        for p, s, nb in c2:
+            conv(p, s, nb, bias)
+    c_last = channels // (2 ** n_up)
+    conv("output_conv.1", (out_channels, c_last, kernel_size), out_channels)
+    if use_ar:
+        dims = [ar_input] + [ar_hidden] * 4 + [ar_output]
+        for li in range(5):
+            spec[f"ar_model.model.{2 * li}.weight"] = (dims[li + 1], dims[li])
+            spec[f"ar_model.model.{2 * li}.bias"] = (dims[li + 1],)
+    return spec
+
+
+def synth_state_dict(generator_params: dict, seed: int = 1234, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """Synthesise a reference-layout generator state_dict as float32 numpy arrays.
+
+    ``weight_v ~ U(-b, b)`` with ``b = gain * sqrt(3 / fan_in)`` (unit-variance-preserving),
+    ``weight_g = ||v|| * U(0.8, 1.2)`` so that the weight-norm fold is *not* the identity,
+    ``bias ~ U(-0.05, 0.05)``.
+    """
+    spec = generator_param_spec(**generator_params)
+    out = OrderedDict()
+    for name, shape in spec.items():
+        if name.endswith(".weight_v") or name.endswith(".weight"):
+            fan_in = int(np.prod(shape[1:]))
+            b = gain * np.sqrt(3.0 / fan_in)
+            out[name] = uniform(seed, name, shape, -b, b)
+        elif name.endswith(".bias"):
+            out[name] = uniform(seed, name, shape, -0.05, 0.05)
+    for name, shape in spec.items():
+        if name.endswith(".weight_g"):
+            v = out[name[: -len("weight_g")] + "weight_v"].astype(np.float64)
+            norm = np.sqrt((v.reshape(v.shape[0], -1) ** 2).sum(axis=1)).reshape(shape)
+            jitter = uniform(seed, name, shape, 0.8, 1.2).astype(np.float64)
+            out[name] = (norm * jitter).astype(np.float32)
+    # restore spec order
+    return OrderedDict((k, out[k]) for k in spec)
+
+
+def synth_features(batch: int, frames: int, dims: int, seed: int) -> np.ndarray:
+    """Synthetic EMA(+pitch) features, (B, T, dims) fp32: N(0,1) with channel 0 ~ U(0,1).
+
+    Mirrors the min-max-normalised pitch channel of the reference's feature files
+    (egs/ema/voc1/local/combine_feats.py:42-62).  numpy PCG64, as SURVEY.md §8(d) specifies.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = rng.standard_normal((batch, frames, dims)).astype(np.float32)
+    x[:, :, 0] = rng.random((batch, frames)).astype(np.float32)
+    return x
