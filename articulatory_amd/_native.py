@@ -1,0 +1,144 @@
+"""ctypes binding of libhificar.so (C ABI: include/hificar.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  The CPU oracle under ``oracle/`` is test infrastructure and is never
+imported from here.
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhificar.so")
+
+MAX_STAGES = 8
+MAX_BLOCKS = 4
+MAX_DILATIONS = 4
+
+PREC_F32 = 0
+PREC_BF16X3 = 1
+PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3}
+
+# every symbol include/hificar.h declares (tests/test_cabi.py checks the .so exports each one)
+SYMBOLS = (
+    "hificar_create",
+    "hificar_set_weight",
+    "hificar_finalize",
+    "hificar_set_precision",
+    "hificar_workspace_bytes",
+    "hificar_forward",
+    "hificar_ar_loop",
+    "hificar_macs",
+    "hificar_destroy",
+    "hificar_last_error",
+    "hificar_version",
+)
+
+
+class HificarConfig(ctypes.Structure):
+    _fields_ = [
+        ("in_channels", ctypes.c_int32),
+        ("out_channels", ctypes.c_int32),
+        ("channels", ctypes.c_int32),
+        ("kernel_size", ctypes.c_int32),
+        ("n_stages", ctypes.c_int32),
+        ("upsample_scales", ctypes.c_int32 * MAX_STAGES),
+        ("upsample_kernel_sizes", ctypes.c_int32 * MAX_STAGES),
+        ("n_blocks", ctypes.c_int32),
+        ("resblock_kernel_sizes", ctypes.c_int32 * MAX_BLOCKS),
+        ("n_dilations", ctypes.c_int32 * MAX_BLOCKS),
+        ("resblock_dilations", (ctypes.c_int32 * MAX_DILATIONS) * MAX_BLOCKS),
+        ("use_additional_convs", ctypes.c_int32),
+        ("bias", ctypes.c_int32),
+        ("lrelu_slope", ctypes.c_float),
+        ("use_tanh", ctypes.c_int32),
+        ("use_ar", ctypes.c_int32),
+        ("ar_input", ctypes.c_int32),
+        ("ar_hidden", ctypes.c_int32),
+        ("ar_output", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libhificar.so (once) and declare the prototypes.  Raises RuntimeError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C articulatory_amd/csrc`). "
+            "There is no CPU fallback for the generator forward pass."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp = ctypes.c_void_p
+    lib.hificar_create.argtypes = [ctypes.POINTER(HificarConfig), ctypes.POINTER(vp)]
+    lib.hificar_create.restype = ctypes.c_int
+    lib.hificar_set_weight.argtypes = [vp, ctypes.c_char_p, vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+    lib.hificar_set_weight.restype = ctypes.c_int
+    lib.hificar_finalize.argtypes = [vp]
+    lib.hificar_finalize.restype = ctypes.c_int
+    lib.hificar_set_precision.argtypes = [vp, ctypes.c_int]
+    lib.hificar_set_precision.restype = ctypes.c_int
+    lib.hificar_workspace_bytes.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.hificar_workspace_bytes.restype = ctypes.c_size_t
+    lib.hificar_forward.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.hificar_forward.restype = ctypes.c_int
+    lib.hificar_ar_loop.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.hificar_ar_loop.restype = ctypes.c_int
+    lib.hificar_macs.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.hificar_macs.restype = ctypes.c_double
+    lib.hificar_destroy.argtypes = [vp]
+    lib.hificar_destroy.restype = None
+    lib.hificar_last_error.argtypes = []
+    lib.hificar_last_error.restype = ctypes.c_char_p
+    lib.hificar_version.argtypes = []
+    lib.hificar_version.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load_library().hificar_last_error().decode("utf-8", "replace")
+        exc = ValueError if rc == -1 else RuntimeError
+        raise exc(f"{what}: {msg} (hificar error {rc})")
+
+
+def make_config(params: dict, precision: int) -> HificarConfig:
+    """generator_params (reference YAML keys) -> hificar_config."""
+    cfg = HificarConfig()
+    scales = list(params["upsample_scales"])
+    ksizes = list(params["upsample_kernel_sizes"])
+    rks = list(params["resblock_kernel_sizes"])
+    rds = [list(d) for d in params["resblock_dilations"]]
+    if len(scales) > MAX_STAGES or len(rks) > MAX_BLOCKS or any(len(d) > MAX_DILATIONS for d in rds):
+        raise ValueError("generator is larger than the C ABI's fixed-size config arrays")
+    cfg.in_channels = params["in_channels"]
+    cfg.out_channels = params["out_channels"]
+    cfg.channels = params["channels"]
+    cfg.kernel_size = params["kernel_size"]
+    cfg.n_stages = len(scales)
+    for i, (s, k) in enumerate(zip(scales, ksizes)):
+        cfg.upsample_scales[i] = s
+        cfg.upsample_kernel_sizes[i] = k
+    cfg.n_blocks = len(rks)
+    for j, k in enumerate(rks):
+        cfg.resblock_kernel_sizes[j] = k
+        cfg.n_dilations[j] = len(rds[j])
+        for d, v in enumerate(rds[j]):
+            cfg.resblock_dilations[j][d] = v
+    cfg.use_additional_convs = int(params["use_additional_convs"])
+    cfg.bias = int(params["bias"])
+    cfg.lrelu_slope = float(params["nonlinear_activation_params"].get("negative_slope", 0.01))
+    cfg.use_tanh = int(params["use_tanh"])
+    cfg.use_ar = int(params["use_ar"])
+    cfg.ar_input = params["ar_input"]
+    cfg.ar_hidden = params["ar_hidden"]
+    cfg.ar_output = params["ar_output"]
+    cfg.precision = precision
+    return cfg

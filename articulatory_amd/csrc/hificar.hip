@@ -1,0 +1,714 @@
+// libhificar.so — host side of the C ABI declared in include/hificar.h.
+// Builds the layer list of the reference's HiFiGANGenerator (articulatory/models/hifigan.py:108-175)
+// from a hificar_config, repacks folded weights into the kernels' layouts, plans the workspace and
+// enqueues the forward pass / the batched autoregressive loop on the caller's HIP stream.
+#include "hificar_kernels.hip.h"
+
+#include "../../include/hificar.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace hificar;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return fail(HIFICAR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// model description
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct ConvLayer {
+    std::string name;     // reference module path, e.g. "blocks.3.convs1.2.1"
+    bool transposed = false;
+    int cin = 0;          // real input channels
+    int cin_pad = 0;      // row pitch of the input buffer (multiple of 16)
+    int cout = 0;         // real output channels (per phase for transposed)
+    int K = 0, dilation = 1, stride = 1, padding = 0;
+    bool has_bias = true;
+    // derived
+    int n_phase = 1, ntaps = 0, NJ = 4, NB = 128, n_blocks = 0, nb_per_phase = 0, cout_total = 0;
+    int off_min = 0, off_max = 0, chunk = 0;
+    int tap_off[kMaxPhase][kMaxTaps];
+    int tap_k[kMaxPhase][kMaxTaps];  // which kernel index each (phase, tap) uses; -1 = zero weights
+    float* d_w = nullptr;
+    float* d_bias = nullptr;
+};
+
+struct hificar_handle {
+    hificar_config cfg;
+    bool finalized = false;
+    int precision = HIFICAR_PREC_F32;
+    int cf = 0;       // feature channels = in_channels - ar_output*use_ar
+    int cin_pad = 0;  // padded input-conv channels
+    int hop = 1;
+    std::map<std::string, std::vector<int64_t>> expected;  // name -> shape
+    std::map<std::string, HostTensor> tensors;
+    ConvLayer input_conv;
+    std::vector<ConvLayer> ups;
+    std::vector<ConvLayer> convs1;  // [stage][block][dil] flattened
+    std::vector<ConvLayer> convs2;
+    // output conv
+    float* d_out_w = nullptr;
+    float out_bias = 0.f;
+    // MLP
+    float* d_mlp_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* d_mlp_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<void*> allocs;
+};
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+static int stage_channels(const hificar_config& c, int i) { return c.channels >> i; }  // channels // 2**i
+
+static int conv_index(const hificar_handle* h, int stage, int block, int dil) {
+    int idx = 0;
+    for (int b = 0; b < stage * h->cfg.n_blocks + block; ++b) idx += h->cfg.n_dilations[b % h->cfg.n_blocks];
+    return idx + dil;
+}
+
+// Derive tap tables and blocking for one layer.
+static int plan_layer(ConvLayer& L) {
+    if (L.cout % 32 != 0)
+        return fail(HIFICAR_E_INVALID, "%s: output channels (%d) must be a multiple of 32 for the MFMA kernels",
+                    L.name.c_str(), L.cout);
+    L.NB = std::min(128, L.cout);
+    if (L.cout % L.NB != 0) L.NB = (L.cout % 64 == 0) ? 64 : 32;
+    L.NJ = L.NB / 32;
+    if (!L.transposed) {
+        if (L.K > kMaxTaps) return fail(HIFICAR_E_INVALID, "%s: kernel size %d > %d", L.name.c_str(), L.K, kMaxTaps);
+        L.n_phase = 1;
+        L.ntaps = L.K;
+        for (int k = 0; k < L.K; ++k) {
+            L.tap_off[0][k] = k * L.dilation - L.padding;
+            L.tap_k[0][k] = k;
+        }
+    } else {
+        const int s = L.stride, p = L.padding;
+        if (s > kMaxPhase) return fail(HIFICAR_E_INVALID, "%s: upsample scale %d > %d", L.name.c_str(), s, kMaxPhase);
+        L.n_phase = s;
+        L.ntaps = (L.K + s - 1) / s;
+        if (L.ntaps > kMaxTaps) return fail(HIFICAR_E_INVALID, "%s: too many taps", L.name.c_str());
+        for (int r = 0; r < s; ++r) {
+            // out[q*s + r] = sum_k x[q + (r + p - k)/s] * W[:, :, k] over k == (r + p) mod s
+            const int k0 = (r + p) % s;
+            for (int t = 0; t < L.ntaps; ++t) {
+                const int k = k0 + t * s;
+                if (k < L.K) {
+                    L.tap_k[r][t] = k;
+                    L.tap_off[r][t] = (r + p - k) / s;  // exact: r + p - k is a multiple of s
+                } else {
+                    L.tap_k[r][t] = -1;
+                    L.tap_off[r][t] = 0;
+                }
+            }
+        }
+    }
+    L.off_min = 0;
+    L.off_max = 0;
+    for (int r = 0; r < L.n_phase; ++r)
+        for (int t = 0; t < L.ntaps; ++t) {
+            L.off_min = std::min(L.off_min, L.tap_off[r][t]);
+            L.off_max = std::max(L.off_max, L.tap_off[r][t]);
+        }
+    L.cout_total = L.cout * L.n_phase;
+    L.nb_per_phase = L.cout / L.NB;
+    L.n_blocks = L.nb_per_phase * L.n_phase;
+    // input-channel chunk: largest multiple of 8 dividing cin_pad, <= 64
+    L.chunk = 8;
+    for (int c = 8; c <= 64; c += 8)
+        if (L.cin_pad % c == 0) L.chunk = c;
+    return HIFICAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* hificar_last_error(void) { return g_err; }
+extern "C" const char* hificar_version(void) { return "hificar 0.1 gfx950"; }
+
+extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
+    if (!cfg || !out) return fail(HIFICAR_E_INVALID, "hificar_create: null argument");
+    const hificar_config& c = *cfg;
+    if (c.out_channels != 1) return fail(HIFICAR_E_INVALID, "out_channels=%d unsupported (PQMF multi-band output is out of scope)", c.out_channels);
+    if (c.kernel_size % 2 != 1) return fail(HIFICAR_E_INVALID, "Kernel size must be odd number.");
+    if (c.n_stages < 1 || c.n_stages > HIFICAR_MAX_STAGES) return fail(HIFICAR_E_INVALID, "n_stages=%d out of range", c.n_stages);
+    if (c.n_blocks < 1 || c.n_blocks > 3) return fail(HIFICAR_E_INVALID, "n_blocks=%d unsupported (1..3 residual blocks per stage)", c.n_blocks);
+    if (!c.use_additional_convs) return fail(HIFICAR_E_INVALID, "use_additional_convs=false is unsupported");
+    if (c.use_ar && (c.ar_input > 1024 || c.ar_hidden > 1024 || c.ar_output > 1024 || c.ar_input < 1))
+        return fail(HIFICAR_E_INVALID, "PastFCEncoder dims must be <= 1024");
+    if (c.precision != HIFICAR_PREC_F32 && c.precision != HIFICAR_PREC_BF16X3)
+        return fail(HIFICAR_E_INVALID, "unknown precision %d", c.precision);
+    if (c.channels % (1 << c.n_stages) != 0) return fail(HIFICAR_E_INVALID, "channels=%d not divisible by 2^n_stages", c.channels);
+
+    hificar_handle* h = new hificar_handle();
+    h->cfg = c;
+    h->precision = c.precision;
+    h->cf = c.in_channels - (c.use_ar ? c.ar_output : 0);
+    if (h->cf < 1) {
+        delete h;
+        return fail(HIFICAR_E_INVALID, "in_channels=%d leaves no feature channels", c.in_channels);
+    }
+    h->cin_pad = round_up(c.in_channels, 16);
+    h->hop = 1;
+    for (int i = 0; i < c.n_stages; ++i) h->hop *= c.upsample_scales[i];
+
+    int rc = HIFICAR_OK;
+    auto expect = [&](const std::string& n, std::vector<int64_t> s) { h->expected[n] = s; };
+
+    ConvLayer& ic = h->input_conv;
+    ic.name = "input_conv";
+    ic.cin = c.in_channels;
+    ic.cin_pad = h->cin_pad;
+    ic.cout = c.channels;
+    ic.K = c.kernel_size;
+    ic.padding = (c.kernel_size - 1) / 2;
+    rc = plan_layer(ic);
+    expect("input_conv.weight", {c.channels, c.in_channels, c.kernel_size});
+    expect("input_conv.bias", {c.channels});
+
+    for (int i = 0; i < c.n_stages && rc == HIFICAR_OK; ++i) {
+        const int s = c.upsample_scales[i], K = c.upsample_kernel_sizes[i];
+        const int pad = s / 2 + s % 2, opad = s % 2;  // hifigan.py:82-103
+        if (K - 2 * pad + opad != s) {
+            rc = fail(HIFICAR_E_INVALID, "upsample stage %d: kernel %d / scale %d does not give L_out = scale*L_in", i, K, s);
+            break;
+        }
+        ConvLayer u;
+        u.name = "upsamples." + std::to_string(i) + ".1";
+        u.transposed = true;
+        u.cin = u.cin_pad = stage_channels(c, i);
+        u.cout = stage_channels(c, i + 1);
+        u.K = K;
+        u.stride = s;
+        u.padding = pad;
+        if (u.cin_pad % 16 != 0) {
+            rc = fail(HIFICAR_E_INVALID, "stage %d input channels %d must be a multiple of 16", i, u.cin_pad);
+            break;
+        }
+        rc = plan_layer(u);
+        expect(u.name + ".weight", {u.cin, u.cout, K});
+        expect(u.name + ".bias", {u.cout});
+        h->ups.push_back(u);
+        for (int j = 0; j < c.n_blocks && rc == HIFICAR_OK; ++j) {
+            const int k = c.resblock_kernel_sizes[j];
+            if (k % 2 != 1) {
+                rc = fail(HIFICAR_E_INVALID, "Kernel size must be odd number.");
+                break;
+            }
+            if (c.n_dilations[j] < 1 || c.n_dilations[j] > HIFICAR_MAX_DILATIONS) {
+                rc = fail(HIFICAR_E_INVALID, "block %d: n_dilations out of range", j);
+                break;
+            }
+            for (int d = 0; d < c.n_dilations[j] && rc == HIFICAR_OK; ++d) {
+                const std::string base = "blocks." + std::to_string(i * c.n_blocks + j);
+                ConvLayer c1;
+                c1.name = base + ".convs1." + std::to_string(d) + ".1";
+                c1.cin = c1.cin_pad = c1.cout = u.cout;
+                c1.K = k;
+                c1.dilation = c.resblock_dilations[j][d];
+                c1.padding = (k - 1) / 2 * c1.dilation;
+                c1.has_bias = c.bias != 0;
+                rc = plan_layer(c1);
+                ConvLayer c2 = c1;
+                c2.name = base + ".convs2." + std::to_string(d) + ".1";
+                c2.dilation = 1;
+                c2.padding = (k - 1) / 2;
+                if (rc == HIFICAR_OK) rc = plan_layer(c2);
+                for (const ConvLayer* l : {&c1, &c2}) {
+                    expect(l->name + ".weight", {l->cout, l->cin, k});
+                    if (l->has_bias) expect(l->name + ".bias", {l->cout});
+                }
+                h->convs1.push_back(c1);
+                h->convs2.push_back(c2);
+            }
+        }
+    }
+    const int c_last = stage_channels(c, c.n_stages);
+    expect("output_conv.1.weight", {1, c_last, c.kernel_size});
+    expect("output_conv.1.bias", {1});
+    if (c.use_ar) {
+        int dims[6] = {c.ar_input, c.ar_hidden, c.ar_hidden, c.ar_hidden, c.ar_hidden, c.ar_output};
+        for (int l = 0; l < 5; ++l) {
+            expect("ar_model.model." + std::to_string(2 * l) + ".weight", {dims[l + 1], dims[l]});
+            expect("ar_model.model." + std::to_string(2 * l) + ".bias", {dims[l + 1]});
+        }
+    }
+    if (rc != HIFICAR_OK) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return HIFICAR_OK;
+}
+
+extern "C" void hificar_destroy(hificar_handle* h) {
+    if (!h) return;
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" int hificar_set_weight(hificar_handle* h, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!h || !name || !data || !shape) return fail(HIFICAR_E_INVALID, "hificar_set_weight: null argument");
+    if (h->finalized) return fail(HIFICAR_E_STATE, "hificar_set_weight(%s) after hificar_finalize", name);
+    auto it = h->expected.find(name);
+    if (it == h->expected.end()) return fail(HIFICAR_E_INVALID, "unexpected tensor name '%s' for this configuration", name);
+    std::vector<int64_t> s(shape, shape + ndim);
+    if (s != it->second) {
+        std::string want, got;
+        for (auto v : it->second) want += std::to_string(v) + ",";
+        for (auto v : s) got += std::to_string(v) + ",";
+        return fail(HIFICAR_E_INVALID, "size mismatch for %s: expected (%s) got (%s)", name, want.c_str(), got.c_str());
+    }
+    size_t n = 1;
+    for (auto v : s) n *= (size_t)v;
+    HostTensor t;
+    t.shape = s;
+    t.data.assign(data, data + n);
+    h->tensors[name] = std::move(t);
+    return HIFICAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: repack + upload
+// ------------------------------------------------------------------------------------------------
+static int upload(hificar_handle* h, const std::vector<float>& v, float** dptr) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(float)));
+    h->allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dptr = static_cast<float*>(p);
+    return HIFICAR_OK;
+}
+
+static int pack_conv(hificar_handle* h, ConvLayer& L) {
+    const HostTensor& W = h->tensors.at(L.name + ".weight");
+    std::vector<float> wp((size_t)L.n_blocks * L.ntaps * L.cin_pad * L.NB, 0.f);
+    for (int nb = 0; nb < L.n_blocks; ++nb) {
+        const int phase = nb / L.nb_per_phase;
+        const int co0 = (nb % L.nb_per_phase) * L.NB;
+        for (int t = 0; t < L.ntaps; ++t) {
+            const int k = L.tap_k[phase][t];
+            if (k < 0) continue;
+            for (int ci = 0; ci < L.cin; ++ci) {
+                float* dst = &wp[(((size_t)nb * L.ntaps + t) * L.cin_pad + ci) * L.NB];
+                for (int n = 0; n < L.NB; ++n) {
+                    const int co = co0 + n;
+                    // Conv1d weight (Cout, Cin, K); ConvTranspose1d weight (Cin, Cout, K)
+                    const size_t src = L.transposed ? ((size_t)ci * L.cout + co) * L.K + k : ((size_t)co * L.cin + ci) * L.K + k;
+                    dst[n] = W.data[src];
+                }
+            }
+        }
+    }
+    std::vector<float> bias((size_t)L.cout_total, 0.f);
+    if (L.has_bias) {
+        const HostTensor& Bv = h->tensors.at(L.name + ".bias");
+        for (int r = 0; r < L.n_phase; ++r)
+            for (int co = 0; co < L.cout; ++co) bias[(size_t)r * L.cout + co] = Bv.data[co];
+    }
+    int rc = upload(h, wp, &L.d_w);
+    if (rc != HIFICAR_OK) return rc;
+    return upload(h, bias, &L.d_bias);
+}
+
+template <int MI, int NJ, int WM, int WN>
+static hipError_t set_lds_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<MI, NJ, WM, WN>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+extern "C" int hificar_finalize(hificar_handle* h) {
+    if (!h) return fail(HIFICAR_E_INVALID, "hificar_finalize: null handle");
+    if (h->finalized) return HIFICAR_OK;
+    for (auto& kv : h->expected)
+        if (!h->tensors.count(kv.first)) return fail(HIFICAR_E_STATE, "Missing key(s) in state_dict: \"%s\"", kv.first.c_str());
+    int rc;
+    if ((rc = pack_conv(h, h->input_conv)) != HIFICAR_OK) return rc;
+    for (auto& l : h->ups)
+        if ((rc = pack_conv(h, l)) != HIFICAR_OK) return rc;
+    for (auto& l : h->convs1)
+        if ((rc = pack_conv(h, l)) != HIFICAR_OK) return rc;
+    for (auto& l : h->convs2)
+        if ((rc = pack_conv(h, l)) != HIFICAR_OK) return rc;
+    {   // output conv weight (1, C, K) -> [k][C]
+        const HostTensor& W = h->tensors.at("output_conv.1.weight");
+        const int C = (int)W.shape[1], K = (int)W.shape[2];
+        std::vector<float> w((size_t)C * K);
+        for (int ch = 0; ch < C; ++ch)
+            for (int k = 0; k < K; ++k) w[(size_t)k * C + ch] = W.data[(size_t)ch * K + k];
+        if ((rc = upload(h, w, &h->d_out_w)) != HIFICAR_OK) return rc;
+        h->out_bias = h->tensors.at("output_conv.1.bias").data[0];
+    }
+    if (h->cfg.use_ar) {
+        for (int l = 0; l < 5; ++l) {
+            const HostTensor& W = h->tensors.at("ar_model.model." + std::to_string(2 * l) + ".weight");
+            const int dout = (int)W.shape[0], din = (int)W.shape[1];
+            std::vector<float> wt((size_t)din * dout);
+            for (int o = 0; o < dout; ++o)
+                for (int i = 0; i < din; ++i) wt[(size_t)i * dout + o] = W.data[(size_t)o * din + i];
+            if ((rc = upload(h, wt, &h->d_mlp_w[l])) != HIFICAR_OK) return rc;
+            if ((rc = upload(h, h->tensors.at("ar_model.model." + std::to_string(2 * l) + ".bias").data, &h->d_mlp_b[l])) != HIFICAR_OK) return rc;
+        }
+    }
+    HIP_TRY((set_lds_attr<1, 4, 4, 1>()));
+    HIP_TRY((set_lds_attr<1, 4, 2, 2>()));
+    HIP_TRY((set_lds_attr<1, 4, 1, 4>()));
+    HIP_TRY((set_lds_attr<2, 4, 4, 1>()));
+    HIP_TRY((set_lds_attr<1, 2, 4, 1>()));
+    HIP_TRY((set_lds_attr<1, 2, 2, 2>()));
+    HIP_TRY((set_lds_attr<1, 2, 1, 4>()));
+    HIP_TRY((set_lds_attr<2, 2, 4, 1>()));
+    HIP_TRY((set_lds_attr<1, 1, 4, 1>()));
+    HIP_TRY((set_lds_attr<1, 1, 2, 2>()));
+    HIP_TRY((set_lds_attr<1, 1, 1, 4>()));
+    HIP_TRY((set_lds_attr<2, 1, 4, 1>()));
+    HIP_TRY(hipDeviceSynchronize());
+    h->tensors.clear();  // host copies no longer needed
+    h->finalized = true;
+    return HIFICAR_OK;
+}
+
+extern "C" int hificar_set_precision(hificar_handle* h, int precision) {
+    if (!h) return fail(HIFICAR_E_INVALID, "null handle");
+    if (precision == HIFICAR_PREC_F32) {
+        h->precision = precision;
+        return HIFICAR_OK;
+    }
+    return fail(HIFICAR_E_INVALID, "precision %d is not available in this build", precision);
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace plan
+// ------------------------------------------------------------------------------------------------
+struct Workspace {
+    float* xin;
+    float* h0;
+    float* u;
+    float* x[3];
+    float* xt[3];
+    size_t bytes;
+};
+
+static size_t stage_elems(const hificar_handle* h, int B, int T) {
+    size_t mx = 0, L = (size_t)T;
+    for (int i = 0; i < h->cfg.n_stages; ++i) {
+        L *= h->cfg.upsample_scales[i];
+        mx = std::max(mx, L * (size_t)stage_channels(h->cfg, i + 1));
+    }
+    return mx * (size_t)B;
+}
+
+static Workspace plan_workspace(const hificar_handle* h, int B, int T, void* base) {
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t elems) {
+        float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr;
+        off += round_up_sz(elems * sizeof(float), 256);
+        return p;
+    };
+    w.xin = take((size_t)B * T * h->cin_pad);
+    w.h0 = take((size_t)B * T * h->cfg.channels);
+    const size_t se = stage_elems(h, B, T);
+    w.u = take(se);
+    for (int j = 0; j < 3; ++j) w.x[j] = take(se);
+    for (int j = 0; j < 3; ++j) w.xt[j] = take(se);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t hificar_workspace_bytes(const hificar_handle* h, int B, int T) {
+    if (!h || B < 1 || T < 1) return 0;
+    return plan_workspace(h, B, T, nullptr).bytes;
+}
+
+extern "C" double hificar_macs(const hificar_handle* h, int B, int T) {
+    if (!h) return 0.0;
+    const hificar_config& c = h->cfg;
+    double m = (double)T * c.in_channels * c.channels * c.kernel_size;
+    double L = T;
+    for (int i = 0; i < c.n_stages; ++i) {
+        const double cin = stage_channels(c, i), cout = stage_channels(c, i + 1);
+        m += L * cin * cout * c.upsample_kernel_sizes[i];
+        L *= c.upsample_scales[i];
+        for (int j = 0; j < c.n_blocks; ++j) m += L * cout * cout * c.resblock_kernel_sizes[j] * 2.0 * c.n_dilations[j];
+    }
+    m += L * stage_channels(c, c.n_stages) * c.kernel_size;
+    if (c.use_ar) m += (double)c.ar_input * c.ar_hidden + 3.0 * c.ar_hidden * c.ar_hidden + (double)c.ar_hidden * c.ar_output;
+    return m * B;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------------
+struct TileCfg {
+    int MI, WM, WN;
+};
+static const TileCfg kTileCfgs[4] = {{2, 4, 1}, {1, 4, 1}, {1, 2, 2}, {1, 1, 4}};
+
+static TileCfg pick_tile(const ConvLayer& L, int rows) {
+    TileCfg best = kTileCfgs[1];
+    double best_cost = 1e300;
+    for (const TileCfg& t : kTileCfgs) {
+        const int TM = t.WM * t.MI * 32;
+        if (t.MI == 2 && L.NJ > 2) continue;  // MI=2 only where channels are few (register budget)
+        const double padded_rows = (double)((rows + TM - 1) / TM) * TM;
+        const double padded_blocks = (double)((L.n_blocks + t.WN - 1) / t.WN) * t.WN;
+        const double cost = padded_rows * padded_blocks;
+        if (cost < best_cost - 0.5) {  // ties keep the earlier (larger-TM) entry
+            best_cost = cost;
+            best = t;
+        }
+    }
+    return best;
+}
+
+static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, const float* const* xin, int nin,
+                        const float* res, float* y, float slope) {
+    p.x0 = xin[0];
+    p.x1 = nin > 1 ? xin[1] : nullptr;
+    p.x2 = nin > 2 ? xin[2] : nullptr;
+    p.w = L.d_w;
+    p.bias = L.d_bias;
+    p.res = res;
+    p.y = y;
+    p.L = rows;
+    p.tiles_per_seq = (rows + TM - 1) / TM;
+    p.cin = L.cin_pad;
+    p.cout_total = L.cout_total;
+    p.chunk = L.chunk;
+    p.n_blocks = L.n_blocks;
+    p.nb_per_phase = L.nb_per_phase;
+    p.ntaps = L.ntaps;
+    p.off_min = L.off_min;
+    p.halo = L.off_max - L.off_min;
+    p.nin = nin;
+    p.slope = slope;
+    memcpy(p.tap_off, L.tap_off, sizeof(p.tap_off));
+}
+
+template <int MI, int NJ, int WM, int WN>
+static hipError_t launch_conv_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<MI, NJ, WM, WN>), grid, dim3(256), lds, stream, mp);
+    return hipGetLastError();
+}
+
+// Launch nbr (1..3) same-shape conv layers ("branches") as one grid; branch = blockIdx.z.
+static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows,
+                       const float* (*xin)[3], int nin, const float* const* res, float* const* y, float slope,
+                       hipStream_t stream) {
+    const ConvLayer& L0 = *layers[0];
+    const TileCfg tc = pick_tile(L0, rows);
+    const int TM = tc.WM * tc.MI * 32;
+    MultiConvParams mp;
+    memset(&mp, 0, sizeof(mp));
+    int max_halo = 0;
+    for (int b = 0; b < nbr; ++b) {
+        fill_params(mp.p[b], *layers[b], rows, TM, xin[b], nin, res ? res[b] : nullptr, y[b], slope);
+        max_halo = std::max(max_halo, mp.p[b].halo);
+        if (layers[b]->NJ != L0.NJ || layers[b]->n_blocks != L0.n_blocks || layers[b]->chunk != L0.chunk)
+            return fail(HIFICAR_E_INVALID, "internal: branch shape mismatch");
+    }
+    const size_t lds = (size_t)(TM + max_halo) * (L0.chunk + 4) * sizeof(float);
+    if (lds > 160 * 1024) return fail(HIFICAR_E_INVALID, "internal: LDS tile too large (%zu)", lds);
+    dim3 grid((unsigned)(nseq * ((rows + TM - 1) / TM)), (unsigned)((L0.n_blocks + tc.WN - 1) / tc.WN), (unsigned)nbr);
+    hipError_t e = hipErrorInvalidValue;
+#define HIFICAR_DISPATCH(mi, nj, wm, wn)                                              \
+    if (tc.MI == mi && L0.NJ == nj && tc.WM == wm && tc.WN == wn) e = launch_conv_t<mi, nj, wm, wn>(mp, grid, lds, stream);
+    HIFICAR_DISPATCH(1, 4, 4, 1)
+    HIFICAR_DISPATCH(1, 4, 2, 2)
+    HIFICAR_DISPATCH(1, 4, 1, 4)
+    HIFICAR_DISPATCH(2, 4, 4, 1)
+    HIFICAR_DISPATCH(1, 2, 4, 1)
+    HIFICAR_DISPATCH(1, 2, 2, 2)
+    HIFICAR_DISPATCH(1, 2, 1, 4)
+    HIFICAR_DISPATCH(2, 2, 4, 1)
+    HIFICAR_DISPATCH(1, 1, 4, 1)
+    HIFICAR_DISPATCH(1, 1, 2, 2)
+    HIFICAR_DISPATCH(1, 1, 1, 4)
+    HIFICAR_DISPATCH(2, 1, 4, 1)
+#undef HIFICAR_DISPATCH
+    if (e != hipSuccess) return fail(HIFICAR_E_HIP, "conv launch (%s) failed: %s", L0.name.c_str(), hipGetErrorString(e));
+    return HIFICAR_OK;
+}
+
+// One generator forward on B sequences of T frames.
+//   c: element (b, ch, t) at c[b*c_bstride + ch*c_cstride + t];  prev: (b, i) at prev[b*prev_bstride + i] or null
+//   out: sample (b, n) at out[b*out_bstride + n]
+static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, int64_t c_cstride, const float* prev,
+                        int64_t prev_bstride, float* out, int64_t out_bstride, int B, int T, const Workspace& ws,
+                        hipStream_t stream) {
+    const hificar_config& cfg = h->cfg;
+    // 1. front end
+    FrontParams fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.c = c;
+    fp.c_bstride = c_bstride;
+    fp.c_cstride = c_cstride;
+    fp.prev = prev;
+    fp.prev_bstride = prev_bstride;
+    fp.xin = ws.xin;
+    fp.T = T;
+    fp.cf = h->cf;
+    fp.cin_pad = h->cin_pad;
+    fp.use_ar = cfg.use_ar;
+    fp.ar_input = cfg.ar_input;
+    fp.ar_hidden = cfg.ar_hidden;
+    fp.ar_output = cfg.ar_output;
+    for (int l = 0; l < 5; ++l) {
+        fp.wt[l] = h->d_mlp_w[l];
+        fp.bs[l] = h->d_mlp_b[l];
+    }
+    hipLaunchKernelGGL(front_kernel, dim3(B), dim3(256), 0, stream, fp);
+    HIP_TRY(hipGetLastError());
+
+    int rc;
+    // 2. input conv (no activation in front of it: hifigan.py:221)
+    {
+        const ConvLayer* lay[1] = {&h->input_conv};
+        const float* xin[1][3] = {{ws.xin, nullptr, nullptr}};
+        float* y[1] = {ws.h0};
+        if ((rc = launch_conv(h, lay, 1, B, T, xin, 1, nullptr, y, 1.0f, stream)) != HIFICAR_OK) return rc;
+    }
+    // 3. stages
+    int rows = T;
+    const int nbk = cfg.n_blocks;
+    for (int i = 0; i < cfg.n_stages; ++i) {
+        {   // LeakyReLU + ConvTranspose1d (hifigan.py:224); input = previous stage's MRF mean
+            const ConvLayer* lay[1] = {&h->ups[i]};
+            const float* xin[1][3] = {{i == 0 ? ws.h0 : ws.x[0], i == 0 ? nullptr : (nbk > 1 ? ws.x[1] : nullptr),
+                                       i == 0 ? nullptr : (nbk > 2 ? ws.x[2] : nullptr)}};
+            float* y[1] = {ws.u};
+            if ((rc = launch_conv(h, lay, 1, B, rows, xin, i == 0 ? 1 : nbk, nullptr, y, cfg.lrelu_slope, stream)) != HIFICAR_OK)
+                return rc;
+        }
+        rows *= cfg.upsample_scales[i];
+        // residual blocks (residual_block.py:217-221); blocks run side by side, heaviest kernel size first
+        int order[3] = {0, 1, 2};
+        std::sort(order, order + nbk, [&](int a, int b) { return cfg.resblock_kernel_sizes[a] > cfg.resblock_kernel_sizes[b]; });
+        int max_d = 0;
+        for (int j = 0; j < nbk; ++j) max_d = std::max(max_d, cfg.n_dilations[j]);
+        for (int d = 0; d < max_d; ++d) {
+            const ConvLayer* l1[3];
+            const ConvLayer* l2[3];
+            const float* in1[3][3];
+            const float* in2[3][3];
+            const float* res[3];
+            float* y1[3];
+            float* y2[3];
+            int n = 0;
+            for (int oj = 0; oj < nbk; ++oj) {
+                const int j = order[oj];
+                if (d >= cfg.n_dilations[j]) continue;
+                const int ci = conv_index(h, i, j, d);
+                l1[n] = &h->convs1[ci];
+                l2[n] = &h->convs2[ci];
+                const float* xcur = d == 0 ? ws.u : ws.x[j];
+                in1[n][0] = xcur; in1[n][1] = nullptr; in1[n][2] = nullptr;
+                y1[n] = ws.xt[j];
+                in2[n][0] = ws.xt[j]; in2[n][1] = nullptr; in2[n][2] = nullptr;
+                res[n] = xcur;
+                y2[n] = ws.x[j];
+                ++n;
+            }
+            if ((rc = launch_conv(h, l1, n, B, rows, in1, 1, nullptr, y1, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+            if ((rc = launch_conv(h, l2, n, B, rows, in2, 1, res, y2, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+        }
+        // a block with fewer dilations than another keeps its last x[j]; nothing to do
+    }
+    // 4. output conv: LeakyReLU(0.01) + Conv1d + tanh (hifigan.py:146-159)
+    OutConvParams op;
+    memset(&op, 0, sizeof(op));
+    op.x0 = ws.x[0];
+    op.x1 = nbk > 1 ? ws.x[1] : nullptr;
+    op.x2 = nbk > 2 ? ws.x[2] : nullptr;
+    op.nin = nbk;
+    op.w = h->d_out_w;
+    op.bias = h->out_bias;
+    op.out = out;
+    op.out_bstride = out_bstride;
+    op.L = rows;
+    op.C = stage_channels(cfg, cfg.n_stages);
+    op.K = cfg.kernel_size;
+    op.slope = 0.01f;
+    op.use_tanh = cfg.use_tanh;
+    const size_t lds = ((size_t)(256 + op.K - 1) * (op.C + 1) + (size_t)op.K * op.C) * sizeof(float);
+    hipLaunchKernelGGL(output_conv_kernel, dim3((rows + 255) / 256, B), dim3(256), lds, stream, op);
+    HIP_TRY(hipGetLastError());
+    return HIFICAR_OK;
+}
+
+static int check_ready(hificar_handle* h, int B, int T, void* ws, size_t ws_bytes) {
+    if (!h) return fail(HIFICAR_E_INVALID, "null handle");
+    if (!h->finalized) return fail(HIFICAR_E_STATE, "hificar_finalize has not been called");
+    if (B < 1 || T < 1) return fail(HIFICAR_E_INVALID, "B=%d, T=%d must be positive", B, T);
+    const size_t need = hificar_workspace_bytes(h, B, T);
+    if (!ws || ws_bytes < need) return fail(HIFICAR_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
+    if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) return fail(HIFICAR_E_INVALID, "workspace must be 256-byte aligned");
+    return HIFICAR_OK;
+}
+
+extern "C" int hificar_forward(hificar_handle* h, const float* c, const float* ar, float* out, int B, int T, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    int rc = check_ready(h, B, T, workspace, workspace_bytes);
+    if (rc != HIFICAR_OK) return rc;
+    if (!c || !out) return fail(HIFICAR_E_INVALID, "hificar_forward: null tensor");
+    if (h->cfg.use_ar && !ar) return fail(HIFICAR_E_INVALID, "use_ar model needs the ar context (got NULL)");
+    const Workspace ws = plan_workspace(h, B, T, workspace);
+    return forward_impl(h, c, (int64_t)h->cf * T, T, h->cfg.use_ar ? ar : nullptr, h->cfg.ar_input, out,
+                        (int64_t)h->hop * T, B, T, ws, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hificar_ar_loop(hificar_handle* h, const float* c, float* out, int B, int T_total, int chunk_frames,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (h && !h->cfg.use_ar) return fail(HIFICAR_E_INVALID, "hificar_ar_loop on a model built with use_ar=false");
+    if (chunk_frames < 1) return fail(HIFICAR_E_INVALID, "chunk_frames=%d must be positive", chunk_frames);
+    int rc = check_ready(h, B, std::min(chunk_frames, std::max(T_total, 1)), workspace, workspace_bytes);
+    if (rc != HIFICAR_OK) return rc;
+    if (T_total < 1) return fail(HIFICAR_E_INVALID, "T_total=%d must be positive", T_total);
+    if (!c || !out) return fail(HIFICAR_E_INVALID, "hificar_ar_loop: null tensor");
+    if (h->cfg.ar_input > h->hop * chunk_frames && T_total > chunk_frames)
+        return fail(HIFICAR_E_INVALID, "ar_input (%d) > chunk audio length (%d): the reference loop (decode.py:79-81) is ill-formed there",
+                    h->cfg.ar_input, h->hop * chunk_frames);
+    const int Tc = std::min(chunk_frames, T_total);
+    const Workspace ws = plan_workspace(h, B, Tc, workspace);
+    const int64_t out_bstride = (int64_t)h->hop * T_total;
+    for (int f0 = 0; f0 < T_total; f0 += chunk_frames) {
+        const int Tn = std::min(chunk_frames, T_total - f0);
+        const int64_t pos = (int64_t)h->hop * f0;
+        // prev = last ar_input samples already written for this utterance (zeros for the first chunk)
+        const float* prev = f0 == 0 ? nullptr : out + pos - h->cfg.ar_input;
+        rc = forward_impl(h, c + f0, (int64_t)h->cf * T_total, T_total, prev, out_bstride, out + pos, out_bstride, B, Tn, ws,
+                          static_cast<hipStream_t>(stream));
+        if (rc != HIFICAR_OK) return rc;
+    }
+    return HIFICAR_OK;
+}

@@ -1,0 +1,336 @@
+// HIP kernels for the HiFi-GAN / HiFi-CAR generator forward pass on gfx950 (CDNA4, wave64).
+//
+// Internal activation layout is CHANNELS-LAST: (sequence, time, channel) fp32 with the channel
+// axis contiguous.  The reference's (B, C, T) layout exists only at the C-ABI boundary (feature
+// input, waveform output), which `front_kernel` / `output_conv_kernel` convert on the fly.
+// Channels-last makes every halo a whole-row affair (zero rows outside [0, L) reproduce the
+// reference's per-conv zero padding exactly), keeps global loads 16-byte aligned for any tap
+// offset, and puts the GEMM reduction axis (input channels) contiguous for MFMA operand reads.
+//
+// Every Conv1d and every ConvTranspose1d of the generator runs through ONE implicit-GEMM kernel
+// family (`conv_mfma_f32_kernel`):  D[t, co] = sum_{tap} sum_{ci} act(X)[t + off(tap), ci] * W[tap][ci][co]
+// with M = time, N = output channels, K = taps x input channels.  A ConvTranspose1d with K = 2*stride
+// is the same contraction with N = stride*Cout "virtual" channels (phase-major) and per-phase tap
+// lists, because out[(q*s + r), co] in channels-last memory IS row q, column r*Cout + co.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hificar {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxPhase = 8;
+constexpr int kMaxTaps = 16;
+
+// The A operand (activations) is produced while staging into LDS from `nin` inputs:
+//   nin = 1: x0;  nin = 2: (x0 + x1) / 2;  nin = 3: ((x0 + x1) + x2) / 3
+// (the MRF mean `cs / num_blocks` of reference hifigan.py:226-230, summed in the reference's order).
+
+struct ConvParams {
+    const float* x0;
+    const float* x1;
+    const float* x2;
+    const float* w;     // packed [n_block][tap][ci][NB]
+    const float* bias;  // [cout_total] (never null; zeros when the layer has no bias)
+    const float* res;   // residual, same layout as y, or null
+    float* y;
+    int L;              // rows (time steps) per sequence, input rows == output rows
+    int tiles_per_seq;  // ceil(L / TM)
+    int cin;            // padded input channels == row pitch of x*
+    int cout_total;     // row pitch of y / res / bias length
+    int chunk;          // input-channel chunk staged per pass (multiple of 8, divides cin)
+    int n_blocks;       // number of NB-wide output blocks (cout_total / NB)
+    int nb_per_phase;   // n_blocks / n_phase
+    int ntaps;          // taps per phase (same for all phases; missing taps have zero weights)
+    int off_min;        // min over all tap offsets (<= 0)
+    int halo;           // off_max - off_min
+    int nin;            // number of inputs averaged while staging (1..3)
+    float slope;        // LeakyReLU slope applied to the staged input; 1.0f = identity
+    int tap_off[kMaxPhase][kMaxTaps];
+};
+
+struct MultiConvParams {
+    ConvParams p[3];
+};
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+// ------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
+//
+//   workgroup = 4 waves arranged WM (time) x WN (channel blocks); a wave owns MI x NJ MFMA tiles
+//   of 32x32, i.e. MI*32 time rows x NB = NJ*32 output channels.  TM = WM*MI*32 rows per workgroup.
+//   grid = (sequences * tiles_per_seq, ceil(n_blocks / WN), branches)
+//
+//   LDS holds act(X)[t0 + off_min .. t0 + TM + off_max) x chunk channels, row pitch chunk+4 floats
+//   (pitch/4 odd => the ds_read_b128 of 16 lanes x distinct rows hit 16 distinct 16-byte slots).
+//   Weights are NOT staged: each lane's B operand is a contiguous float<NJ> of the packed weight
+//   row, 512 B per half-wave, L1/L2-served (the whole 54 MB model sits in the 256 MB Infinity Cache).
+//
+//   MFMA operand maps (32x32x2 f32): A lane l -> A[i = l&31][k = l>>5], B lane l -> B[k = l>>5][n = l&31],
+//   D reg r -> D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].  K is consumed 8 channels at a time:
+//   the half-wave g = l>>5 takes channels c8 + 4g .. c8 + 4g + 3 (one b128 LDS read = 4 MFMA steps).
+//   Output column n of tile j is channel NJ*n + j, so a lane's NJ accumulators of one row are NJ
+//   adjacent floats in memory (vector store).
+// ------------------------------------------------------------------------------------------------
+template <int MI, int NJ, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const MultiConvParams mp) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int NB = NJ * 32;
+    constexpr int TM = WM * MI * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const ConvParams& p = mp.p[blockIdx.z];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int li = lane & 31;
+    const int g = lane >> 5;
+
+    const int seq = blockIdx.x / p.tiles_per_seq;
+    const int t0 = (blockIdx.x % p.tiles_per_seq) * TM;
+    const int nb = blockIdx.y * WN + wn;
+    const bool active = nb < p.n_blocks;
+    const int phase = active ? nb / p.nb_per_phase : 0;
+
+    const int P = p.chunk + 4;            // LDS row pitch (floats)
+    const int R = TM + p.halo;            // staged rows
+    const int c4n = p.chunk >> 2;         // float4 per staged row
+    const size_t seq_base = (size_t)seq * p.L;
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.f;
+
+    const float* wblk = p.w + (size_t)(active ? nb : 0) * p.ntaps * p.cin * NB;
+    const int wave_row0 = wm * (MI * 32);
+    const float slope = p.slope;
+    const float* tapoff = nullptr;
+    (void)tapoff;
+
+    for (int c0 = 0; c0 < p.cin; c0 += p.chunk) {
+        __syncthreads();
+        // ---- stage act(X)[rows, c0 : c0+chunk] into LDS (zero rows outside the sequence) ----
+        for (int idx = tid; idx < R * c4n; idx += 256) {
+            const int r = idx / c4n;
+            const int c4 = idx - r * c4n;
+            const int t = t0 + p.off_min + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t < p.L) {
+                const size_t off = (seq_base + t) * p.cin + c0 + c4 * 4;
+                v = *reinterpret_cast<const f32x4*>(p.x0 + off);
+                if (p.nin == 3) {
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.x1 + off);
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(p.x2 + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((v[e] + v1[e]) + v2[e]) / 3.0f;
+                } else if (p.nin == 2) {
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.x1 + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] + v1[e]) / 2.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], slope);
+            }
+            *reinterpret_cast<f32x4*>(&smem[r * P + c4 * 4]) = v;
+        }
+        __syncthreads();
+        if (!active) continue;
+        // ---- MFMA over taps x channels of this chunk ----
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int roff = p.tap_off[phase][t] - p.off_min;  // >= 0
+            const float* arow = &smem[(wave_row0 + li + roff) * P + 4 * g];
+            const float* wrow = wblk + ((size_t)t * p.cin + c0 + 4 * g) * NB + NJ * li;
+            for (int c8 = 0; c8 < p.chunk; c8 += 8) {
+                f32x4 a[MI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(arow + mi * 32 * P + c8);
+                float b[4][NJ];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float* wp = wrow + (size_t)(c8 + s) * NB;
+                    if constexpr (NJ == 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(wp);
+                        b[s][0] = v[0]; b[s][1] = v[1]; b[s][2] = v[2]; b[s][3] = v[3];
+                    } else if constexpr (NJ == 2) {
+                        const f32x2 v = *reinterpret_cast<const f32x2*>(wp);
+                        b[s][0] = v[0]; b[s][1] = v[1];
+                    } else {
+                        b[s][0] = *wp;
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[s][j], acc[mi][j], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+
+    // ---- epilogue: + bias (+ residual), vector store of NJ adjacent channels per row ----
+    const int co = nb * NB + NJ * li;
+    float bj[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bj[j] = p.bias[co + j];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave_row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const int t = t0 + row;
+            if (t < p.L) {
+                const size_t off = (seq_base + t) * p.cout_total + co;
+                float v[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) v[j] = acc[mi][j][r] + bj[j];
+                if (p.res) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) v[j] += p.res[off + j];
+                }
+                if constexpr (NJ == 4) {
+                    *reinterpret_cast<f32x4*>(p.y + off) = f32x4{v[0], v[1], v[2], v[3]};
+                } else if constexpr (NJ == 2) {
+                    *reinterpret_cast<f32x2*>(p.y + off) = f32x2{v[0], v[1]};
+                } else {
+                    p.y[off] = v[0];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Front end: PastFCEncoder (reference pytorch_layers.py:438-460) + feature transpose + AR concat
+// (reference hifigan.py:208-211).  One workgroup per utterance.
+//   xin[b, t, 0:cf]        = c[b, :, t]                (features, (B, C, T) -> channels-last)
+//   xin[b, t, cf:cf+ar_out] = MLP(prev[b, :])          (time-constant AR channels)
+//   xin[b, t, rest]        = 0                         (pad to a multiple of 16 channels)
+// MLP weights are stored transposed (in, out) so that thread j's reads are coalesced over j.
+// ------------------------------------------------------------------------------------------------
+struct FrontParams {
+    const float* c;       // features; element (b, ch, t) at c[b*c_bstride + ch*c_cstride + t]
+    int64_t c_bstride;
+    int64_t c_cstride;
+    const float* prev;    // AR context; element (b, i) at prev[b*prev_bstride + i]; null => zeros
+    int64_t prev_bstride;
+    float* xin;           // (B, T, cin_pad)
+    int T;
+    int cf;               // feature channels
+    int cin_pad;
+    int use_ar;
+    int ar_input, ar_hidden, ar_output;
+    const float* wt[5];   // transposed Linear weights (in, out)
+    const float* bs[5];
+};
+
+__global__ __launch_bounds__(256) void front_kernel(const FrontParams p) {
+    __shared__ float bufA[1024];
+    __shared__ float bufB[1024];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    float* cur = bufA;
+    float* nxt = bufB;
+    if (p.use_ar) {
+        for (int i = tid; i < p.ar_input; i += 256) cur[i] = p.prev ? p.prev[(size_t)b * p.prev_bstride + i] : 0.f;
+        __syncthreads();
+        int din = p.ar_input;
+        for (int layer = 0; layer < 5; ++layer) {
+            const int dout = layer == 4 ? p.ar_output : p.ar_hidden;
+            const float* wt = p.wt[layer];
+            for (int j = tid; j < dout; j += 256) {
+                float s = p.bs[layer][j];
+                for (int i = 0; i < din; ++i) s = fmaf(cur[i], wt[(size_t)i * dout + j], s);
+                nxt[j] = layer < 4 ? lrelu(s, 0.1f) : s;
+            }
+            __syncthreads();
+            float* tmp = cur; cur = nxt; nxt = tmp;
+            din = dout;
+        }
+    }
+    // cur[0:ar_output] now holds the AR features
+    const int n = p.T * p.cin_pad;
+    float* xo = p.xin + (size_t)b * n;
+    for (int idx = tid; idx < n; idx += 256) {
+        const int t = idx / p.cin_pad;
+        const int ch = idx - t * p.cin_pad;
+        float v = 0.f;
+        if (ch < p.cf) v = p.c[(size_t)b * p.c_bstride + (size_t)ch * p.c_cstride + t];
+        else if (p.use_ar && ch < p.cf + p.ar_output) v = cur[ch - p.cf];
+        xo[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output conv: LeakyReLU(0.01) -> Conv1d(C -> 1, k) -> tanh (reference hifigan.py:146-159, 231), reading
+// the MRF mean of the last stage's three ResBlock outputs on the fly.  C*k = 224 MACs per sample
+// (0.015 % of the path): a plain VALU kernel, one output sample per thread, input rows staged in LDS.
+// Writes the waveform in the boundary layout: out[b*out_bstride + t].
+// ------------------------------------------------------------------------------------------------
+struct OutConvParams {
+    const float* x0;
+    const float* x1;
+    const float* x2;
+    int nin;           // inputs averaged (1..3), as in ConvParams
+    const float* w;    // [k][C]
+    float bias;
+    float* out;
+    int64_t out_bstride;
+    int L;             // samples per sequence
+    int C;
+    int K;
+    float slope;
+    int use_tanh;
+};
+
+__global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int seq = blockIdx.y;
+    const int t0 = blockIdx.x * 256;
+    const int pad = (p.K - 1) / 2;
+    const int R = 256 + p.K - 1;
+    const int P = p.C + 1;
+    float* ws = smem + R * P;  // weights [k][C]
+    for (int i = tid; i < p.K * p.C; i += 256) ws[i] = p.w[i];
+    const size_t base = (size_t)seq * p.L;
+    for (int idx = tid; idx < R * p.C; idx += 256) {
+        const int r = idx / p.C;
+        const int ch = idx - r * p.C;
+        const int t = t0 - pad + r;
+        float v = 0.f;
+        if (t >= 0 && t < p.L) {
+            const size_t off = (base + t) * p.C + ch;
+            v = p.x0[off];
+            if (p.nin == 3) v = ((v + p.x1[off]) + p.x2[off]) / 3.0f;
+            else if (p.nin == 2) v = (v + p.x1[off]) / 2.0f;
+            v = lrelu(v, p.slope);
+        }
+        smem[r * P + ch] = v;
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t < p.L) {
+        float s = p.bias;
+        for (int k = 0; k < p.K; ++k) {
+            const float* xr = &smem[(tid + k) * P];
+            const float* wk = &ws[k * p.C];
+            for (int ch = 0; ch < p.C; ++ch) s = fmaf(xr[ch], wk[ch], s);
+        }
+        p.out[(size_t)seq * p.out_bstride + t] = p.use_tanh ? tanhf(s) : s;
+    }
+}
+
+}  // namespace hificar

@@ -1,0 +1,409 @@
+"""HiFi-GAN / HiFi-CAR generator behind the reference's ``generator_type`` plugin surface.
+
+Drop-in for ``articulatory.models.HiFiGANGenerator`` (reference articulatory/models/hifigan.py:21-314)
+on the *inference* path: same class name, same constructor keywords (so the shipped YAMLs'
+``generator_params`` construct it unchanged; ``final_scale`` / ``extra_art``, which make
+``e2w_hifigan_car.yaml`` fail on the reference class, are accepted and ignored), same parameter
+names and shapes (so reference checkpoints ``load_state_dict`` unchanged, weight-norm keys
+included), same ``forward(c, spk_id=None, ar=None, ph=None)`` / ``inference`` / ``remove_weight_norm`` /
+``apply_weight_norm`` / ``register_stats`` methods.
+
+What differs is where the arithmetic runs: this module owns the parameters only.  ``forward`` hands
+device pointers to ``libhificar.so`` (hand-written HIP kernels for gfx950, C ABI in
+include/hificar.h).  There is no PyTorch-operator implementation of the network in this package and
+no CPU fallback: calling ``forward`` on a CPU tensor, without a GPU, or without the built library
+raises.  Training (autograd through the generator) is scope row f1 in SURVEY.md §8 and raises
+NotImplementedError.
+"""
+
+import ctypes
+import logging
+import math
+
+import numpy as np
+import torch
+
+from .. import _native
+
+
+def _fold(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """w = v * g / ||v||, norm over every dim but 0 (torch.nn.utils.weight_norm(dim=0) semantics,
+    which the reference applies at hifigan.py:268-278 and bakes at :256-266)."""
+    norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(g.shape)
+    return v * (g / norm)
+
+
+class _ConvParams(torch.nn.Module):
+    """Parameter holder for one Conv1d / ConvTranspose1d of the reference, with or without weight norm.
+
+    Registration order matches torch's weight-normed modules (bias, weight_g, weight_v) so that
+    ``state_dict()`` key order equals the reference's.
+    """
+
+    def __init__(self, weight_shape, n_bias, bias=True, fan_in=None):
+        super().__init__()
+        self.weight_shape = tuple(weight_shape)
+        fan_in = fan_in or int(np.prod(weight_shape[1:]))
+        bound = 1.0 / math.sqrt(fan_in)
+        if bias:
+            self.bias = torch.nn.Parameter(torch.empty(n_bias).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        # torch's default Conv init: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+        self.weight = torch.nn.Parameter(torch.empty(self.weight_shape).uniform_(-bound, bound))
+
+    @property
+    def has_weight_norm(self):
+        return "weight_g" in self._parameters
+
+    def apply_weight_norm(self):
+        if self.has_weight_norm:
+            return
+        w = self._parameters.pop("weight").detach()
+        g = w.reshape(w.shape[0], -1).norm(dim=1).reshape((w.shape[0],) + (1,) * (w.dim() - 1))
+        self.weight_g = torch.nn.Parameter(g)
+        self.weight_v = torch.nn.Parameter(w.clone())
+
+    def remove_weight_norm(self):
+        if not self.has_weight_norm:
+            raise ValueError("weight_norm not found")
+        w = self.folded_weight()
+        del self._parameters["weight_g"]
+        del self._parameters["weight_v"]
+        self.weight = torch.nn.Parameter(w)
+
+    def folded_weight(self) -> torch.Tensor:
+        if self.has_weight_norm:
+            return _fold(self.weight_v.detach(), self.weight_g.detach())
+        return self.weight.detach()
+
+
+class _ResBlockParams(torch.nn.Module):
+    """Parameters of one HiFiGANResidualBlock (reference articulatory/layers/residual_block.py:141-205)."""
+
+    def __init__(self, kernel_size, channels, dilations, bias, use_additional_convs, slope):
+        super().__init__()
+        assert kernel_size % 2 == 1, "Kernel size must be odd number."
+
+        def slot():
+            return torch.nn.Sequential(torch.nn.LeakyReLU(slope), _ConvParams((channels, channels, kernel_size), channels, bias))
+
+        self.convs1 = torch.nn.ModuleList([slot() for _ in dilations])
+        if use_additional_convs:
+            self.convs2 = torch.nn.ModuleList([slot() for _ in dilations])
+
+
+class _PastFCParams(torch.nn.Module):
+    """Parameters of PastFCEncoder (reference articulatory/layers/pytorch_layers.py:426-449)."""
+
+    def __init__(self, input_len, hidden_dim, output_dim):
+        super().__init__()
+        dims = [input_len] + [hidden_dim] * 4 + [output_dim]
+        mods = []
+        for i in range(5):
+            mods.append(torch.nn.Linear(dims[i], dims[i + 1]))
+            if i < 4:
+                mods.append(torch.nn.LeakyReLU(0.1))
+        self.model = torch.nn.Sequential(*mods)
+
+
+class HiFiGANGenerator(torch.nn.Module):
+    """HiFiGAN generator module (MI355X-native forward)."""
+
+    def __init__(
+        self,
+        in_channels=80,
+        out_channels=1,
+        channels=512,
+        kernel_size=7,
+        upsample_scales=(8, 8, 2, 2),
+        upsample_kernel_sizes=(16, 16, 4, 4),
+        paddings=None,
+        output_paddings=None,
+        resblock_kernel_sizes=(3, 7, 11),
+        resblock_dilations=[(1, 3, 5), (1, 3, 5), (1, 3, 5)],
+        use_additional_convs=True,
+        bias=True,
+        nonlinear_activation="LeakyReLU",
+        nonlinear_activation_params={"negative_slope": 0.1},
+        use_weight_norm=True,
+        use_ar=False,
+        ar_input=512,
+        ar_hidden=256,
+        ar_output=128,
+        use_tanh=True,
+        use_spk_id=False,
+        num_spk=None,
+        spk_emb_size=32,
+        use_ph=False,
+        num_ph=None,
+        ph_emb_size=8,
+        use_ph_loss=False,
+        final_scale=None,  # present in e2w_hifigan_car.yaml:42; unused by the network
+        extra_art=None,  # present in e2w_hifigan_car.yaml:54; only read by the WSOLA driver
+        precision="f32",
+    ):
+        super().__init__()
+        # same validity checks as the reference (hifigan.py:78-80)
+        assert kernel_size % 2 == 1, "Kernel size must be odd number."
+        assert len(upsample_scales) == len(upsample_kernel_sizes)
+        assert len(resblock_dilations) == len(resblock_kernel_sizes)
+        if use_spk_id or use_ph or use_ph_loss:
+            raise NotImplementedError("use_spk_id / use_ph / use_ph_loss are not built yet (SURVEY.md §8 row f4)")
+        if nonlinear_activation != "LeakyReLU":
+            raise NotImplementedError(f"nonlinear_activation={nonlinear_activation!r}: only LeakyReLU is built")
+        for name, val in (("paddings", paddings), ("output_paddings", output_paddings)):
+            if val is not None and any(v != "default" for v in val):
+                raise NotImplementedError(f"{name}: only None / 'default' entries are supported (as in the reference)")
+        if precision not in _native.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_native.PRECISIONS)}")
+
+        self.use_ar = use_ar
+        self.use_spk_id = use_spk_id
+        self.use_ph = use_ph
+        self.use_ph_loss = use_ph_loss
+        self.num_upsamples = len(upsample_kernel_sizes)
+        self.num_blocks = len(resblock_kernel_sizes)
+        slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self._params = dict(
+            in_channels=in_channels, out_channels=out_channels, channels=channels, kernel_size=kernel_size,
+            upsample_scales=list(upsample_scales), upsample_kernel_sizes=list(upsample_kernel_sizes),
+            resblock_kernel_sizes=list(resblock_kernel_sizes), resblock_dilations=[list(d) for d in resblock_dilations],
+            use_additional_convs=use_additional_convs, bias=bias,
+            nonlinear_activation_params={"negative_slope": slope}, use_tanh=use_tanh,
+            use_ar=use_ar, ar_input=ar_input, ar_hidden=ar_hidden, ar_output=ar_output,
+        )
+        self.hop = int(np.prod(upsample_scales))
+        self.precision = precision
+
+        self.input_conv = _ConvParams((channels, in_channels, kernel_size), channels)
+        self.upsamples = torch.nn.ModuleList()
+        self.blocks = torch.nn.ModuleList()
+        for i in range(self.num_upsamples):
+            cin, cout = channels // (2 ** i), channels // (2 ** (i + 1))
+            k = upsample_kernel_sizes[i]
+            # ConvTranspose1d weight is (Cin, Cout, K); torch computes its fan_in from dim 1
+            self.upsamples.append(torch.nn.Sequential(torch.nn.LeakyReLU(slope), _ConvParams((cin, cout, k), cout, fan_in=cout * k)))
+            for j in range(self.num_blocks):
+                self.blocks.append(_ResBlockParams(resblock_kernel_sizes[j], cout, resblock_dilations[j], bias,
+                                                   use_additional_convs, slope))
+        c_last = channels // (2 ** self.num_upsamples)
+        out_mods = [torch.nn.LeakyReLU(), _ConvParams((out_channels, c_last, kernel_size), out_channels)]
+        if use_tanh:
+            out_mods.append(torch.nn.Tanh())
+        self.output_conv = torch.nn.Sequential(*out_mods)
+        if use_ar:
+            self.ar_model = _PastFCParams(ar_input, ar_hidden, ar_output)
+
+        if use_weight_norm:
+            self.apply_weight_norm()
+        else:
+            self.reset_parameters()
+
+        self._handle = None
+        self._workspaces = {}
+        self._lib = None
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _conv_params(self):
+        return [m for m in self.modules() if isinstance(m, _ConvParams)]
+
+    def reset_parameters(self):
+        """N(0, 0.01) on conv weights (hifigan.py:241-254).  With weight norm on this has no lasting
+        effect in the reference (the hook recomputes ``weight`` from g/v), so it is only applied to
+        un-normalised weights here."""
+        for m in self._conv_params():
+            if not m.has_weight_norm:
+                m.weight.data.normal_(0.0, 0.01)
+        self._invalidate()
+
+    def remove_weight_norm(self):
+        """Bake w = v*g/||v|| into ``weight`` for every conv layer (hifigan.py:256-266)."""
+        for m in self._conv_params():
+            if m.has_weight_norm:
+                logging.debug(f"Weight norm is removed from {m}.")
+                m.remove_weight_norm()
+        self._invalidate()
+
+    def apply_weight_norm(self):
+        """Re-parametrise every conv weight as (weight_g, weight_v) (hifigan.py:268-278)."""
+        for m in self._conv_params():
+            m.apply_weight_norm()
+        self._invalidate()
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._invalidate()
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._invalidate()
+        return out
+
+    def register_stats(self, stats):
+        """Register mean/scale buffers for input normalisation (hifigan.py:280-296)."""
+        assert stats.endswith(".h5") or stats.endswith(".npy")
+        if stats.endswith(".h5"):
+            try:
+                import h5py
+            except ImportError as e:  # h5py is not in this image
+                raise RuntimeError("register_stats: .h5 statistics need h5py; use the .npy form") from e
+            with h5py.File(stats, "r") as f:
+                mean = f["mean"][()].reshape(-1)
+                scale = f["scale"][()].reshape(-1)
+        else:
+            arr = np.load(stats)
+            mean = arr[0].reshape(-1)
+            scale = arr[1].reshape(-1)
+        self.register_buffer("mean", torch.from_numpy(np.asarray(mean)).float())
+        self.register_buffer("scale", torch.from_numpy(np.asarray(scale)).float())
+        logging.info("Successfully registered stats as buffer.")
+
+    def folded_state(self):
+        """{reference post-remove_weight_norm key: fp32 CPU tensor} — what the C ABI consumes."""
+        out = {}
+        for name, m in self.named_modules():
+            if isinstance(m, _ConvParams):
+                out[name + ".weight"] = m.folded_weight().float().cpu().contiguous()
+                if m.bias is not None:
+                    out[name + ".bias"] = m.bias.detach().float().cpu().contiguous()
+            elif isinstance(m, torch.nn.Linear):
+                out[name + ".weight"] = m.weight.detach().float().cpu().contiguous()
+                out[name + ".bias"] = m.bias.detach().float().cpu().contiguous()
+        return out
+
+    # ------------------------------------------------------------------ native handle
+    def _invalidate(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and self._lib is not None:
+            self._lib.hificar_destroy(h)
+        self._handle = None
+        self._workspaces = {}
+
+    def __del__(self):
+        try:
+            self._invalidate()
+        except Exception:
+            pass
+
+    def refresh_native(self):
+        """Re-upload weights after an in-place parameter edit (e.g. ``p.data.copy_``)."""
+        self._invalidate()
+
+    def set_precision(self, precision):
+        if precision not in _native.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_native.PRECISIONS)}")
+        self.precision = precision
+        if self._handle is not None:
+            _native.check(self._lib.hificar_set_precision(self._handle, _native.PRECISIONS[precision]), "hificar_set_precision")
+
+    def _device(self):
+        return next(self.parameters()).device
+
+    def _native_handle(self):
+        if self._handle is not None:
+            return self._handle
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError(
+                "HiFiGANGenerator: parameters are on %s; the generator forward only exists as HIP kernels "
+                "(move the model to a MI355X with .to('cuda')). There is no CPU fallback." % dev)
+        lib = _native.load_library()
+        self._lib = lib
+        cfg = _native.make_config(self._params, _native.PRECISIONS[self.precision])
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _native.check(lib.hificar_create(ctypes.byref(cfg), ctypes.byref(handle)), "hificar_create")
+            try:
+                for name, t in self.folded_state().items():
+                    shape = (ctypes.c_int64 * t.dim())(*t.shape)
+                    _native.check(lib.hificar_set_weight(handle, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()),
+                                  "hificar_set_weight")
+                _native.check(lib.hificar_finalize(handle), "hificar_finalize")
+            except Exception:
+                lib.hificar_destroy(handle)
+                raise
+        self._handle = handle
+        return handle
+
+    def _workspace(self, B, T):
+        key = (B, T)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            n = self._lib.hificar_workspace_bytes(self._handle, B, T)
+            if len(self._workspaces) > 8:
+                self._workspaces.clear()
+            ws = torch.empty(n + 256, dtype=torch.uint8, device=self._device())
+            self._workspaces[key] = ws
+        off = (-ws.data_ptr()) % 256
+        return ws.data_ptr() + off, ws.numel() - off
+
+    def macs(self, B, T):
+        """Algorithmic multiply-accumulates of one forward of B x T frames (SURVEY.md §8d constant)."""
+        self._native_handle()
+        return float(self._lib.hificar_macs(self._handle, B, T))
+
+    # ------------------------------------------------------------------ forward paths
+    def _check_input(self, c):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError(
+                "HiFiGANGenerator.forward under autograd/training is not built (SURVEY.md §8 row f1); "
+                "call .eval() and wrap in torch.no_grad()")
+        if not c.is_cuda:
+            raise RuntimeError("HiFiGANGenerator.forward needs a CUDA/HIP tensor; there is no CPU fallback")
+        cf = self._params["in_channels"] - (self._params["ar_output"] if self.use_ar else 0)
+        if c.dim() != 3 or c.shape[1] != cf:
+            raise RuntimeError(f"Expected input of shape (B, {cf}, T), got {tuple(c.shape)}")
+
+    def forward(self, c, spk_id=None, ar=None, ph=None):
+        """c: (B, in_channels[-ar_output], T) -> (B, out_channels, T * prod(upsample_scales))  (hifigan.py:198-239)."""
+        self._check_input(c)
+        if self.use_ar:
+            if ar is None:
+                raise RuntimeError("use_ar=True: forward() needs ar=(B, out_channels, ar_input/out_channels) past samples")
+            if ar.numel() != c.shape[0] * self._params["ar_input"]:
+                raise RuntimeError(f"ar has {ar.numel()} elements, expected {c.shape[0]}x{self._params['ar_input']}")
+            ar = ar.to(device=c.device, dtype=torch.float32).contiguous()
+        c = c.to(torch.float32).contiguous()
+        B, _, T = c.shape
+        handle = self._native_handle()
+        out = torch.empty((B, 1, T * self.hop), dtype=torch.float32, device=c.device)
+        with torch.cuda.device(c.device):
+            ws_ptr, ws_bytes = self._workspace(B, T)
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = self._lib.hificar_forward(handle, c.data_ptr(), ar.data_ptr() if self.use_ar else None, out.data_ptr(),
+                                           B, T, ws_ptr, ws_bytes, ctypes.c_void_p(stream))
+        _native.check(rc, "hificar_forward")
+        return out
+
+    def ar_synthesis(self, c, chunk_frames):
+        """Batched autoregressive synthesis of equal-length utterances on device.
+
+        c: (B, C, T_total) features; returns (B, hop*T_total).  Per utterance this equals the
+        reference's ``ar_loop`` (articulatory/bin/decode.py:54-83) with
+        ``chunk_frames = batch_max_steps // hop_size``; the reference driver is batch-1 only.
+        """
+        if not self.use_ar:
+            raise RuntimeError("ar_synthesis needs a use_ar=True generator")
+        self._check_input(c)
+        c = c.to(torch.float32).contiguous()
+        B, _, T = c.shape
+        handle = self._native_handle()
+        out = torch.empty((B, T * self.hop), dtype=torch.float32, device=c.device)
+        with torch.cuda.device(c.device):
+            ws_ptr, ws_bytes = self._workspace(B, min(int(chunk_frames), T))
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = self._lib.hificar_ar_loop(handle, c.data_ptr(), out.data_ptr(), B, T, int(chunk_frames), ws_ptr, ws_bytes,
+                                           ctypes.c_void_p(stream))
+        _native.check(rc, "hificar_ar_loop")
+        return out
+
+    def inference(self, c, normalize_before=False):
+        """(T, in_channels) -> (T * prod(upsample_scales), out_channels)  (hifigan.py:298-314)."""
+        if not isinstance(c, torch.Tensor):
+            c = torch.tensor(c, dtype=torch.float).to(self._device())
+        if normalize_before:
+            c = (c - self.mean) / self.scale
+        c = self.forward(c.transpose(1, 0).unsqueeze(0))
+        return c.squeeze(0).transpose(1, 0)

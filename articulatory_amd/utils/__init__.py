@@ -1,0 +1,1 @@
+from .load import load_model  # noqa: F401

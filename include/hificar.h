@@ -1,0 +1,127 @@
+/*
+ * hificar.h — C ABI of libhificar.so: the MI355X-native (gfx950) HiFi-GAN / HiFi-CAR generator
+ * forward pass (200-Hz EMA/pitch frames -> 16-kHz waveform).
+ *
+ * The reference (articulatory/articulatory) has NO native boundary for this path: it is a Python
+ * class protocol on top of PyTorch operators.  Each entry point below therefore names the
+ * reference Python interface it stands in for (paths relative to the reference repo):
+ *
+ *   hificar_create          HiFiGANGenerator.__init__            articulatory/models/hifigan.py:24-196
+ *   hificar_set_weight      load_state_dict + remove_weight_norm articulatory/utils/utils.py:340-342,
+ *                                                                articulatory/models/hifigan.py:256-266
+ *   hificar_finalize        model.eval().to(device)              egs/ema/voc1/local/predict_wav.py:114-115
+ *   hificar_forward         HiFiGANGenerator.forward             articulatory/models/hifigan.py:198-239
+ *   hificar_ar_loop         ar_loop (non-WSOLA branch), batched  articulatory/bin/decode.py:31-83
+ *   hificar_workspace_bytes (torch's caching allocator does this implicitly in the reference)
+ *   hificar_last_error      Python exceptions / assert           articulatory/models/hifigan.py:78-80
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  Device pointers are HIP device pointers.
+ *   - tensors at the boundary use the reference's layouts: features (B, C, T) fp32 with T contiguous,
+ *     AR context (B, 1, ar_input) fp32, waveform (B, 1, hop*T) fp32.
+ *   - every function returns 0 on success or a negative HIFICAR_E_* code; hificar_last_error() then
+ *     returns a thread-local, human-readable message.  Nothing ever calls exit().
+ *   - all device work is enqueued on the caller-supplied hipStream_t (passed as void*); no call
+ *     synchronises the device except hificar_finalize() (one-time weight upload).
+ *   - a handle is not thread-safe; use one handle per (process, device).
+ */
+#ifndef HIFICAR_H
+#define HIFICAR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIFICAR_MAX_STAGES 8
+#define HIFICAR_MAX_BLOCKS 4
+#define HIFICAR_MAX_DILATIONS 4
+
+#define HIFICAR_OK 0
+#define HIFICAR_E_INVALID (-1)     /* bad argument / unsupported hyper-parameter            */
+#define HIFICAR_E_STATE (-2)       /* call order (e.g. forward before finalize, missing weight) */
+#define HIFICAR_E_HIP (-3)         /* a HIP runtime call failed (message carries hipGetErrorString) */
+#define HIFICAR_E_WORKSPACE (-4)   /* workspace too small                                    */
+
+/* arithmetic used by the convolution kernels */
+#define HIFICAR_PREC_F32 0         /* v_mfma_f32_32x32x2_f32: exact fp32 multiply, fp32 accumulate */
+#define HIFICAR_PREC_BF16X3 1      /* fp32 operands split hi+lo bf16, 3 bf16 MFMAs, fp32 accumulate */
+
+typedef struct hificar_handle hificar_handle;
+
+/* Mirrors the keyword arguments of HiFiGANGenerator.__init__ (hifigan.py:24-50) that affect
+ * inference.  in_channels keeps the reference's meaning: feature dims + ar_output when use_ar. */
+typedef struct hificar_config {
+    int32_t in_channels;
+    int32_t out_channels; /* must be 1 */
+    int32_t channels;
+    int32_t kernel_size;
+    int32_t n_stages;
+    int32_t upsample_scales[HIFICAR_MAX_STAGES];
+    int32_t upsample_kernel_sizes[HIFICAR_MAX_STAGES];
+    int32_t n_blocks;
+    int32_t resblock_kernel_sizes[HIFICAR_MAX_BLOCKS];
+    int32_t n_dilations[HIFICAR_MAX_BLOCKS];
+    int32_t resblock_dilations[HIFICAR_MAX_BLOCKS][HIFICAR_MAX_DILATIONS];
+    int32_t use_additional_convs; /* must be 1 */
+    int32_t bias;                 /* ResBlock conv bias flag */
+    float lrelu_slope;            /* nonlinear_activation_params.negative_slope */
+    int32_t use_tanh;
+    int32_t use_ar;
+    int32_t ar_input;
+    int32_t ar_hidden;
+    int32_t ar_output;
+    int32_t precision; /* HIFICAR_PREC_* */
+} hificar_config;
+
+/* Build an (empty) generator for these hyper-parameters on the current HIP device. */
+int hificar_create(const hificar_config* cfg, hificar_handle** out);
+
+/* Hand over one FOLDED tensor (weight-norm already baked: w = v*g/||v||) by its reference
+ * state_dict name after remove_weight_norm(), e.g. "input_conv.weight", "upsamples.0.1.weight"
+ * (Cin,Cout,K), "blocks.3.convs1.2.1.bias", "output_conv.1.weight", "ar_model.model.4.weight".
+ * `data` is a HOST pointer to contiguous fp32 in the reference's layout; the library repacks into
+ * its kernel layout and the caller keeps ownership. */
+int hificar_set_weight(hificar_handle* h, const char* name, const float* data, const int64_t* shape, int ndim);
+
+/* Check that every tensor arrived, repack, upload to the device.  Synchronises the device once. */
+int hificar_finalize(hificar_handle* h);
+
+/* Switch the conv arithmetic after creation (HIFICAR_PREC_*).  Cheap; weights for both modes are resident. */
+int hificar_set_precision(hificar_handle* h, int precision);
+
+/* Bytes of device scratch hificar_forward / hificar_ar_loop need for B utterances of T frames per call
+ * (for hificar_ar_loop pass T = chunk_frames). */
+size_t hificar_workspace_bytes(const hificar_handle* h, int B, int T);
+
+/* One generator forward.  c: (B, in_channels - ar_output*use_ar, T) device fp32, time-contiguous with
+ * row stride c_stride_t... see hificar_forward_strided for views; ar: (B,1,ar_input) device fp32 or NULL
+ * when !use_ar; out: (B, 1, hop*T) device fp32.  hop = prod(upsample_scales). */
+int hificar_forward(hificar_handle* h, const float* c, const float* ar, float* out, int B, int T,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Batched autoregressive synthesis of B equal-length utterances (decode.py:54-83 per utterance):
+ * c: (B, C, T_total) device fp32; out: (B, hop*T_total) device fp32.  Chunks of chunk_frames frames
+ * (= batch_max_steps / hop_size, decode.py:50) run sequentially, each conditioned on the last ar_input
+ * output samples of the previous one (zeros for the first); the last chunk may be shorter.
+ * Requires ar_input <= hop*chunk_frames (the only case in which the reference's loop is well formed). */
+int hificar_ar_loop(hificar_handle* h, const float* c, float* out, int B, int T_total, int chunk_frames,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Algorithmic multiply-accumulates of one forward of B x T frames (conv + MLP MACs; bias/activation
+ * excluded) — the constant SURVEY.md §8(d) defines; used by bench.py for the roofline figure. */
+double hificar_macs(const hificar_handle* h, int B, int T);
+
+void hificar_destroy(hificar_handle* h);
+
+const char* hificar_last_error(void);
+
+/* Library / build identification, e.g. "hificar 0.1 gfx950". */
+const char* hificar_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIFICAR_H */
