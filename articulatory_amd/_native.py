@@ -29,6 +29,8 @@ SYMBOLS = (
     "hificar_forward",
     "hificar_ar_loop",
     "hificar_macs",
+    "hificar_profile_begin",
+    "hificar_profile_end",
     "hificar_destroy",
     "hificar_last_error",
     "hificar_version",
@@ -57,6 +59,16 @@ class HificarConfig(ctypes.Structure):
         ("ar_hidden", ctypes.c_int32),
         ("ar_output", ctypes.c_int32),
         ("precision", ctypes.c_int32),
+    ]
+
+
+class HificarKernelStat(ctypes.Structure):
+    _fields_ = [
+        ("name", ctypes.c_char * 96),
+        ("launches", ctypes.c_int64),
+        ("total_ms", ctypes.c_double),
+        ("flops", ctypes.c_double),
+        ("bytes", ctypes.c_double),
     ]
 
 
@@ -92,6 +104,10 @@ def load_library():
     lib.hificar_ar_loop.restype = ctypes.c_int
     lib.hificar_macs.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.hificar_macs.restype = ctypes.c_double
+    lib.hificar_profile_begin.argtypes = [vp]
+    lib.hificar_profile_begin.restype = ctypes.c_int
+    lib.hificar_profile_end.argtypes = [vp, ctypes.POINTER(HificarKernelStat), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    lib.hificar_profile_end.restype = ctypes.c_int
     lib.hificar_destroy.argtypes = [vp]
     lib.hificar_destroy.restype = None
     lib.hificar_last_error.argtypes = []

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Predict waveforms with a trained generator — counterpart of the reference's
+egs/ema/voc1/local/predict_wav.py:24-137 (same flags, same scp / config / checkpoint conventions).
+
+Differences, all on the device side: the autoregressive loop of every utterance runs as ONE enqueued
+C-ABI call (no per-chunk host round trip), and utterances of equal length can be batched
+(``--batch-size``; the reference is strictly one utterance at a time).  ``soundfile`` is not in this
+image, so 16-bit PCM WAV files are written with the standard library.
+"""
+
+import argparse
+import logging
+import os
+import wave
+
+import numpy as np
+import torch
+import yaml
+
+from articulatory_amd.bin.decode import ar_loop, ar_loop_batch
+from articulatory_amd.utils import load_model
+
+
+def write_wav(path, y, sampling_rate):
+    """float waveform in [-1, 1] -> mono PCM_16 WAV (what sf.write's default subtype produces for .wav)."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    pcm = np.clip(np.rint(y * 32767.0), -32768, 32767).astype("<i2")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(int(sampling_rate))
+        f.writeframes(pcm.tobytes())
+
+
+def read_scp(path):
+    """kaldi-style 'utt_id path.npy' lines (predict_wav.py:95-105)."""
+    fids, featps = [], []
+    with open(path, "r") as inf:
+        for line in inf:
+            parts = line.strip().split()
+            if len(parts) < 2:
+                continue
+            fids.append(parts[0])
+            featps.append(parts[1])
+    return fids, featps
+
+
+def get_parser():
+    parser = argparse.ArgumentParser(description="Decode dumped features with trained generator.")
+    parser.add_argument("--feats-scp", "--scp", default=None, type=str, help="kaldi-style feats.scp file.")
+    parser.add_argument("--outdir", type=str, required=True, help="directory to save generated speech.")
+    parser.add_argument("--checkpoint", type=str, required=True, help="checkpoint file to be loaded.")
+    parser.add_argument("--config", default=None, type=str,
+                        help="yaml format configuration file. if not explicitly provided, "
+                             "it will be searched in the checkpoint directory. (default=None)")
+    parser.add_argument("--verbose", type=int, default=1, help="logging level. higher is more logging. (default=1)")
+    parser.add_argument("--batch-size", type=int, default=1,
+                        help="synthesise up to this many equal-length utterances per device call (extension; default=1)")
+    return parser
+
+
+def synthesize_file_list(model, fids, featps, config, device, outdir, batch_size=1, writer=write_wav):
+    """The generation loop of predict_wav.py:124-137."""
+    use_ar = bool(config["generator_params"].get("use_ar", False))
+    written = []
+    pending = {}  # length -> [(fid, tensor)]
+
+    def flush(items):
+        if not items:
+            return
+        if len(items) == 1:
+            ys = [ar_loop(model, items[0][1], config)]
+        else:
+            ys = list(ar_loop_batch(model, torch.stack([c for _, c in items]), config))
+        for (fid, _), y in zip(items, ys):
+            writer(os.path.join(outdir, fid + ".wav"), y.cpu().numpy(), config["sampling_rate"])
+            written.append(fid)
+
+    with torch.no_grad():
+        for fid, featp in zip(fids, featps):
+            c = np.load(featp)
+            c = torch.tensor(c, dtype=torch.float).to(device)
+            if c.shape[0] > 250:  # the reference skips short utterances (predict_wav.py:130)
+                if use_ar:
+                    if batch_size <= 1:
+                        flush([(fid, c)])
+                    else:
+                        bucket = pending.setdefault(c.shape[0], [])
+                        bucket.append((fid, c))
+                        if len(bucket) >= batch_size:
+                            flush(bucket)
+                            pending[c.shape[0]] = []
+                else:
+                    if len(c.shape) == 1:
+                        c = c.long()
+                    y = model.inference(c)
+                    writer(os.path.join(outdir, fid + ".wav"), y.cpu().numpy(), config["sampling_rate"])
+                    written.append(fid)
+        for bucket in pending.values():
+            flush(bucket)
+    return written
+
+
+def main(argv=None):
+    args = get_parser().parse_args(argv)
+    level = logging.DEBUG if args.verbose > 1 else logging.INFO if args.verbose > 0 else logging.WARN
+    logging.basicConfig(level=level, format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    if args.verbose <= 0:
+        logging.warning("Skip DEBUG/INFO messages")
+    if not os.path.exists(args.outdir):
+        os.makedirs(args.outdir)
+    if args.config is None:
+        args.config = os.path.join(os.path.dirname(args.checkpoint), "config.yml")
+    with open(args.config) as f:
+        config = yaml.load(f, Loader=yaml.Loader)
+    config.update(vars(args))
+    fids, featps = read_scp(args.feats_scp)
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("predict_wav: no GPU visible; this package has no CPU synthesis path")
+    device = torch.device("cuda")
+    model = load_model(args.checkpoint, config)
+    logging.info(f"Loaded model parameters from {args.checkpoint}.")
+    model.remove_weight_norm()
+    model = model.eval().to(device)
+    print(sum(p.numel() for p in model.parameters() if p.requires_grad))
+    synthesize_file_list(model, fids, featps, config, device, config["outdir"], batch_size=args.batch_size)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,39 @@
+"""Utterance-batch sharding across the GPUs of one node.
+
+Utterances never interact (no cross-item op; the AR state is per utterance), so the batch axis is
+partitioned across ranks with NO data-path collective; the only exchange is one all-gather of the
+finished waveforms ("waveform collection only").  One process per GPU (``torchrun``); on ROCm the
+``nccl`` backend is RCCL over xGMI.  The reference has no multi-GPU inference at all (its only
+distributed code is the disabled DDP wrap at articulatory/bin/train.py:1790-1801).
+"""
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, world_size, rank):
+    """Contiguous [lo, hi) slice of n_items for this rank; requires equal shards so that the gather is a
+    single fixed-size collective."""
+    if n_items % world_size != 0:
+        raise ValueError(f"batch of {n_items} utterances does not split evenly over {world_size} ranks; "
+                         "pad or bucket the batch first")
+    per = n_items // world_size
+    return rank * per, (rank + 1) * per
+
+
+def synthesize_sharded(synth_fn, feats, group=None):
+    """Each rank synthesises its slice of ``feats`` (B, ...) with ``synth_fn`` and every rank receives all
+    waveforms (B, n_samples) in the original utterance order.
+
+    synth_fn: (feats_shard) -> (B/W, n_samples) tensor on the compute device, e.g.
+              ``lambda x: ar_loop_batch(model, x, config)``.
+    """
+    if not dist.is_available() or not dist.is_initialized():
+        return synth_fn(feats)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_range(feats.shape[0], world, rank)
+    y = synth_fn(feats[lo:hi]).contiguous()
+    out = torch.empty((world * y.shape[0],) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+    dist.all_gather_into_tensor(out, y, group=group)
+    return out

@@ -82,6 +82,36 @@ struct hificar_handle {
     float* d_mlp_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float* d_mlp_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs;
+    // profiling (hificar_profile_begin/end)
+    bool profiling = false;
+    struct ProfRec {
+        hipEvent_t e0, e1;
+        std::string name;
+        double flops, bytes;
+    };
+    std::vector<ProfRec> prof;
+    hipStream_t prof_stream = nullptr;
+};
+
+// RAII bracket: records an event before and after one kernel launch while profiling is on.
+struct ProfScope {
+    hificar_handle* h;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::string name;
+    double flops, bytes;
+    ProfScope(hificar_handle* h_, hipStream_t s_, const std::string& n, double f, double b) : h(h_), s(s_), name(n), flops(f), bytes(b) {
+        if (!h->profiling) return;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, s);
+    }
+    ~ProfScope() {
+        if (!h->profiling) return;
+        (void)hipEventRecord(e1, s);
+        h->prof.push_back({e0, e1, name, flops, bytes});
+        h->prof_stream = s;
+    }
 };
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -541,6 +571,16 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     if (lds > 160 * 1024) return fail(HIFICAR_E_INVALID, "internal: LDS tile too large (%zu)", lds);
     dim3 grid((unsigned)(nseq * ((rows + TM - 1) / TM)), (unsigned)((L0.n_blocks + tc.WN - 1) / tc.WN), (unsigned)nbr);
     hipError_t e = hipErrorInvalidValue;
+    double flops = 0.0, bytes = 0.0;
+    for (int b = 0; b < nbr; ++b) {
+        const ConvLayer& Lb = *layers[b];
+        const double pos = (double)nseq * rows;
+        flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K;
+        bytes += 4.0 * (pos * Lb.cin_pad * nin + pos * Lb.cout_total * (res ? 2 : 1) + (double)Lb.cin * Lb.cout * Lb.K);
+    }
+    char kname[96];
+    snprintf(kname, sizeof(kname), "conv_mfma_f32_kernel<%d,%d,%d,%d>", tc.MI, L0.NJ, tc.WM, tc.WN);
+    ProfScope prof(h, stream, kname, flops, bytes);
 #define HIFICAR_DISPATCH(mi, nj, wm, wn)                                              \
     if (tc.MI == mi && L0.NJ == nj && tc.WM == wm && tc.WN == wn) e = launch_conv_t<mi, nj, wm, wn>(mp, grid, lds, stream);
     HIFICAR_DISPATCH(1, 4, 4, 1)
@@ -587,7 +627,12 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
         fp.wt[l] = h->d_mlp_w[l];
         fp.bs[l] = h->d_mlp_b[l];
     }
-    hipLaunchKernelGGL(front_kernel, dim3(B), dim3(256), 0, stream, fp);
+    {
+        const double mlp_macs = cfg.use_ar ? (double)cfg.ar_input * cfg.ar_hidden + 3.0 * cfg.ar_hidden * cfg.ar_hidden +
+                                                 (double)cfg.ar_hidden * cfg.ar_output : 0.0;
+        ProfScope prof(h, stream, "front_kernel", 2.0 * B * mlp_macs, 4.0 * B * (mlp_macs + (double)T * (h->cf + h->cin_pad)));
+        hipLaunchKernelGGL(front_kernel, dim3(B), dim3(256), 0, stream, fp);
+    }
     HIP_TRY(hipGetLastError());
 
     int rc;
@@ -661,7 +706,11 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     op.slope = 0.01f;
     op.use_tanh = cfg.use_tanh;
     const size_t lds = ((size_t)(256 + op.K - 1) * (op.C + 1) + (size_t)op.K * op.C) * sizeof(float);
-    hipLaunchKernelGGL(output_conv_kernel, dim3((rows + 255) / 256, B), dim3(256), lds, stream, op);
+    {
+        const double pos = (double)B * rows;
+        ProfScope prof(h, stream, "output_conv_kernel", 2.0 * pos * op.C * op.K, 4.0 * pos * (op.C * nbk + 1));
+        hipLaunchKernelGGL(output_conv_kernel, dim3((rows + 255) / 256, B), dim3(256), lds, stream, op);
+    }
     HIP_TRY(hipGetLastError());
     return HIFICAR_OK;
 }
@@ -710,5 +759,50 @@ extern "C" int hificar_ar_loop(hificar_handle* h, const float* c, float* out, in
                           static_cast<hipStream_t>(stream));
         if (rc != HIFICAR_OK) return rc;
     }
+    return HIFICAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-kernel event timing
+// ------------------------------------------------------------------------------------------------
+extern "C" int hificar_profile_begin(hificar_handle* h) {
+    if (!h) return fail(HIFICAR_E_INVALID, "null handle");
+    for (auto& r : h->prof) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    h->prof.clear();
+    h->profiling = true;
+    return HIFICAR_OK;
+}
+
+extern "C" int hificar_profile_end(hificar_handle* h, hificar_kernel_stat* stats, int max_stats, int* n_stats) {
+    if (!h || !n_stats) return fail(HIFICAR_E_INVALID, "null argument");
+    h->profiling = false;
+    if (!h->prof.empty()) HIP_TRY(hipStreamSynchronize(h->prof_stream));
+    std::vector<hificar_kernel_stat> agg;
+    for (auto& r : h->prof) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
+        size_t k = 0;
+        for (; k < agg.size(); ++k)
+            if (r.name == agg[k].name) break;
+        if (k == agg.size()) {
+            hificar_kernel_stat st;
+            memset(&st, 0, sizeof(st));
+            snprintf(st.name, sizeof(st.name), "%s", r.name.c_str());
+            agg.push_back(st);
+        }
+        agg[k].launches += 1;
+        agg[k].total_ms += ms;
+        agg[k].flops += r.flops;
+        agg[k].bytes += r.bytes;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    h->prof.clear();
+    std::sort(agg.begin(), agg.end(), [](const hificar_kernel_stat& a, const hificar_kernel_stat& b) { return a.total_ms > b.total_ms; });
+    *n_stats = (int)agg.size();
+    for (int i = 0; i < (int)agg.size() && i < max_stats && stats; ++i) stats[i] = agg[i];
     return HIFICAR_OK;
 }

@@ -344,6 +344,19 @@ class HiFiGANGenerator(torch.nn.Module):
         self._native_handle()
         return float(self._lib.hificar_macs(self._handle, B, T))
 
+    def profile_begin(self):
+        """Start bracketing every kernel launch with HIP events (bench.py roofline leg)."""
+        self._native_handle()
+        _native.check(self._lib.hificar_profile_begin(self._handle), "hificar_profile_begin")
+
+    def profile_end(self):
+        """Stop profiling; returns [{name, launches, total_ms, flops, bytes}], slowest kernel first."""
+        stats = (_native.HificarKernelStat * 32)()
+        n = ctypes.c_int(0)
+        _native.check(self._lib.hificar_profile_end(self._handle, stats, 32, ctypes.byref(n)), "hificar_profile_end")
+        return [dict(name=stats[i].name.decode(), launches=int(stats[i].launches), total_ms=float(stats[i].total_ms),
+                     flops=float(stats[i].flops), bytes=float(stats[i].bytes)) for i in range(min(n.value, 32))]
+
     # ------------------------------------------------------------------ forward paths
     def _check_input(self, c):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:

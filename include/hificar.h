@@ -96,9 +96,9 @@ int hificar_set_precision(hificar_handle* h, int precision);
  * (for hificar_ar_loop pass T = chunk_frames). */
 size_t hificar_workspace_bytes(const hificar_handle* h, int B, int T);
 
-/* One generator forward.  c: (B, in_channels - ar_output*use_ar, T) device fp32, time-contiguous with
- * row stride c_stride_t... see hificar_forward_strided for views; ar: (B,1,ar_input) device fp32 or NULL
- * when !use_ar; out: (B, 1, hop*T) device fp32.  hop = prod(upsample_scales). */
+/* One generator forward.  c: (B, in_channels - ar_output*use_ar, T) contiguous device fp32;
+ * ar: (B, 1, ar_input) contiguous device fp32, or NULL when !use_ar; out: (B, 1, hop*T) device fp32,
+ * hop = prod(upsample_scales).  Inputs are not modified. */
 int hificar_forward(hificar_handle* h, const float* c, const float* ar, float* out, int B, int T,
                     void* workspace, size_t workspace_bytes, void* stream);
 
@@ -113,6 +113,21 @@ int hificar_ar_loop(hificar_handle* h, const float* c, float* out, int B, int T_
 /* Algorithmic multiply-accumulates of one forward of B x T frames (conv + MLP MACs; bias/activation
  * excluded) — the constant SURVEY.md §8(d) defines; used by bench.py for the roofline figure. */
 double hificar_macs(const hificar_handle* h, int B, int T);
+
+/* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg; no reference
+ * counterpart — the reference times whole utterances with time.time(), articulatory/bin/decode.py:302-318).
+ * Between hificar_profile_begin and hificar_profile_end every kernel launch of this handle is bracketed
+ * by two hipEvents.  hificar_profile_end synchronises the stream used, then fills up to `max_stats`
+ * entries (one per distinct kernel) and writes the number of distinct kernels to *n_stats. */
+typedef struct hificar_kernel_stat {
+    char name[96];     /* e.g. "conv_mfma_f32_kernel<1,4,4,1>" (template args as in the rocprof kernel name) */
+    int64_t launches;
+    double total_ms;   /* sum of hipEventElapsedTime over the launches */
+    double flops;      /* algorithmic FLOPs (2 x MACs) of those launches */
+    double bytes;      /* algorithmic bytes (inputs + outputs + weights read once) of those launches */
+} hificar_kernel_stat;
+int hificar_profile_begin(hificar_handle* h);
+int hificar_profile_end(hificar_handle* h, hificar_kernel_stat* stats, int max_stats, int* n_stats);
 
 void hificar_destroy(hificar_handle* h);
 

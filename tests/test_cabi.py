@@ -1,0 +1,100 @@
+"""The C-ABI library loads and exports every symbol include/hificar.h declares; host-only entry points
+(create / set_weight / workspace_bytes / macs / error reporting) behave.  No compute calls: no GPU here."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import E2W_PARAMS, REPO
+from articulatory_amd import _native
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _native.load_library()
+
+
+def _full_params(**over):
+    p = dict(E2W_PARAMS, use_tanh=True)
+    p.update(over)
+    return p
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(REPO, "include", "hificar.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(hificar_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_native.SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert b"gfx950" in lib.hificar_version()
+
+
+def test_config_struct_matches_header_layout():
+    # 5 scalars + 8 + 8 + 1 + 4 + 4 + 16 + 2 ints + float + 6 ints = 56 x 4 bytes
+    assert ctypes.sizeof(_native.HificarConfig) == 4 * (5 + 8 + 8 + 1 + 4 + 4 + 16 + 2 + 1 + 6)
+    assert ctypes.sizeof(_native.HificarKernelStat) == 96 + 8 + 3 * 8
+
+
+def test_create_macs_workspace(lib):
+    cfg = _native.make_config(_full_params(), _native.PREC_F32)
+    h = ctypes.c_void_p()
+    assert lib.hificar_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    try:
+        mlp = 512 * 256 + 3 * 256 * 256 + 256 * 128
+        # 117 668 864 conv MACs per frame (HiFi-CAR 13-dim) + 360 448 per PastFCEncoder call
+        assert lib.hificar_macs(h, 1, 1) == 117668864 + mlp
+        assert lib.hificar_macs(h, 64, 25) == 64 * (25 * 117668864 + mlp)
+        assert abs(lib.hificar_macs(h, 1, 25) / 2000 - 1471041) < 1.0  # MAC per output sample at chunk 25
+        ws = lib.hificar_workspace_bytes(h, 64, 25)
+        assert 100e6 < ws < 200e6
+        assert lib.hificar_workspace_bytes(h, 0, 25) == 0
+        # forward before finalize is a state error, not a crash
+        rc = lib.hificar_forward(h, 1, 1, 1, 1, 1, 1, 0, None)
+        assert rc == -2 and b"finalize" in lib.hificar_last_error()
+        rc = lib.hificar_finalize(h)
+        assert rc == -2 and b"Missing key" in lib.hificar_last_error()
+    finally:
+        lib.hificar_destroy(h)
+
+
+def test_set_weight_validation(lib):
+    cfg = _native.make_config(_full_params(), _native.PREC_F32)
+    h = ctypes.c_void_p()
+    assert lib.hificar_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    try:
+        w = np.zeros((512, 141, 7), dtype=np.float32)
+        shp = (ctypes.c_int64 * 3)(512, 141, 7)
+        assert lib.hificar_set_weight(h, b"input_conv.weight", w.ctypes.data, shp, 3) == 0
+        bad = (ctypes.c_int64 * 3)(512, 140, 7)
+        assert lib.hificar_set_weight(h, b"input_conv.weight", w.ctypes.data, bad, 3) == -1
+        assert b"size mismatch for input_conv.weight" in lib.hificar_last_error()
+        assert lib.hificar_set_weight(h, b"input_conv.weight_v", w.ctypes.data, shp, 3) == -1
+        assert b"unexpected tensor name" in lib.hificar_last_error()
+    finally:
+        lib.hificar_destroy(h)
+
+
+@pytest.mark.parametrize("over,msg", [
+    (dict(out_channels=4), b"out_channels"),
+    (dict(kernel_size=6), b"odd"),
+    (dict(upsample_scales=[5, 4, 2, 2], upsample_kernel_sizes=[11, 8, 4, 4]), b"L_out"),
+    (dict(channels=64), b"multiple of 32"),
+    (dict(resblock_kernel_sizes=[3, 7, 11, 13], resblock_dilations=[[1]] * 4), b"n_blocks"),
+])
+def test_create_rejects_unsupported(lib, over, msg):
+    cfg = _native.make_config(_full_params(**over), _native.PREC_F32)
+    h = ctypes.c_void_p()
+    rc = lib.hificar_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc == -1
+    assert msg in lib.hificar_last_error(), lib.hificar_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "libhificar.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.load_library()

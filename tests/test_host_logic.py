@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's plugin surface: registry lookup, constructor keywords, state_dict
+layout, weight-norm fold, load_model, predict_wav plumbing, and the no-CPU-fallback rule.  CPU only."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import E2W_PARAMS, GOLDEN, rel_err
+import articulatory_amd
+from articulatory_amd.bin import decode as D
+from articulatory_amd.bin import predict_wav as PW
+from articulatory_amd.utils import load_model
+from articulatory_amd.utils.synth import synth_features, synth_state_dict
+from oracle import hificar_oracle as O
+
+
+def _ref_keys():
+    return [(l.split()[0], tuple(int(s) for s in l.split()[1:]))
+            for l in open(os.path.join(GOLDEN, "gold_state_dict_keys.txt")).read().strip().splitlines()]
+
+
+def test_registry_lookup_and_yaml_kwargs():
+    cls = getattr(articulatory_amd.models, "HiFiGANGenerator")
+    # e2w_hifigan_car.yaml carries final_scale / extra_art, which the reference class rejects
+    g = cls(**dict(E2W_PARAMS, final_scale=80, extra_art=False))
+    assert [(k, tuple(v.shape)) for k, v in g.state_dict().items()] == _ref_keys()
+    assert sum(p.numel() for p in g.parameters() if p.requires_grad) == 13467778
+    with pytest.raises(TypeError):
+        cls(**dict(E2W_PARAMS, not_a_kwarg=1))
+    with pytest.raises(AssertionError, match="odd"):
+        cls(**dict(E2W_PARAMS, kernel_size=6))
+
+
+def test_load_state_dict_and_fold_match_reference():
+    params = dict(E2W_PARAMS, channels=64)
+    sd = synth_state_dict(params, seed=1234)
+    g = articulatory_amd.models.HiFiGANGenerator(**params)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    g.remove_weight_norm()
+    gold = np.load(os.path.join(GOLDEN, "gold_wnfold.npz"))
+    after = g.state_dict()
+    for name in ["upsamples.0.1", "blocks.4.convs2.1.1", "output_conv.1"]:
+        assert name + ".weight_g" not in after
+        assert rel_err(after[name + ".weight"].numpy(), gold[name + ".weight"]) < 1e-6
+    # key order after remove_weight_norm is (bias, weight) per layer, as torch leaves it
+    assert list(after.keys())[:2] == ["input_conv.bias", "input_conv.weight"]
+    # folded_state() of a still-normalised model equals the baked weights
+    g2 = articulatory_amd.models.HiFiGANGenerator(**params)
+    g2.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    f2 = g2.folded_state()
+    for k, v in g.folded_state().items():
+        assert torch.equal(v, f2[k]), k
+    # apply -> remove round trip leaves weights unchanged
+    g.apply_weight_norm()
+    assert "input_conv.weight_g" in g.state_dict()
+    g.remove_weight_norm()
+    assert rel_err(g.state_dict()["upsamples.0.1.weight"].numpy(), gold["upsamples.0.1.weight"]) < 1e-6
+
+
+def test_strict_load_rejects_wrong_checkpoint():
+    g = articulatory_amd.models.HiFiGANGenerator(**E2W_PARAMS)
+    sd = synth_state_dict(dict(E2W_PARAMS, in_channels=140), seed=1)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+
+
+def test_no_cpu_fallback():
+    g = articulatory_amd.models.HiFiGANGenerator(**E2W_PARAMS).eval()
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            g(torch.zeros(1, 13, 25), ar=torch.zeros(1, 1, 512))
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            g.ar_synthesis(torch.zeros(1, 13, 50), 25)
+    g.train()
+    with pytest.raises(NotImplementedError, match="training"):
+        g(torch.zeros(1, 13, 25), ar=torch.zeros(1, 1, 512))
+    for kw in ("use_spk_id", "use_ph", "use_ph_loss"):
+        with pytest.raises(NotImplementedError):
+            articulatory_amd.models.HiFiGANGenerator(**dict(E2W_PARAMS, **{kw: True}))
+
+
+def test_product_code_never_imports_the_oracle():
+    import re
+    root = os.path.join(os.path.dirname(GOLDEN), "..", "articulatory_amd")
+    for dp, _, fns in os.walk(root):
+        for fn in fns:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def _write_checkpoint(tmp_path, params, cfg_extra=None):
+    sd = synth_state_dict(params, seed=1234)
+    ckpt = tmp_path / "checkpoint-1steps.pkl"
+    # the reference trainer's layout (train.py:147-176)
+    torch.save({"model": {"generator": {k: torch.from_numpy(v) for k, v in sd.items()}, "discriminator": {}},
+                "optimizer": {}, "scheduler": {}, "steps": 1, "epochs": 0}, ckpt)
+    config = dict(generator_type="HiFiGANGenerator", generator_params=dict(params), format="npy",
+                  sampling_rate=16000, hop_size=80, batch_max_steps=8000, dataset_mode="a2w")
+    config.update(cfg_extra or {})
+    with open(tmp_path / "config.yml", "w") as f:
+        yaml.dump(config, f)
+    return str(ckpt), config, sd
+
+
+def test_load_model_reads_reference_checkpoint_layout(tmp_path):
+    params = dict(E2W_PARAMS, channels=64)
+    ckpt, config, sd = _write_checkpoint(tmp_path, params)
+    np.save(tmp_path / "stats.npy", np.stack([np.arange(13.0), np.arange(13.0) + 1]))
+    m = load_model(ckpt)  # config.yml found beside the checkpoint, stats.npy registered
+    assert isinstance(m, articulatory_amd.models.HiFiGANGenerator)
+    assert torch.equal(m.state_dict()["input_conv.weight_v"], torch.from_numpy(sd["input_conv.weight_v"]))
+    assert hasattr(m, "mean") and m.scale.shape == (13,)
+    with pytest.raises(AttributeError, match="ParallelWaveGANGenerator"):
+        load_model(ckpt, {k: v for k, v in config.items() if k != "generator_type"})
+    # typo workaround (utils.py:330-333)
+    gp = dict(config["generator_params"])
+    gp["upsample_kernal_sizes"] = gp.pop("upsample_kernel_sizes")
+    assert load_model(ckpt, dict(config, generator_params=gp)) is not None
+
+
+class _OracleBackedModel:
+    """Stands in for the HIP generator on the CPU box so that the *plumbing* (scp parsing, chunk length,
+    batching by length, skipping short utterances, wav writing) can be tested here.  Test-only."""
+
+    def __init__(self, params, sd):
+        self.params, self.w = params, O.fold_weight_norm(sd)
+        self.calls = []
+
+    def ar_synthesis(self, c, chunk_frames):
+        self.calls.append((tuple(c.shape), chunk_frames))
+        return O.ar_loop_batched(self.w, self.params, c.permute(0, 2, 1), chunk_frames * 80, 80)
+
+
+def test_predict_wav_plumbing_matches_reference_pin(tmp_path):
+    """configs[0]: one (700, 13) utterance through the predict_wav counterpart; the waveform handed to the
+    wav writer must equal what the real predict_wav.py hands to sf.write (gold_predict_wav.npz)."""
+    import wave
+    gold = np.load(os.path.join(GOLDEN, "gold_predict_wav.npz"))
+    sd = synth_state_dict(E2W_PARAMS, seed=1234)
+    model = _OracleBackedModel(E2W_PARAMS, sd)
+    feat = tmp_path / "utt1.npy"
+    np.save(feat, gold["x"].astype(np.float64))  # .npy features are float64 on disk (mk_ema_feats.py:67-72)
+    short = tmp_path / "short.npy"
+    np.save(short, synth_features(1, 250, 13, seed=5)[0].astype(np.float64))
+    scp = tmp_path / "feats.scp"
+    scp.write_text(f"utt1 {feat}\nshort {short}\n")
+    fids, featps = PW.read_scp(str(scp))
+    assert fids == ["utt1", "short"]
+    config = dict(generator_params=dict(E2W_PARAMS), sampling_rate=16000, hop_size=80, batch_max_steps=8000,
+                  dataset_mode="a2w")
+    captured = {}
+
+    def writer(path, y, sr):
+        captured[os.path.basename(path)] = np.asarray(y)
+        PW.write_wav(path, y, sr)
+
+    written = PW.synthesize_file_list(model, fids, featps, config, "cpu", str(tmp_path), writer=writer)
+    assert written == ["utt1"]  # T <= 250 is skipped, as in the reference
+    assert model.calls == [((1, 13, 700), 100)]
+    assert rel_err(captured["utt1.wav"], gold["out"]) < 2e-5
+    with wave.open(str(tmp_path / "utt1.wav")) as f:
+        assert (f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()) == (16000, 1, 2, 56000)
+
+
+def test_predict_wav_batches_equal_lengths(tmp_path):
+    params = dict(E2W_PARAMS)
+    model = _OracleBackedModel(params, synth_state_dict(params, seed=1234))
+    paths = []
+    for i, T in enumerate([260, 300, 260]):
+        p = tmp_path / f"u{i}.npy"
+        np.save(p, synth_features(1, T, 13, seed=10 + i)[0])
+        paths.append(str(p))
+    config = dict(generator_params=params, sampling_rate=16000, hop_size=80, batch_max_steps=8000)
+    outs = {}
+    PW.synthesize_file_list(model, ["u0", "u1", "u2"], paths, config, "cpu", str(tmp_path), batch_size=2,
+                            writer=lambda p, y, sr: outs.__setitem__(os.path.basename(p), y))
+    assert sorted(model.calls) == [((1, 13, 300), 100), ((2, 13, 260), 100)]
+    single = _OracleBackedModel(params, synth_state_dict(params, seed=1234))
+    y0 = D.ar_loop(single, torch.from_numpy(np.load(paths[0])).float(), config)
+    assert rel_err(outs["u0.wav"], y0.numpy()) < 2e-5
+
+
+def test_ar_loop_rejects_unbuilt_variants():
+    with pytest.raises(NotImplementedError):
+        D.ar_loop(None, torch.zeros(10, 13), dict(batch_max_steps=2000, hop_size=80, generator_params=E2W_PARAMS), do_wsola=True)
+    with pytest.raises(NotImplementedError):
+        D.ar_loop(None, torch.zeros(10, 13), dict(batch_max_steps=2000, hop_size=80, generator_params=E2W_PARAMS,
+                                                   dataset_mode="w2a"))
