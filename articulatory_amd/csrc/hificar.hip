@@ -60,6 +60,9 @@ struct ConvLayer {
     int tap_k[kMaxPhase][kMaxTaps];  // which kernel index each (phase, tap) uses; -1 = zero weights
     float* d_w = nullptr;
     float* d_bias = nullptr;
+    // bf16x3 path
+    int chunk16 = 0, n_blocks32 = 0, nb32_per_phase = 0;
+    uint16_t* d_w16 = nullptr;
 };
 
 struct hificar_handle {
@@ -176,6 +179,11 @@ static int plan_layer(ConvLayer& L) {
     L.chunk = 8;
     for (int c = 8; c <= 64; c += 8)
         if (L.cin_pad % c == 0) L.chunk = c;
+    L.chunk16 = 16;
+    for (int c = 16; c <= 64; c += 16)
+        if (L.cin_pad % c == 0) L.chunk16 = c;
+    L.n_blocks32 = L.cout_total / 32;
+    L.nb32_per_phase = L.cout / 32;
     return HIFICAR_OK;
 }
 
@@ -339,6 +347,19 @@ static int upload(hificar_handle* h, const std::vector<float>& v, float** dptr) 
     return HIFICAR_OK;
 }
 
+static inline uint16_t f32_to_bf16(float f) {  // round to nearest even (finite inputs)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 static int pack_conv(hificar_handle* h, ConvLayer& L) {
     const HostTensor& W = h->tensors.at(L.name + ".weight");
     std::vector<float> wp((size_t)L.n_blocks * L.ntaps * L.cin_pad * L.NB, 0.f);
@@ -367,7 +388,43 @@ static int pack_conv(hificar_handle* h, ConvLayer& L) {
     }
     int rc = upload(h, wp, &L.d_w);
     if (rc != HIFICAR_OK) return rc;
-    return upload(h, bias, &L.d_bias);
+    if ((rc = upload(h, bias, &L.d_bias)) != HIFICAR_OK) return rc;
+
+    // bf16x3 path: B fragments in MFMA lane order, [n_block32][chunk][tap][c16][hi|lo][lane][8]
+    const int nc16 = L.chunk16 / 16, nchunk = L.cin_pad / L.chunk16;
+    const size_t frag = 64 * 8;  // bf16 elements per fragment
+    std::vector<uint16_t> w16(((size_t)L.n_blocks32 * nchunk * L.ntaps * nc16 * 2 + 2 * nc16) * frag, 0);
+    for (int nb = 0; nb < L.n_blocks32; ++nb) {
+        const int phase = nb / L.nb32_per_phase;
+        const int co0 = (nb % L.nb32_per_phase) * 32;
+        for (int c = 0; c < nchunk; ++c)
+            for (int t = 0; t < L.ntaps; ++t) {
+                const int k = L.tap_k[phase][t];
+                if (k < 0) continue;
+                for (int u = 0; u < nc16; ++u) {
+                    uint16_t* hi = &w16[(((((size_t)nb * nchunk + c) * L.ntaps + t) * nc16 + u) * 2) * frag];
+                    uint16_t* lo = hi + frag;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int g = lane >> 5, n = lane & 31, co = co0 + n;
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = c * L.chunk16 + u * 16 + 8 * g + j;
+                            if (ci >= L.cin) continue;
+                            const size_t src = L.transposed ? ((size_t)ci * L.cout + co) * L.K + k : ((size_t)co * L.cin + ci) * L.K + k;
+                            const float v = W.data[src];
+                            const uint16_t vh = f32_to_bf16(v);
+                            hi[lane * 8 + j] = vh;
+                            lo[lane * 8 + j] = f32_to_bf16(v - bf16_to_f32(vh));
+                        }
+                    }
+                }
+            }
+    }
+    void* dp = nullptr;
+    HIP_TRY(hipMalloc(&dp, w16.size() * sizeof(uint16_t)));
+    h->allocs.push_back(dp);
+    HIP_TRY(hipMemcpy(dp, w16.data(), w16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    L.d_w16 = static_cast<uint16_t*>(dp);
+    return HIFICAR_OK;
 }
 
 template <int MI, int NJ, int WM, int WN>
@@ -375,6 +432,17 @@ static hipError_t set_lds_attr() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<MI, NJ, WM, WN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
+
+template <int MI, int WM, int WN, int NC16>
+static hipError_t set_lds_attr_b() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3_kernel<MI, WM, WN, NC16>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// every (MI, WM, WN) x NC16 instantiation of the bf16x3 kernel
+#define HIFICAR_FOR_BF16_TILES(X, nc) \
+    X(4, 1, 4, nc) X(4, 2, 2, nc) X(4, 4, 1, nc) X(2, 1, 4, nc) X(2, 2, 2, nc) X(2, 4, 1, nc) X(1, 1, 4, nc) X(1, 2, 2, nc) X(1, 4, 1, nc)
+#define HIFICAR_FOR_BF16_ALL(X) HIFICAR_FOR_BF16_TILES(X, 1) HIFICAR_FOR_BF16_TILES(X, 2) HIFICAR_FOR_BF16_TILES(X, 3) HIFICAR_FOR_BF16_TILES(X, 4)
 
 extern "C" int hificar_finalize(hificar_handle* h) {
     if (!h) return fail(HIFICAR_E_INVALID, "hificar_finalize: null handle");
@@ -421,6 +489,9 @@ extern "C" int hificar_finalize(hificar_handle* h) {
     HIP_TRY((set_lds_attr<1, 1, 2, 2>()));
     HIP_TRY((set_lds_attr<1, 1, 1, 4>()));
     HIP_TRY((set_lds_attr<2, 1, 4, 1>()));
+#define HIFICAR_SET_ATTR(mi, wm, wn, nc) HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>()));
+    HIFICAR_FOR_BF16_ALL(HIFICAR_SET_ATTR)
+#undef HIFICAR_SET_ATTR
     HIP_TRY(hipDeviceSynchronize());
     h->tensors.clear();  // host copies no longer needed
     h->finalized = true;
@@ -429,11 +500,11 @@ extern "C" int hificar_finalize(hificar_handle* h) {
 
 extern "C" int hificar_set_precision(hificar_handle* h, int precision) {
     if (!h) return fail(HIFICAR_E_INVALID, "null handle");
-    if (precision == HIFICAR_PREC_F32) {
+    if (precision == HIFICAR_PREC_F32 || precision == HIFICAR_PREC_BF16X3) {
         h->precision = precision;
         return HIFICAR_OK;
     }
-    return fail(HIFICAR_E_INVALID, "precision %d is not available in this build", precision);
+    return fail(HIFICAR_E_INVALID, "unknown precision %d", precision);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,6 +598,9 @@ static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, con
     p.x1 = nin > 1 ? xin[1] : nullptr;
     p.x2 = nin > 2 ? xin[2] : nullptr;
     p.w = L.d_w;
+    p.w16 = reinterpret_cast<const bf16x8*>(L.d_w16);
+    p.n_blocks32 = L.n_blocks32;
+    p.nb32_per_phase = L.nb32_per_phase;
     p.bias = L.d_bias;
     p.res = res;
     p.y = y;
@@ -552,9 +626,66 @@ static hipError_t launch_conv_t(const MultiConvParams& mp, dim3 grid, size_t lds
 }
 
 // Launch nbr (1..3) same-shape conv layers ("branches") as one grid; branch = blockIdx.z.
+struct TileCfgB {
+    int MI, WM, WN;
+};
+// preference order: ties keep the earlier entry (taller wave tiles re-read fewer weights per MFMA)
+static const TileCfgB kTileCfgsB[9] = {{4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {2, 1, 4}, {2, 2, 2}, {2, 4, 1}, {1, 1, 4}, {1, 2, 2}, {1, 4, 1}};
+
+template <int MI, int WM, int WN, int NC16>
+static hipError_t launch_conv_b(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((conv_mfma_bf16x3_kernel<MI, WM, WN, NC16>), grid, dim3(256), lds, stream, mp);
+    return hipGetLastError();
+}
+
+static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows,
+                              const float* (*xin)[3], int nin, const float* const* res, float* const* y, float slope,
+                              hipStream_t stream) {
+    const ConvLayer& L0 = *layers[0];
+    TileCfgB tc = kTileCfgsB[0];
+    double best = 1e300;
+    for (const TileCfgB& t : kTileCfgsB) {
+        const int TM = t.WM * t.MI * 32;
+        const double cost = (double)((rows + TM - 1) / TM) * TM * ((L0.n_blocks32 + t.WN - 1) / t.WN) * t.WN;
+        if (cost < best - 0.5) {
+            best = cost;
+            tc = t;
+        }
+    }
+    const int TM = tc.WM * tc.MI * 32;
+    const int nc16 = L0.chunk16 / 16;
+    MultiConvParams mp;
+    memset(&mp, 0, sizeof(mp));
+    int max_halo = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int b = 0; b < nbr; ++b) {
+        const ConvLayer& Lb = *layers[b];
+        fill_params(mp.p[b], Lb, rows, TM, xin[b], nin, res ? res[b] : nullptr, y[b], slope);
+        max_halo = std::max(max_halo, mp.p[b].halo);
+        if (Lb.n_blocks32 != L0.n_blocks32 || Lb.chunk16 != L0.chunk16) return fail(HIFICAR_E_INVALID, "internal: branch shape mismatch");
+        const double pos = (double)nseq * rows;
+        flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K;
+        bytes += 4.0 * (pos * Lb.cin_pad * nin + pos * Lb.cout_total * (res ? 2 : 1) + (double)Lb.cin * Lb.cout * Lb.K);
+    }
+    const size_t lds = (size_t)(TM + max_halo) * (L0.chunk16 * 4 + 16);
+    if (lds > 160 * 1024) return fail(HIFICAR_E_INVALID, "internal: LDS tile too large (%zu)", lds);
+    dim3 grid((unsigned)(nseq * ((rows + TM - 1) / TM)), (unsigned)((L0.n_blocks32 + tc.WN - 1) / tc.WN), (unsigned)nbr);
+    char kname[96];
+    snprintf(kname, sizeof(kname), "conv_mfma_bf16x3_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, nc16);
+    ProfScope prof(h, stream, kname, flops, bytes);
+    hipError_t e = hipErrorInvalidValue;
+#define HIFICAR_DISPATCH_B(mi, wm, wn, nc) \
+    if (tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_b<mi, wm, wn, nc>(mp, grid, lds, stream);
+    HIFICAR_FOR_BF16_ALL(HIFICAR_DISPATCH_B)
+#undef HIFICAR_DISPATCH_B
+    if (e != hipSuccess) return fail(HIFICAR_E_HIP, "conv launch (%s, %s) failed: %s", L0.name.c_str(), kname, hipGetErrorString(e));
+    return HIFICAR_OK;
+}
+
 static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows,
                        const float* (*xin)[3], int nin, const float* const* res, float* const* y, float slope,
                        hipStream_t stream) {
+    if (h->precision == HIFICAR_PREC_BF16X3) return launch_conv_bf16x3(h, layers, nbr, nseq, rows, xin, nin, res, y, slope, stream);
     const ConvLayer& L0 = *layers[0];
     const TileCfg tc = pick_tile(L0, rows);
     const int TM = tc.WM * tc.MI * 32;

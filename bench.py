@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0, help="clip length")
     ap.add_argument("--chunk-frames", type=int, default=25, help="batch_max_steps // hop_size (e2w_hifigan_car.yaml: 2000/80)")
-    ap.add_argument("--precision", default=os.environ.get("HIFICAR_PRECISION", "f32"), choices=["f32", "bf16x3"])
+    ap.add_argument("--precision", default=os.environ.get("HIFICAR_PRECISION", "bf16x3"), choices=["f32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
