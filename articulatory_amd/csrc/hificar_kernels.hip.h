@@ -282,35 +282,62 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16x3_kernel(const MultiConvPa
 
     for (int c0 = 0; c0 < p.cin; c0 += CH) {
         __syncthreads();
-        for (int idx = tid; idx < R * C4N; idx += 256) {
+        // ---- stage split(act(X))[rows, c0 : c0+CH]; loads are issued UB at a time before any is consumed ----
+        constexpr int UB = 8;
+        const int n_units = R * C4N;
+        auto split_store = [&](int idx, const f32x4& v) {
             const int r = idx / C4N;
             const int c4 = idx - r * C4N;
-            const int t = t0 + p.off_min + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < p.L) {
-                const size_t off = (seq_base + t) * p.cin + c0 + c4 * 4;
-                v = *reinterpret_cast<const f32x4*>(p.x0 + off);
-                if (p.nin == 3) {
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.x1 + off);
-                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(p.x2 + off);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ((v[e] + v1[e]) + v2[e]) / 3.0f;
-                } else if (p.nin == 2) {
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.x1 + off);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (v[e] + v1[e]) / 2.0f;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], slope);
-            }
             bf16x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hi[e] = (__bf16)v[e];
-                lo[e] = (__bf16)(v[e] - (float)hi[e]);
+                const float a = lrelu(v[e], slope);
+                hi[e] = (__bf16)a;
+                lo[e] = (__bf16)(a - (float)hi[e]);
             }
             *reinterpret_cast<bf16x4*>(smem_b + r * PITCH + c4 * 8) = hi;
             *reinterpret_cast<bf16x4*>(smem_b + r * PITCH + CH * 2 + c4 * 8) = lo;
+        };
+        if (p.nin == 1) {
+            for (int base = 0; base < n_units; base += 256 * UB) {
+                f32x4 v[UB];
+#pragma unroll
+                for (int q = 0; q < UB; ++q) {
+                    const int idx = base + q * 256 + tid;
+                    const int r = idx / C4N;
+                    const int c4 = idx - r * C4N;
+                    const int t = t0 + p.off_min + r;
+                    v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (idx < n_units && t >= 0 && t < p.L)
+                        v[q] = *reinterpret_cast<const f32x4*>(p.x0 + (seq_base + t) * p.cin + c0 + c4 * 4);
+                }
+#pragma unroll
+                for (int q = 0; q < UB; ++q) {
+                    const int idx = base + q * 256 + tid;
+                    if (idx < n_units) split_store(idx, v[q]);
+                }
+            }
+        } else {  // MRF mean of the previous stage's ResBlock outputs (upsample convs only)
+            for (int idx = tid; idx < n_units; idx += 256) {
+                const int r = idx / C4N;
+                const int c4 = idx - r * C4N;
+                const int t = t0 + p.off_min + r;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (t >= 0 && t < p.L) {
+                    const size_t off = (seq_base + t) * p.cin + c0 + c4 * 4;
+                    v = *reinterpret_cast<const f32x4*>(p.x0 + off);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.x1 + off);
+                    if (p.nin == 3) {
+                        const f32x4 v2 = *reinterpret_cast<const f32x4*>(p.x2 + off);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ((v[e] + v1[e]) + v2[e]) / 3.0f;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (v[e] + v1[e]) / 2.0f;
+                    }
+                }
+                split_store(idx, v);
+            }
         }
         __syncthreads();
         if (!active) continue;
@@ -327,9 +354,10 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16x3_kernel(const MultiConvPa
                 for (int mi = 0; mi < MI; ++mi) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arow + mi * 32 * PITCH + u * 32);
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(arow + mi * 32 * PITCH + CH * 2 + u * 32);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mi], 0, 0, 0);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mi], 0, 0, 0);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mi], 0, 0, 0);
+                    // D^T = W * X^T: rows = channels, cols = time, so a lane ends up with 4 adjacent channels per register quad
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[mi], 0, 0, 0);
                 }
             }
             wp += NC16 * 128;
@@ -337,19 +365,26 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16x3_kernel(const MultiConvPa
     }
     if (!active) return;
 
-    const int co = nb * 32 + li;
-    const float bj = p.bias[co];
+    // epilogue: lane holds time column t = li and channels co = 8q + 4g + {0..3} in acc[mi][4q .. 4q+3]
+    f32x4 bias4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias4[q] = *reinterpret_cast<const f32x4*>(p.bias + nb * 32 + 8 * q + 4 * g);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+        const int t = t0 + wave_row0 + mi * 32 + li;
+        if (t < p.L) {
+            const size_t off = (seq_base + t) * p.cout_total + nb * 32 + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave_row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            const int t = t0 + row;
-            if (t < p.L) {
-                const size_t off = (seq_base + t) * p.cout_total + co;
-                float v = acc[mi][r] + bj;
-                if (p.res) v += p.res[off];
-                p.y[off] = v;
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mi][4 * q + e] + bias4[q][e];
+                if (p.res) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + off + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                }
+                *reinterpret_cast<f32x4*>(p.y + off + 8 * q) = v;
             }
         }
     }
