@@ -165,6 +165,10 @@ static int plan_layer(ConvLayer& L) {
             }
         }
     }
+    for (int r = 0; r < L.n_phase; ++r)
+        for (int t = 1; t < L.ntaps; ++t)
+            if (L.tap_off[r][t] - L.tap_off[r][t - 1] != L.tap_off[0][1] - L.tap_off[0][0])
+                return fail(HIFICAR_E_INVALID, "%s: tap offsets are not an arithmetic progression", L.name.c_str());
     L.off_min = 0;
     L.off_max = 0;
     for (int r = 0; r < L.n_phase; ++r)
@@ -203,6 +207,8 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (!c.use_additional_convs) return fail(HIFICAR_E_INVALID, "use_additional_convs=false is unsupported");
     if (c.use_ar && (c.ar_input > 1024 || c.ar_hidden > 1024 || c.ar_output > 1024 || c.ar_input < 1))
         return fail(HIFICAR_E_INVALID, "PastFCEncoder dims must be <= 1024");
+    if (c.use_ar && (c.ar_hidden % 4 != 0 || c.ar_output % 4 != 0))
+        return fail(HIFICAR_E_INVALID, "PastFCEncoder hidden/output dims must be multiples of 4");
     if (c.precision != HIFICAR_PREC_F32 && c.precision != HIFICAR_PREC_BF16X3)
         return fail(HIFICAR_E_INVALID, "unknown precision %d", c.precision);
     if (c.channels % (1 << c.n_stages) != 0) return fail(HIFICAR_E_INVALID, "channels=%d not divisible by 2^n_stages", c.channels);
@@ -616,7 +622,8 @@ static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, con
     p.halo = L.off_max - L.off_min;
     p.nin = nin;
     p.slope = slope;
-    memcpy(p.tap_off, L.tap_off, sizeof(p.tap_off));
+    p.tap_step = L.ntaps > 1 ? L.tap_off[0][1] - L.tap_off[0][0] : 0;
+    for (int r = 0; r < kMaxPhase; ++r) p.tap_off0[r] = r < L.n_phase ? L.tap_off[r][0] : 0;
 }
 
 template <int MI, int NJ, int WM, int WN>

@@ -54,7 +54,11 @@ struct ConvParams {
     int halo;           // off_max - off_min
     int nin;            // number of inputs averaged while staging (1..3)
     float slope;        // LeakyReLU slope applied to the staged input; 1.0f = identity
-    int tap_off[kMaxPhase][kMaxTaps];
+    // tap t of phase r reads input row  t_out + tap_off0[r] + t * tap_step  (an arithmetic progression for both
+    // Conv1d: -padding + t*dilation, and the polyphase ConvTranspose1d: floor((r+p)/s) - t); no per-tap table
+    // lookups in the K loop (a memory lookup there would drain the weight prefetch queue with vmcnt(0)).
+    int tap_step;
+    int tap_off0[kMaxPhase];
 };
 
 struct MultiConvParams {
@@ -119,8 +123,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const MultiConvParam
     const float* wblk = p.w + (size_t)(active ? nb : 0) * p.ntaps * p.cin * NB;
     const int wave_row0 = wm * (MI * 32);
     const float slope = p.slope;
-    const float* tapoff = nullptr;
-    (void)tapoff;
+    const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
 
     for (int c0 = 0; c0 < p.cin; c0 += p.chunk) {
         __syncthreads();
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const MultiConvParam
         if (!active) continue;
         // ---- MFMA over taps x channels of this chunk ----
         for (int t = 0; t < p.ntaps; ++t) {
-            const int roff = p.tap_off[phase][t] - p.off_min;  // >= 0
+            const int roff = roff0 + t * p.tap_step;  // >= 0
             const float* arow = &smem[(wave_row0 + li + roff) * P + 4 * g];
             const float* wrow = wblk + ((size_t)t * p.cin + c0 + 4 * g) * NB + NJ * li;
             for (int c8 = 0; c8 < p.chunk; c8 += 8) {
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16x3_kernel(const MultiConvPa
     }
     wp += NC16 * 128;
     const int wave_row0 = wm * (MI * 32);
+    const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
 
     for (int c0 = 0; c0 < p.cin; c0 += CH) {
         __syncthreads();
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16x3_kernel(const MultiConvPa
         __syncthreads();
         if (!active) continue;
         for (int t = 0; t < p.ntaps; ++t) {
-            const int roff = p.tap_off[phase][t] - p.off_min;
+            const int roff = roff0 + t * p.tap_step;
             const char* arow = smem_b + (wave_row0 + li + roff) * PITCH + g * 16;
 #pragma unroll
             for (int u = 0; u < NC16; ++u) {
@@ -396,7 +400,9 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16x3_kernel(const MultiConvPa
 //   xin[b, t, 0:cf]        = c[b, :, t]                (features, (B, C, T) -> channels-last)
 //   xin[b, t, cf:cf+ar_out] = MLP(prev[b, :])          (time-constant AR channels)
 //   xin[b, t, rest]        = 0                         (pad to a multiple of 16 channels)
-// MLP weights are stored transposed (in, out) so that thread j's reads are coalesced over j.
+// MLP weights are stored transposed (in, out): a lane reads 4 adjacent outputs (16 B) per input row, 1 KB per
+// wave-instruction; the four waves split the input dimension and reduce through LDS.  The MLP sits on the
+// AR critical path (chunk n+1 cannot start before it), so it is built for latency: 8 loads in flight per lane.
 // ------------------------------------------------------------------------------------------------
 struct FrontParams {
     const float* c;       // features; element (b, ch, t) at c[b*c_bstride + ch*c_cstride + t]
@@ -415,30 +421,56 @@ struct FrontParams {
 };
 
 __global__ __launch_bounds__(256) void front_kernel(const FrontParams p) {
-    __shared__ float bufA[1024];
-    __shared__ float bufB[1024];
+    __shared__ __attribute__((aligned(16))) float act[2][1024];
+    __shared__ __attribute__((aligned(16))) float part[4][1024];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    float* cur = bufA;
-    float* nxt = bufB;
+    const int lane = tid & 63;
+    const int ks = tid >> 6;  // wave index = K slice: each wave reduces a quarter of the input dimension
+    int cur = 0;
     if (p.use_ar) {
-        for (int i = tid; i < p.ar_input; i += 256) cur[i] = p.prev ? p.prev[(size_t)b * p.prev_bstride + i] : 0.f;
+        for (int i = tid; i < p.ar_input; i += 256) act[0][i] = p.prev ? p.prev[(size_t)b * p.prev_bstride + i] : 0.f;
         __syncthreads();
         int din = p.ar_input;
         for (int layer = 0; layer < 5; ++layer) {
             const int dout = layer == 4 ? p.ar_output : p.ar_hidden;
             const float* wt = p.wt[layer];
-            for (int j = tid; j < dout; j += 256) {
-                float s = p.bs[layer][j];
-                for (int i = 0; i < din; ++i) s = fmaf(cur[i], wt[(size_t)i * dout + j], s);
-                nxt[j] = layer < 4 ? lrelu(s, 0.1f) : s;
+            const float* x = act[cur];
+            const int i0 = (din * ks) / 4, i1 = (din * (ks + 1)) / 4;
+            for (int j4 = lane * 4; j4 < dout; j4 += 256) {  // dims are multiples of 4 (checked at create)
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                int i = i0;
+                for (; i + 8 <= i1; i += 8) {  // 8 independent 16-byte loads in flight per lane
+                    f32x4 w[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(wt + (size_t)(i + q) * dout + j4);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float xv = x[i + q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[e] = fmaf(xv, w[q][e], s[e]);
+                    }
+                }
+                for (; i < i1; ++i) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wt + (size_t)i * dout + j4);
+                    const float xv = x[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] = fmaf(xv, w[e], s[e]);
+                }
+                *reinterpret_cast<f32x4*>(&part[ks][j4]) = s;
             }
             __syncthreads();
-            float* tmp = cur; cur = nxt; nxt = tmp;
+            for (int j = tid; j < dout; j += 256) {
+                const float v = ((part[0][j] + part[1][j]) + (part[2][j] + part[3][j])) + p.bs[layer][j];
+                act[cur ^ 1][j] = layer < 4 ? lrelu(v, 0.1f) : v;
+            }
+            __syncthreads();
+            cur ^= 1;
             din = dout;
         }
     }
-    // cur[0:ar_output] now holds the AR features
+    // act[cur][0:ar_output] now holds the AR features
+    const float* feats = act[cur];
     const int n = p.T * p.cin_pad;
     float* xo = p.xin + (size_t)b * n;
     for (int idx = tid; idx < n; idx += 256) {
@@ -446,7 +478,7 @@ __global__ __launch_bounds__(256) void front_kernel(const FrontParams p) {
         const int ch = idx - t * p.cin_pad;
         float v = 0.f;
         if (ch < p.cf) v = p.c[(size_t)b * p.c_bstride + (size_t)ch * p.c_cstride + t];
-        else if (p.use_ar && ch < p.cf + p.ar_output) v = cur[ch - p.cf];
+        else if (p.use_ar && ch < p.cf + p.ar_output) v = feats[ch - p.cf];
         xo[idx] = v;
     }
 }
