@@ -69,9 +69,11 @@ struct hificar_handle {
     hificar_config cfg;
     bool finalized = false;
     int precision = HIFICAR_PREC_F32;
+    bool profile_detail = false;   // HIFICAR_PROFILE_DETAIL=1: profile rows carry the layer name
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
     int cin_pad = 0;  // padded input-conv channels
     int hop = 1;
+    int num_cus = 256;
     std::map<std::string, std::vector<int64_t>> expected;  // name -> shape
     std::map<std::string, HostTensor> tensors;
     ConvLayer input_conv;
@@ -85,6 +87,7 @@ struct hificar_handle {
     float* d_mlp_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float* d_mlp_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs;
+    char* d_zeros = nullptr;  // 256 bytes of zeros: source of padding rows for the LDS DMA
     // profiling (hificar_profile_begin/end)
     bool profiling = false;
     struct ProfRec {
@@ -130,6 +133,8 @@ static int conv_index(const hificar_handle* h, int stage, int block, int dil) {
 
 // Derive tap tables and blocking for one layer.
 static int plan_layer(ConvLayer& L) {
+    if (L.cin_pad < 32)
+        return fail(HIFICAR_E_INVALID, "%s: needs at least 32 (padded) input channels", L.name.c_str());
     if (L.cout % 32 != 0)
         return fail(HIFICAR_E_INVALID, "%s: output channels (%d) must be a multiple of 32 for the MFMA kernels",
                     L.name.c_str(), L.cout);
@@ -183,9 +188,8 @@ static int plan_layer(ConvLayer& L) {
     L.chunk = 8;
     for (int c = 8; c <= 64; c += 8)
         if (L.cin_pad % c == 0) L.chunk = c;
-    L.chunk16 = 16;
-    for (int c = 16; c <= 64; c += 16)
-        if (L.cin_pad % c == 0) L.chunk16 = c;
+    // 16/32/64 channels per LDS item (XOR-swizzled rows), and at least two items per tile (out-buffer hand-off)
+    L.chunk16 = (L.cin_pad % 64 == 0 && L.cin_pad >= 128) ? 64 : (L.cin_pad % 32 == 0 && L.cin_pad >= 64) ? 32 : 16;
     L.n_blocks32 = L.cout_total / 32;
     L.nb32_per_phase = L.cout / 32;
     return HIFICAR_OK;
@@ -209,19 +213,27 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
         return fail(HIFICAR_E_INVALID, "PastFCEncoder dims must be <= 1024");
     if (c.use_ar && (c.ar_hidden % 4 != 0 || c.ar_output % 4 != 0))
         return fail(HIFICAR_E_INVALID, "PastFCEncoder hidden/output dims must be multiples of 4");
+    if (!(c.lrelu_slope >= 0.f && c.lrelu_slope <= 1.f)) return fail(HIFICAR_E_INVALID, "negative_slope=%g outside [0, 1]", c.lrelu_slope);
     if (c.precision != HIFICAR_PREC_F32 && c.precision != HIFICAR_PREC_BF16X3)
         return fail(HIFICAR_E_INVALID, "unknown precision %d", c.precision);
     if (c.channels % (1 << c.n_stages) != 0) return fail(HIFICAR_E_INVALID, "channels=%d not divisible by 2^n_stages", c.channels);
 
     hificar_handle* h = new hificar_handle();
     h->cfg = c;
+    if (const char* e = getenv("HIFICAR_PROFILE_DETAIL")) h->profile_detail = atoi(e) != 0;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            h->num_cus = prop.multiProcessorCount;
+    }
     h->precision = c.precision;
     h->cf = c.in_channels - (c.use_ar ? c.ar_output : 0);
     if (h->cf < 1) {
         delete h;
         return fail(HIFICAR_E_INVALID, "in_channels=%d leaves no feature channels", c.in_channels);
     }
-    h->cin_pad = round_up(c.in_channels, 16);
+    h->cin_pad = std::max(32, round_up(c.in_channels, 16));
     h->hop = 1;
     for (int i = 0; i < c.n_stages; ++i) h->hop *= c.upsample_scales[i];
 
@@ -441,14 +453,14 @@ static hipError_t set_lds_attr() {
 
 template <int MI, int WM, int WN, int NC16>
 static hipError_t set_lds_attr_b() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3_kernel<MI, WM, WN, NC16>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MI, WM, WN, NC16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 // every (MI, WM, WN) x NC16 instantiation of the bf16x3 kernel
 #define HIFICAR_FOR_BF16_TILES(X, nc) \
     X(4, 1, 4, nc) X(4, 2, 2, nc) X(4, 4, 1, nc) X(2, 1, 4, nc) X(2, 2, 2, nc) X(2, 4, 1, nc) X(1, 1, 4, nc) X(1, 2, 2, nc) X(1, 4, 1, nc)
-#define HIFICAR_FOR_BF16_ALL(X) HIFICAR_FOR_BF16_TILES(X, 1) HIFICAR_FOR_BF16_TILES(X, 2) HIFICAR_FOR_BF16_TILES(X, 3) HIFICAR_FOR_BF16_TILES(X, 4)
+#define HIFICAR_FOR_BF16_ALL(X) HIFICAR_FOR_BF16_TILES(X, 1) HIFICAR_FOR_BF16_TILES(X, 2) HIFICAR_FOR_BF16_TILES(X, 4)
 
 extern "C" int hificar_finalize(hificar_handle* h) {
     if (!h) return fail(HIFICAR_E_INVALID, "hificar_finalize: null handle");
@@ -482,6 +494,13 @@ extern "C" int hificar_finalize(hificar_handle* h) {
             if ((rc = upload(h, wt, &h->d_mlp_w[l])) != HIFICAR_OK) return rc;
             if ((rc = upload(h, h->tensors.at("ar_model.model." + std::to_string(2 * l) + ".bias").data, &h->d_mlp_b[l])) != HIFICAR_OK) return rc;
         }
+    }
+    {
+        void* z = nullptr;
+        HIP_TRY(hipMalloc(&z, 256));
+        h->allocs.push_back(z);
+        HIP_TRY(hipMemset(z, 0, 256));
+        h->d_zeros = static_cast<char*>(z);
     }
     HIP_TRY((set_lds_attr<1, 4, 4, 1>()));
     HIP_TRY((set_lds_attr<1, 4, 2, 2>()));
@@ -517,11 +536,13 @@ extern "C" int hificar_set_precision(hificar_handle* h, int precision) {
 // workspace plan
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-    float* xin;
-    float* h0;
-    float* u;
-    float* x[3];
-    float* xt[3];
+    float* xin;    // f32 path: (B, T, cin_pad); bf16x3 path: the same bytes hold split rows
+    float* h0;     // input conv output (f32 rows / split rows)
+    float* u;      // upsample output, fp32 (residual of the first ResBlock layer)
+    float* x[3];   // per-branch residual stream, fp32
+    float* xt[3];  // f32 path: conv1 output fp32; bf16x3 path: conv1 output as split rows
+    char* u_s;     // bf16x3 path: split copy of LeakyReLU(u)
+    char* x_s[3];  // bf16x3 path: split copy of LeakyReLU(x_j)
     size_t bytes;
 };
 
@@ -534,12 +555,13 @@ static size_t stage_elems(const hificar_handle* h, int B, int T) {
     return mx * (size_t)B;
 }
 
+// One layout for both arithmetics (set_precision may switch a live handle): split rows are 4 bytes per element too.
 static Workspace plan_workspace(const hificar_handle* h, int B, int T, void* base) {
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t elems) {
         float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr;
-        off += round_up_sz(elems * sizeof(float), 256);
+        off += round_up_sz(elems * sizeof(float), 1024);
         return p;
     };
     w.xin = take((size_t)B * T * h->cin_pad);
@@ -548,6 +570,8 @@ static Workspace plan_workspace(const hificar_handle* h, int B, int T, void* bas
     w.u = take(se);
     for (int j = 0; j < 3; ++j) w.x[j] = take(se);
     for (int j = 0; j < 3; ++j) w.xt[j] = take(se);
+    w.u_s = reinterpret_cast<char*>(take(se));
+    for (int j = 0; j < 3; ++j) w.x_s[j] = reinterpret_cast<char*>(take(se));
     w.bytes = off;
     return w;
 }
@@ -600,7 +624,7 @@ static TileCfg pick_tile(const ConvLayer& L, int rows) {
 
 static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, const float* const* xin, int nin,
                         const float* res, float* y, float slope) {
-    p.x0 = xin[0];
+    p.x0 = nin > 0 ? xin[0] : nullptr;
     p.x1 = nin > 1 ? xin[1] : nullptr;
     p.x2 = nin > 2 ? xin[2] : nullptr;
     p.w = L.d_w;
@@ -636,26 +660,55 @@ static hipError_t launch_conv_t(const MultiConvParams& mp, dim3 grid, size_t lds
 struct TileCfgB {
     int MI, WM, WN;
 };
+static size_t out_buf_bytes(const TileCfgB& t) { return (size_t)(t.WM * t.MI * 32) * (t.WN * 32 + 4) * sizeof(float); }
 // preference order: ties keep the earlier entry (taller wave tiles re-read fewer weights per MFMA)
 static const TileCfgB kTileCfgsB[9] = {{4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {2, 1, 4}, {2, 2, 2}, {2, 4, 1}, {1, 1, 4}, {1, 2, 2}, {1, 4, 1}};
 
 template <int MI, int WM, int WN, int NC16>
 static hipError_t launch_conv_b(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((conv_mfma_bf16x3_kernel<MI, WM, WN, NC16>), grid, dim3(256), lds, stream, mp);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<MI, WM, WN, NC16>), grid, dim3(512), lds, stream, mp);
     return hipGetLastError();
 }
 
-static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows,
-                              const float* (*xin)[3], int nin, const float* const* res, float* const* y, float slope,
-                              hipStream_t stream) {
+// bf16x3 conv on split rows.  Per branch: xs (split input) -> y (fp32, nullable) and/or ys (split copy of
+// LeakyReLU(out, slope_out), nullable), + optional fp32 residual.
+struct ConvIOB {
+    const char* xs;
+    const float* res;
+    float* y;
+    char* ys;
+};
+
+static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows, const ConvIOB* io,
+                              float slope_out, hipStream_t stream) {
     const ConvLayer& L0 = *layers[0];
-    TileCfgB tc = kTileCfgsB[0];
+    int halo_all = 0;
+    for (int b = 0; b < nbr; ++b) halo_all = std::max(halo_all, layers[b]->off_max - layers[b]->off_min);
+    const int RB = L0.chunk16 * 4;
+    // Tile shape: simulate the kernel's static tile walk (workgroup w takes tiles w, w+G, ...; branch-major order) and
+    // take the shape with the smallest makespan.  A tile costs its MFMA issue cycles (all four MFMA waves run in
+    // lock step: 3*MI MFMAs of 32 cycles per 16-channel K slab) plus a fixed per-tile and per-item overhead.
+    TileCfgB tc = kTileCfgsB[8];
     double best = 1e300;
     for (const TileCfgB& t : kTileCfgsB) {
         const int TM = t.WM * t.MI * 32;
-        const double cost = (double)((rows + TM - 1) / TM) * TM * ((L0.n_blocks32 + t.WN - 1) / t.WN) * t.WN;
-        if (cost < best - 0.5) {
-            best = cost;
+        if (2 * round_up_sz((size_t)(TM + halo_all) * RB, 1024) + out_buf_bytes(t) > 160 * 1024) continue;
+        const long long tiles_per_branch = (long long)nseq * ((rows + TM - 1) / TM) * ((L0.n_blocks32 + t.WN - 1) / t.WN);
+        const long long total = tiles_per_branch * nbr;
+        const int G = (int)std::min<long long>(total, h->num_cus);
+        const int nchunks = L0.cin_pad / L0.chunk16;
+        double worst = 0.0;
+        // workgroups 0 and G-1 bracket the load (earlier ids get the extra tile of a partial round)
+        for (int w : {0, G - 1}) {
+            double acc = 0.0;
+            for (long long i = w; i < total; i += G) {
+                const ConvLayer& Lb = *layers[i / tiles_per_branch];
+                acc += (double)Lb.ntaps * (L0.cin_pad / 16) * 3 * t.MI * 32 / 0.75 + 2500.0 + 400.0 * nchunks;
+            }
+            worst = std::max(worst, acc);
+        }
+        if (worst < best * 0.98) {  // near-ties keep the earlier (taller) shape
+            best = worst;
             tc = t;
         }
     }
@@ -663,22 +716,38 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
     const int nc16 = L0.chunk16 / 16;
     MultiConvParams mp;
     memset(&mp, 0, sizeof(mp));
-    int max_halo = 0;
     double flops = 0.0, bytes = 0.0;
     for (int b = 0; b < nbr; ++b) {
         const ConvLayer& Lb = *layers[b];
-        fill_params(mp.p[b], Lb, rows, TM, xin[b], nin, res ? res[b] : nullptr, y[b], slope);
-        max_halo = std::max(max_halo, mp.p[b].halo);
-        if (Lb.n_blocks32 != L0.n_blocks32 || Lb.chunk16 != L0.chunk16) return fail(HIFICAR_E_INVALID, "internal: branch shape mismatch");
+        if (Lb.n_blocks32 != L0.n_blocks32 || Lb.chunk16 != L0.chunk16 || Lb.cin_pad != L0.cin_pad)
+            return fail(HIFICAR_E_INVALID, "internal: branch shape mismatch");
+        const float* none[3] = {nullptr, nullptr, nullptr};
+        fill_params(mp.p[b], Lb, rows, TM, none, 0, io[b].res, io[b].y, 1.0f);
+        mp.p[b].xs = io[b].xs;
+        mp.p[b].ys = io[b].ys;
+        mp.p[b].zeros = h->d_zeros;
+        mp.p[b].slope_out = slope_out;
+        mp.p[b].cout_real = Lb.cout;
         const double pos = (double)nseq * rows;
         flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K;
-        bytes += 4.0 * (pos * Lb.cin_pad * nin + pos * Lb.cout_total * (res ? 2 : 1) + (double)Lb.cin * Lb.cout * Lb.K);
+        bytes += 4.0 * (pos * Lb.cin_pad + pos * Lb.cout_total * ((io[b].res ? 1 : 0) + (io[b].y ? 1 : 0) + (io[b].ys ? 1 : 0)) +
+                        (double)Lb.cin * Lb.cout * Lb.K);
     }
-    const size_t lds = (size_t)(TM + max_halo) * (L0.chunk16 * 4 + 16);
-    if (lds > 160 * 1024) return fail(HIFICAR_E_INVALID, "internal: LDS tile too large (%zu)", lds);
-    dim3 grid((unsigned)(nseq * ((rows + TM - 1) / TM)), (unsigned)((L0.n_blocks32 + tc.WN - 1) / tc.WN), (unsigned)nbr);
+    const size_t buf_bytes = round_up_sz((size_t)(TM + halo_all) * RB, 1024);
+    const size_t lds = 2 * buf_bytes + out_buf_bytes(tc);
+    mp.n_branches = nbr;
+    mp.nseq_tiles = nseq * ((rows + TM - 1) / TM);
+    mp.ngroups = (L0.n_blocks32 + tc.WN - 1) / tc.WN;
+    mp.total_tiles = nbr * mp.ngroups * mp.nseq_tiles;
+    mp.buf_bytes = (int)buf_bytes;
+    mp.trace = nullptr;
+    dim3 grid((unsigned)std::min(mp.total_tiles, h->num_cus), 1, 1);  // persistent: one workgroup per CU walks the tile list
     char kname[96];
-    snprintf(kname, sizeof(kname), "conv_mfma_bf16x3_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, nc16);
+    snprintf(kname, sizeof(kname), "conv_bf16x3_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, nc16);
+    if (h->profile_detail) {  // per-layer rows in the profile (tools/layer_profile.py)
+        const size_t n = strlen(kname);
+        snprintf(kname + n, sizeof(kname) - n, "|%s x%d", L0.name.c_str(), nbr);
+    }
     ProfScope prof(h, stream, kname, flops, bytes);
     hipError_t e = hipErrorInvalidValue;
 #define HIFICAR_DISPATCH_B(mi, wm, wn, nc) \
@@ -692,7 +761,6 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
 static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows,
                        const float* (*xin)[3], int nin, const float* const* res, float* const* y, float slope,
                        hipStream_t stream) {
-    if (h->precision == HIFICAR_PREC_BF16X3) return launch_conv_bf16x3(h, layers, nbr, nseq, rows, xin, nin, res, y, slope, stream);
     const ConvLayer& L0 = *layers[0];
     const TileCfg tc = pick_tile(L0, rows);
     const int TM = tc.WM * tc.MI * 32;
@@ -753,7 +821,9 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     fp.c_cstride = c_cstride;
     fp.prev = prev;
     fp.prev_bstride = prev_bstride;
-    fp.xin = ws.xin;
+    const bool split = h->precision == HIFICAR_PREC_BF16X3;
+    fp.xin = split ? nullptr : ws.xin;
+    fp.xin_s = split ? reinterpret_cast<char*>(ws.xin) : nullptr;
     fp.T = T;
     fp.cf = h->cf;
     fp.cin_pad = h->cin_pad;
@@ -774,58 +844,117 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     HIP_TRY(hipGetLastError());
 
     int rc;
-    // 2. input conv (no activation in front of it: hifigan.py:221)
-    {
-        const ConvLayer* lay[1] = {&h->input_conv};
-        const float* xin[1][3] = {{ws.xin, nullptr, nullptr}};
-        float* y[1] = {ws.h0};
-        if ((rc = launch_conv(h, lay, 1, B, T, xin, 1, nullptr, y, 1.0f, stream)) != HIFICAR_OK) return rc;
-    }
-    // 3. stages
     int rows = T;
     const int nbk = cfg.n_blocks;
-    for (int i = 0; i < cfg.n_stages; ++i) {
-        {   // LeakyReLU + ConvTranspose1d (hifigan.py:224); input = previous stage's MRF mean
-            const ConvLayer* lay[1] = {&h->ups[i]};
-            const float* xin[1][3] = {{i == 0 ? ws.h0 : ws.x[0], i == 0 ? nullptr : (nbk > 1 ? ws.x[1] : nullptr),
-                                       i == 0 ? nullptr : (nbk > 2 ? ws.x[2] : nullptr)}};
-            float* y[1] = {ws.u};
-            if ((rc = launch_conv(h, lay, 1, B, rows, xin, i == 0 ? 1 : nbk, nullptr, y, cfg.lrelu_slope, stream)) != HIFICAR_OK)
-                return rc;
+    // residual blocks of a stage run side by side, heaviest kernel size first
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + nbk, [&](int a, int b) { return cfg.resblock_kernel_sizes[a] > cfg.resblock_kernel_sizes[b]; });
+    int max_d = 0;
+    for (int j = 0; j < nbk; ++j) max_d = std::max(max_d, cfg.n_dilations[j]);
+
+    if (split) {
+        // ---- bf16x3 path: activations travel as split rows; fp32 only where a residual / the MRF mean needs it ----
+        char* xin_s = reinterpret_cast<char*>(ws.xin);
+        char* h0_s = reinterpret_cast<char*>(ws.h0);
+        char* xt_s[3] = {reinterpret_cast<char*>(ws.xt[0]), reinterpret_cast<char*>(ws.xt[1]), reinterpret_cast<char*>(ws.xt[2])};
+        {   // 2. input conv (no activation in front of it: hifigan.py:221); its consumer applies LeakyReLU(slope)
+            const ConvLayer* lay[1] = {&h->input_conv};
+            const ConvIOB io[1] = {{xin_s, nullptr, nullptr, h0_s}};
+            if ((rc = launch_conv_bf16x3(h, lay, 1, B, T, io, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
         }
-        rows *= cfg.upsample_scales[i];
-        // residual blocks (residual_block.py:217-221); blocks run side by side, heaviest kernel size first
-        int order[3] = {0, 1, 2};
-        std::sort(order, order + nbk, [&](int a, int b) { return cfg.resblock_kernel_sizes[a] > cfg.resblock_kernel_sizes[b]; });
-        int max_d = 0;
-        for (int j = 0; j < nbk; ++j) max_d = std::max(max_d, cfg.n_dilations[j]);
-        for (int d = 0; d < max_d; ++d) {
-            const ConvLayer* l1[3];
-            const ConvLayer* l2[3];
-            const float* in1[3][3];
-            const float* in2[3][3];
-            const float* res[3];
-            float* y1[3];
-            float* y2[3];
-            int n = 0;
-            for (int oj = 0; oj < nbk; ++oj) {
-                const int j = order[oj];
-                if (d >= cfg.n_dilations[j]) continue;
-                const int ci = conv_index(h, i, j, d);
-                l1[n] = &h->convs1[ci];
-                l2[n] = &h->convs2[ci];
-                const float* xcur = d == 0 ? ws.u : ws.x[j];
-                in1[n][0] = xcur; in1[n][1] = nullptr; in1[n][2] = nullptr;
-                y1[n] = ws.xt[j];
-                in2[n][0] = ws.xt[j]; in2[n][1] = nullptr; in2[n][2] = nullptr;
-                res[n] = xcur;
-                y2[n] = ws.x[j];
-                ++n;
+        for (int i = 0; i < cfg.n_stages; ++i) {
+            const char* up_in = h0_s;
+            if (i > 0) {  // MRF mean of the previous stage (hifigan.py:226-230) + LeakyReLU + split, elementwise
+                MrfSplitParams mq;
+                memset(&mq, 0, sizeof(mq));
+                mq.x0 = ws.x[0];
+                mq.x1 = nbk > 1 ? ws.x[1] : nullptr;
+                mq.x2 = nbk > 2 ? ws.x[2] : nullptr;
+                mq.out = xt_s[0];
+                mq.nin = nbk;
+                mq.C = stage_channels(cfg, i);
+                mq.rows = (long long)B * rows;
+                mq.slope = cfg.lrelu_slope;
+                const long long units = mq.rows * (mq.C / 8);
+                const unsigned blocks = (unsigned)std::min<long long>((units + 255) / 256, 8LL * h->num_cus);
+                {
+                    ProfScope prof(h, stream, "mrf_split_kernel", 0.0, 4.0 * mq.rows * mq.C * (nbk + 1));
+                    hipLaunchKernelGGL(mrf_split_kernel, dim3(blocks), dim3(256), 0, stream, mq);
+                }
+                HIP_TRY(hipGetLastError());
+                up_in = xt_s[0];
             }
-            if ((rc = launch_conv(h, l1, n, B, rows, in1, 1, nullptr, y1, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
-            if ((rc = launch_conv(h, l2, n, B, rows, in2, 1, res, y2, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+            {   // LeakyReLU + ConvTranspose1d (hifigan.py:224): fp32 u (first residual) + split copy (first conv input)
+                const ConvLayer* lay[1] = {&h->ups[i]};
+                const ConvIOB io[1] = {{up_in, nullptr, ws.u, ws.u_s}};
+                if ((rc = launch_conv_bf16x3(h, lay, 1, B, rows, io, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+            }
+            rows *= cfg.upsample_scales[i];
+            for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
+                const ConvLayer* l1[3];
+                const ConvLayer* l2[3];
+                ConvIOB io1[3], io2[3];
+                int n = 0;
+                for (int oj = 0; oj < nbk; ++oj) {
+                    const int j = order[oj];
+                    if (d >= cfg.n_dilations[j]) continue;
+                    const int ci = conv_index(h, i, j, d);
+                    l1[n] = &h->convs1[ci];
+                    l2[n] = &h->convs2[ci];
+                    const bool last = d + 1 == cfg.n_dilations[j];
+                    io1[n] = {d == 0 ? ws.u_s : ws.x_s[j], nullptr, nullptr, xt_s[j]};
+                    io2[n] = {xt_s[j], d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : ws.x_s[j]};
+                    ++n;
+                }
+                if ((rc = launch_conv_bf16x3(h, l1, n, B, rows, io1, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+                if ((rc = launch_conv_bf16x3(h, l2, n, B, rows, io2, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+            }
         }
-        // a block with fewer dilations than another keeps its last x[j]; nothing to do
+    } else {
+        // ---- f32 path: fp32 rows everywhere, activation / MRF mean applied while staging ----
+        {   // 2. input conv (no activation in front of it: hifigan.py:221)
+            const ConvLayer* lay[1] = {&h->input_conv};
+            const float* xin[1][3] = {{ws.xin, nullptr, nullptr}};
+            float* y[1] = {ws.h0};
+            if ((rc = launch_conv(h, lay, 1, B, T, xin, 1, nullptr, y, 1.0f, stream)) != HIFICAR_OK) return rc;
+        }
+        for (int i = 0; i < cfg.n_stages; ++i) {
+            {   // LeakyReLU + ConvTranspose1d (hifigan.py:224); input = previous stage's MRF mean
+                const ConvLayer* lay[1] = {&h->ups[i]};
+                const float* xin[1][3] = {{i == 0 ? ws.h0 : ws.x[0], i == 0 ? nullptr : (nbk > 1 ? ws.x[1] : nullptr),
+                                           i == 0 ? nullptr : (nbk > 2 ? ws.x[2] : nullptr)}};
+                float* y[1] = {ws.u};
+                if ((rc = launch_conv(h, lay, 1, B, rows, xin, i == 0 ? 1 : nbk, nullptr, y, cfg.lrelu_slope, stream)) != HIFICAR_OK)
+                    return rc;
+            }
+            rows *= cfg.upsample_scales[i];
+            for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
+                const ConvLayer* l1[3];
+                const ConvLayer* l2[3];
+                const float* in1[3][3];
+                const float* in2[3][3];
+                const float* res[3];
+                float* y1[3];
+                float* y2[3];
+                int n = 0;
+                for (int oj = 0; oj < nbk; ++oj) {
+                    const int j = order[oj];
+                    if (d >= cfg.n_dilations[j]) continue;
+                    const int ci = conv_index(h, i, j, d);
+                    l1[n] = &h->convs1[ci];
+                    l2[n] = &h->convs2[ci];
+                    const float* xcur = d == 0 ? ws.u : ws.x[j];
+                    in1[n][0] = xcur; in1[n][1] = nullptr; in1[n][2] = nullptr;
+                    y1[n] = ws.xt[j];
+                    in2[n][0] = ws.xt[j]; in2[n][1] = nullptr; in2[n][2] = nullptr;
+                    res[n] = xcur;
+                    y2[n] = ws.x[j];
+                    ++n;
+                }
+                if ((rc = launch_conv(h, l1, n, B, rows, in1, 1, nullptr, y1, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+                if ((rc = launch_conv(h, l2, n, B, rows, in2, 1, res, y2, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+            }
+        }
     }
     // 4. output conv: LeakyReLU(0.01) + Conv1d + tanh (hifigan.py:146-159)
     OutConvParams op;

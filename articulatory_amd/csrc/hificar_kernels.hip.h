@@ -39,7 +39,13 @@ struct ConvParams {
     const bf16x8* w16;  // bf16x3 path: packed MFMA B fragments [n_block32][chunk][tap][c16][hi|lo][lane], 16 B each
     const float* bias;  // [cout_total] (never null; zeros when the layer has no bias)
     const float* res;   // residual, same layout as y, or null
-    float* y;
+    float* y;           // fp32 output (bf16x3 path: may be null when only the split copy is consumed)
+    // bf16x3 path ("split rows"): a row of C channels is stored as [hi: C bf16 | lo: C bf16] of act(x), 4*C bytes
+    const char* xs;     // input, already activated + split by its producer
+    char* ys;           // split copy of LeakyReLU(out, slope_out) for the consumer conv, or null
+    const char* zeros;  // >= 16 bytes of zeros (source of padding rows for the LDS DMA)
+    float slope_out;
+    int cout_real;      // channels per real output row (== cout_total except for the polyphase ConvTranspose1d)
     int L;              // rows (time steps) per sequence, input rows == output rows
     int tiles_per_seq;  // ceil(L / TM)
     int cin;            // padded input channels == row pitch of x*
@@ -63,7 +69,25 @@ struct ConvParams {
 
 struct MultiConvParams {
     ConvParams p[3];
+    // persistent-tile bookkeeping (wave-specialised kernel): tiles are numbered branch-major (heaviest branch
+    // first), then channel group, then (sequence, time tile); workgroup w takes tiles w, w + gridDim.x, ...
+    int n_branches;
+    int nseq_tiles;   // sequences * tiles_per_seq
+    int ngroups;      // ceil(n_blocks32 / WN)
+    int total_tiles;  // n_branches * ngroups * nseq_tiles
+    int buf_bytes;    // bytes of one LDS staging buffer (sized for the widest halo among the branches)
+    unsigned long long* trace;  // dev tool only (tools/conv_bench.hip, -DHIFICAR_TRACE): per-workgroup timeline
 };
+
+#ifdef HIFICAR_TRACE
+#define HIFICAR_STAMP(slot)                                                                            \
+    do {                                                                                               \
+        if (mp.trace && lane == 0 && (wave == 0 || wave == 4) && (slot) < 64)                          \
+            mp.trace[((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define HIFICAR_STAMP(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
 
@@ -224,173 +248,397 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const MultiConvParam
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution with fp32 operands split into bf16 hi + lo ("bf16x3"):
 //     x*w ~= x_hi*w_hi + x_hi*w_lo + x_lo*w_hi,   x_hi = bf16(x), x_lo = bf16(x - x_hi)
-// three v_mfma_f32_32x32x16_bf16 per 16-channel K slab, fp32 accumulate.  Each operand carries a
-// 16-bit significand (relative product error ~2^-16; measured end-to-end error vs the fp32 oracle is
-// ~1e-5 of max|y|, two orders inside the 1e-3 parity bar) at 16/3 = 5.3x the fp32-MFMA rate.
+// three v_mfma_f32_32x32x16_bf16 per 16-channel K slab, fp32 accumulate.  Each operand carries a 16-bit
+// significand (relative product error ~2^-16; measured end-to-end error vs the fp32 oracle ~1.5e-5 of max|y|,
+// two orders inside the 1e-3 parity bar) at 16/3 = 5.3x the fp32-MFMA rate.
 //
-//   workgroup = 4 waves as WM (time) x WN (32-channel blocks); a wave owns MI 32x32 tiles stacked in time:
-//   TM = WM*MI*32 rows, TN = WN*32 channels.  grid = (sequences * time tiles, ceil(n_blocks32/WN), branches).
-//   LDS row = [hi: CH bf16 | lo: CH bf16 | 16 B pad]  (pitch/16 odd => ds_read_b128 conflict-free over rows);
-//   LeakyReLU / MRF mean / zero padding / the hi-lo split all happen while staging.
-//   A fragment (32x32x16): lane l -> row l&31, k = 8*(l>>5)+j  == 16 contiguous bytes of the staged row.
-//   B fragments are pre-packed on the host in exactly the lane order the MFMA wants and streamed from
-//   L2 with one global_load_dwordx4 per lane, prefetched one whole tap (NC16 K-slabs) ahead through a
-//   register ring; the stream is contiguous across taps and chunks, so the prefetch runs through the
-//   chunk barrier.  Waves that share time rows (same wm) re-read the same A rows from LDS; waves that
-//   share channels (same wn) hit the same weight lines in L1/L2.
+// Activations travel between layers as "split rows" [hi: C bf16 | lo: C bf16] of LeakyReLU(x): the PRODUCER's
+// epilogue activates and splits once, so a consumer stages its input with pure LDS-DMA
+// (global_load_lds_dwordx4: no VGPRs, no VALU, zero rows from a zero page).  The fp32 value is written
+// next to it only where a residual add or the MRF mean needs it.
+//
+// Persistent + wave-specialised: 8 waves per workgroup, one workgroup per CU, each workgroup walks a static
+// list of output tiles (ids w, w+G, ...; ordered heaviest ResBlock branch first so every workgroup gets the same
+// mix of kernel sizes).  Waves 0-3 ("MFMA waves") only read LDS and issue MFMAs; when a tile is finished they
+// drop the raw accumulators into an LDS out-buffer and move on.  Waves 4-7 ("loaders") issue the DMA for the
+// NEXT (tile, channel chunk) item into a 2-deep LDS ring — across tile boundaries too — and run the whole
+// output pass of the PREVIOUS tile (bias, residual, fp32 store, LeakyReLU + split store) out of that buffer
+// with row-contiguous accesses, so neither staging nor the epilogue is ever on the matrix pipe's critical path.
+// One barrier per item; every launch uses >= 2 chunks per tile so that the out-buffer hand-off cannot race.
+//   tile = TM = WM*MI*32 time rows x TN = WN*32 channels; a wave owns MI 32x32 tiles stacked in time.
+//   LDS item = rows [t0+off_min, t0+TM+off_max) x CH channels, row = [hi CH | lo CH] = CH/4 16-byte slots,
+//   slot index XOR-swizzled by the row so that the 16 lanes of a ds_read_b128 group hit 16 distinct slots
+//   of the 256-byte bank row (LDS-DMA forbids padding: the destination is lane-linear).
+//   MFMA: D^T = W * X^T — weights are the A operand (pre-packed in lane order, streamed from L2 one tap
+//   ahead through a register ring whose pointer jumps to the next tile's stream during a tile's last tap),
+//   activations the B operand (lane l -> time row l&31, channels 8*(l>>5)+j = 16 contiguous bytes), software-
+//   pipelined one K slab ahead.  So a lane ends with 4 adjacent channels per register quad: 16-byte stores.
 // ------------------------------------------------------------------------------------------------
 template <int MI, int WM, int WN, int NC16>
-__global__ __launch_bounds__(256) void conv_mfma_bf16x3_kernel(const MultiConvParams mp) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams mp) {
+    static_assert(WM * WN == 4, "4 MFMA waves per workgroup");
+    static_assert(NC16 == 1 || NC16 == 2 || NC16 == 4, "chunk of 16, 32 or 64 channels");
     constexpr int TM = WM * MI * 32;
-    constexpr int CH = NC16 * 16;          // channels per staged chunk
-    constexpr int PITCH = CH * 4 + 16;     // bytes per LDS row
-    constexpr int C4N = CH / 4;
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    constexpr int CH = NC16 * 16;
+    constexpr int RB = CH * 4;            // bytes per LDS row
+    constexpr int SPR = CH / 4;           // 16-byte slots per row (4, 8, 16)
+    constexpr int LOG_SPR = NC16 == 4 ? 4 : NC16 == 2 ? 3 : 2;
+    constexpr int LOG_RPB = 4 - LOG_SPR;  // log2(rows per 256-byte bank row)
+    extern __shared__ __attribute__((aligned(1024))) char smem_b[];
 
-    const ConvParams& p = mp.p[blockIdx.z];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN;
-    const int wn = wave % WN;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int cw = wave & 3;
+    const int wm = cw / WN;
+    const int wn = cw % WN;
     const int li = lane & 31;
     const int g = lane >> 5;
+    const int nchunks = mp.p[0].cin / CH;  // identical for all branches of a launch
+    const int tiles_per_branch = mp.ngroups * mp.nseq_tiles;
+    const int buf_bytes = mp.buf_bytes;
 
-    const int seq = blockIdx.x / p.tiles_per_seq;
-    const int t0 = (blockIdx.x % p.tiles_per_seq) * TM;
-    const int nb = blockIdx.y * WN + wn;
-    const bool active = nb < p.n_blocks32;
-    const int phase = active ? nb / p.nb32_per_phase : 0;
-    const int R = TM + p.halo;
-    const size_t seq_base = (size_t)seq * p.L;
-    const float slope = p.slope;
+    struct Tile {
+        int b, ng, seq, t0;
+    };
+    auto decode = [&](int tile) {
+        Tile T;
+        T.b = tile / tiles_per_branch;
+        const int rem = tile - T.b * tiles_per_branch;
+        T.ng = rem / mp.nseq_tiles;
+        const int m = rem - T.ng * mp.nseq_tiles;
+        const int tps = mp.p[0].tiles_per_seq;
+        T.seq = m / tps;
+        T.t0 = (m - T.seq * tps) * TM;
+        return T;
+    };
 
-    f32x16 acc[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    constexpr int TN = WN * 32;
+    constexpr int OP = TN + 4;  // out-buffer row pitch (floats)
+    // This workgroup's tiles are w, w + G, w + 2G, ... (one per "round"); the walk starts at round (w mod rounds) and
+    // wraps, so that neighbouring CUs sit in different ResBlock branches / phases at any moment and their DMA
+    // bursts and output passes do not all hit the memory system at once.
+    const int my_rounds = (mp.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int rot = my_rounds > 0 ? (int)(blockIdx.x % (unsigned)my_rounds) : 0;
+    auto tile_of = [&](int it) {
+        int r = it + rot;
+        if (r >= my_rounds) r -= my_rounds;
+        return (int)blockIdx.x + r * (int)gridDim.x;
+    };
+    if (loader) {
+        // ---------------- loader role: LDS-DMA of split rows + the finished tile's output pass ----------------
+        const int lw = wave - 4;
+        const int ltid = tid - 256;
+        const float* O = reinterpret_cast<const float*>(smem_b + 2 * buf_bytes);
 
-    // B stream of this wave's 32-channel block: [chunk][tap][c16][hi|lo] fragments of 64 x 16 B
-    const bf16x8* wp = p.w16 + (size_t)(active ? nb : 0) * p.ntaps * (p.cin / 16) * 128 + lane;
-    bf16x8 bq[NC16][2];
-#pragma unroll
-    for (int u = 0; u < NC16; ++u) {
-        bq[u][0] = wp[u * 128];
-        bq[u][1] = wp[u * 128 + 64];
-    }
-    wp += NC16 * 128;
-    const int wave_row0 = wm * (MI * 32);
-    const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
-
-    for (int c0 = 0; c0 < p.cin; c0 += CH) {
-        __syncthreads();
-        // ---- stage split(act(X))[rows, c0 : c0+CH]; loads are issued UB at a time before any is consumed ----
-        constexpr int UB = 8;
-        const int n_units = R * C4N;
-        auto split_store = [&](int idx, const f32x4& v) {
-            const int r = idx / C4N;
-            const int c4 = idx - r * C4N;
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = lrelu(v[e], slope);
-                hi[e] = (__bf16)a;
-                lo[e] = (__bf16)(a - (float)hi[e]);
-            }
-            *reinterpret_cast<bf16x4*>(smem_b + r * PITCH + c4 * 8) = hi;
-            *reinterpret_cast<bf16x4*>(smem_b + r * PITCH + CH * 2 + c4 * 8) = lo;
-        };
-        if (p.nin == 1) {
-            for (int base = 0; base < n_units; base += 256 * UB) {
-                f32x4 v[UB];
+        // Output pass of a finished tile: the MFMA waves left the raw accumulators in the LDS out-buffer as
+        // O[time row][channel]; the 256 loader threads walk it row-major (a wave-instruction covers whole 512-byte
+        // row segments), add bias and residual, and write the fp32 rows and/or the activated split rows.
+        auto write_out = [&](const Tile& T) {
+            // A CU retires roughly one vector-store wave-instruction per ~70 cycles whatever its width, so every store
+            // here is 16 bytes per lane: a thread owns 8 adjacent channels of a row (2 x float4 in, 16 B hi + 16 B lo out).
+            const ConvParams& p = mp.p[T.b];
+            const int vc_base = T.ng * TN;                            // first virtual channel of the tile
+            const int width = min(TN, p.n_blocks32 * 32 - vc_base);  // a partial channel group is narrower (32 | width)
+            const int w8 = width >> 3;                                // 4, 8, 12 or 16 units per row
+            const int rpp = 256 / w8;                                 // rows per pass of the 256 loader threads
+            const int rr = ltid / w8;
+            const int c8 = (ltid - rr * w8) * 8;                      // this thread's channels: the same in every pass
+            const bool lane_on = rr < rpp;                            // w8 = 12 leaves a few threads idle
+            const size_t seq_base = (size_t)T.seq * p.L;
+            const float slope_out = p.slope_out;
+            const int rows = min(TM, p.L - T.t0);
+            const int vc = vc_base + c8;
+            const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + vc);
+            const f32x4 bv1 = *reinterpret_cast<const f32x4*>(p.bias + vc + 4);
+            // split rows: virtual channel -> (real row within the virtual row, channel); 8 | cout_real
+            const int ph_row = vc / p.cout_real;
+            const int split_off = ph_row * p.cout_real * 4 + (vc - ph_row * p.cout_real) * 2;
+            constexpr int UB = 4;  // rows in flight per thread: LDS reads and residual loads are issued before any is used
+            for (int r0 = 0; r0 < rows; r0 += rpp * UB) {
+                f32x4 v0[UB], v1[UB], q0[UB], q1[UB];
 #pragma unroll
                 for (int q = 0; q < UB; ++q) {
-                    const int idx = base + q * 256 + tid;
-                    const int r = idx / C4N;
-                    const int c4 = idx - r * C4N;
-                    const int t = t0 + p.off_min + r;
-                    v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (idx < n_units && t >= 0 && t < p.L)
-                        v[q] = *reinterpret_cast<const f32x4*>(p.x0 + (seq_base + t) * p.cin + c0 + c4 * 4);
-                }
-#pragma unroll
-                for (int q = 0; q < UB; ++q) {
-                    const int idx = base + q * 256 + tid;
-                    if (idx < n_units) split_store(idx, v[q]);
-                }
-            }
-        } else {  // MRF mean of the previous stage's ResBlock outputs (upsample convs only)
-            for (int idx = tid; idx < n_units; idx += 256) {
-                const int r = idx / C4N;
-                const int c4 = idx - r * C4N;
-                const int t = t0 + p.off_min + r;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (t >= 0 && t < p.L) {
-                    const size_t off = (seq_base + t) * p.cin + c0 + c4 * 4;
-                    v = *reinterpret_cast<const f32x4*>(p.x0 + off);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.x1 + off);
-                    if (p.nin == 3) {
-                        const f32x4 v2 = *reinterpret_cast<const f32x4*>(p.x2 + off);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ((v[e] + v1[e]) + v2[e]) / 3.0f;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (v[e] + v1[e]) / 2.0f;
+                    const int row_l = r0 + q * rpp + rr;
+                    v0[q] = v1[q] = q0[q] = q1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (lane_on && row_l < rows) {
+                        v0[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8]);
+                        v1[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8 + 4]);
+                        if (p.res) {
+                            const float* rp = p.res + (seq_base + T.t0 + row_l) * p.cout_total + vc;
+                            q0[q] = *reinterpret_cast<const f32x4*>(rp);
+                            q1[q] = *reinterpret_cast<const f32x4*>(rp + 4);
+                        }
                     }
                 }
-                split_store(idx, v);
-            }
-        }
-        __syncthreads();
-        if (!active) continue;
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int roff = roff0 + t * p.tap_step;
-            const char* arow = smem_b + (wave_row0 + li + roff) * PITCH + g * 16;
 #pragma unroll
-            for (int u = 0; u < NC16; ++u) {
-                const bf16x8 bh = bq[u][0];
-                const bf16x8 bl = bq[u][1];
-                bq[u][0] = wp[u * 128];       // same K slab of the next tap (or of the next chunk's first tap)
-                bq[u][1] = wp[u * 128 + 64];
+                for (int q = 0; q < UB; ++q) {
+                    const int row_l = r0 + q * rpp + rr;
+                    if (lane_on && row_l < rows) {
+                        const size_t row = seq_base + T.t0 + row_l;
+                        float o[8];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arow + mi * 32 * PITCH + u * 32);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(arow + mi * 32 * PITCH + CH * 2 + u * 32);
-                    // D^T = W * X^T: rows = channels, cols = time, so a lane ends up with 4 adjacent channels per register quad
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[mi], 0, 0, 0);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[mi], 0, 0, 0);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[mi], 0, 0, 0);
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = (v0[q][e] + bv0[e]) + q0[q][e];
+                            o[4 + e] = (v1[q][e] + bv1[e]) + q1[q][e];
+                        }
+                        if (p.y) {
+                            float* yp = p.y + row * p.cout_total + vc;
+                            *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+                            *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+                        }
+                        if (p.ys) {
+                            bf16x8 hi, lo;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float a = fmaxf(o[e], o[e] * slope_out);  // LeakyReLU, 0 <= slope <= 1
+                                hi[e] = (__bf16)a;
+                                lo[e] = (__bf16)(a - (float)hi[e]);
+                            }
+                            char* orow = p.ys + row * (size_t)p.cout_total * 4 + split_off;
+                            *reinterpret_cast<bf16x8*>(orow) = hi;
+                            *reinterpret_cast<bf16x8*>(orow + p.cout_real * 2) = lo;
+                        }
+                    }
                 }
             }
-            wp += NC16 * 128;
+        };
+        auto dma_item = [&](const Tile& T, int c, int jj) {
+            const ConvParams& p = mp.p[T.b];
+            const int R = TM + p.halo;
+            const int ninstr = (R * SPR + 63) >> 6;  // 1 KiB of LDS per wave-instruction
+            const size_t seq_base = (size_t)T.seq * p.L;
+            const int row_bytes = p.cin * 4;
+            char* dst = smem_b + (jj & 1) * buf_bytes;
+            const int c0b = c * CH * 2;  // byte offset of this chunk inside the hi (and lo) half of a row
+            for (int i = lw; i < ninstr; i += 4) {
+                const int n = i * 64 + lane;
+                const int r = n >> LOG_SPR;
+                const int sl = (n & (SPR - 1)) ^ ((r >> LOG_RPB) & (SPR - 1));  // logical slot stored at this position
+                const int t = T.t0 + p.off_min + r;
+                const char* src = p.zeros;
+                if (r < R && t >= 0 && t < p.L)
+                    src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            }
+        };
+        // items are numbered j = 0.. over (tile, chunk); the DMA of item j+1 runs while the MFMA waves compute item j
+        int j = 0;
+        HIFICAR_STAMP(0);
+        bool have_prev = false;
+        Tile Tprev;
+        for (int it = 0; it < my_rounds; ++it) {
+            const Tile T = decode(tile_of(it));
+            for (int c = 0; c < nchunks; ++c, ++j) {
+                dma_item(T, c, j);
+                // the tile that finished with item j-2 published its accumulators at barrier j-1 (nchunks >= 2, so the
+                // MFMA waves cannot overwrite the out-buffer before barrier j+1)
+                if (c == 1 && have_prev) write_out(Tprev);
+                HIFICAR_STAMP(1 + 2 * j);
+                __syncthreads();  // item j landed (hipcc drains vmcnt before the barrier); MFMA waves are done with item j-1's buffer
+                HIFICAR_STAMP(2 + 2 * j);
+            }
+            Tprev = T;
+            have_prev = true;
+        }
+        __syncthreads();  // the last tile's accumulators are in the out-buffer
+        if (have_prev) write_out(Tprev);
+        return;
+    }
+
+    // ---------------- MFMA role ----------------
+    f32x16 acc[MI];
+    bf16x8 bq[NC16][2];
+    auto wstream = [&](const Tile& T) {
+        const ConvParams& p = mp.p[T.b];
+        const int nb = T.ng * WN + wn;
+        return p.w16 + (size_t)(nb < p.n_blocks32 ? nb : 0) * p.ntaps * (p.cin / 16) * 128 + lane;
+    };
+    const bf16x8* wp = nullptr;
+    if (my_rounds > 0) {
+        wp = wstream(decode(tile_of(0)));
+#pragma unroll
+        for (int u = 0; u < NC16; ++u) {
+            bq[u][0] = wp[u * 128];
+            bq[u][1] = wp[u * 128 + 64];
+        }
+        wp += NC16 * 128;
+    }
+    const int wave_row0 = wm * (MI * 32);
+
+    // LDS byte addresses of this lane's activation fragments for one tap: [K slab][hi|lo]
+    auto addr_set = [&](int buf_off, int roff, int (&ad)[NC16][2]) {
+        const int r0 = wave_row0 + li + roff;
+        const int swz = (r0 >> LOG_RPB) & (SPR - 1);
+        const int base = buf_off + r0 * RB;
+#pragma unroll
+        for (int u = 0; u < NC16; ++u) {
+            ad[u][0] = base + (((2 * u + g) ^ swz) << 4);
+            ad[u][1] = base + (((SPR / 2 + 2 * u + g) ^ swz) << 4);
+        }
+    };
+    auto load_x = [&](bf16x8 (&xh)[MI], bf16x8 (&xl)[MI], const int (&ad)[2]) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {  // +32 rows keeps the swizzle (32 % 16 == 0): immediate offsets
+            xh[mi] = *reinterpret_cast<const bf16x8*>(smem_b + ad[0] + mi * 32 * RB);
+            xl[mi] = *reinterpret_cast<const bf16x8*>(smem_b + ad[1] + mi * 32 * RB);
+        }
+    };
+    auto mfma_step = [&](const bf16x8 (&xh)[MI], const bf16x8 (&xl)[MI], const bf16x8& wh, const bf16x8& wl) {
+        // term-major order: consecutive MFMAs never share an accumulator
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[mi], acc[mi], 0, 0, 0);
+    };
+
+    int j = 0;
+    HIFICAR_STAMP(0);
+    for (int it = 0; it < my_rounds; ++it) {
+        const Tile T = decode(tile_of(it));
+        const ConvParams& p = mp.p[T.b];
+        const int nb = T.ng * WN + wn;
+        const bool active = nb < p.n_blocks32;
+        const int phase = active ? nb / p.nb32_per_phase : 0;
+        const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
+        const int tap_step = p.tap_step;
+        const int ntaps = p.ntaps;
+        const bf16x8* wp_next = it + 1 < my_rounds ? wstream(decode(tile_of(it + 1))) : wp;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+        for (int c = 0; c < nchunks; ++c, ++j) {
+            HIFICAR_STAMP(1 + 3 * j);
+            __syncthreads();  // item j is staged
+            HIFICAR_STAMP(2 + 3 * j);
+            if (!active) continue;  // partial channel group: this wave only keeps the barriers
+            const bool last_chunk = c + 1 == nchunks;
+            const int buf_off = (j & 1) * buf_bytes;
+            int ad[NC16][2];
+            addr_set(buf_off, roff0, ad);
+            if constexpr (NC16 % 2 == 0) {
+                bf16x8 x0h[MI], x0l[MI], x1h[MI], x1l[MI];
+                load_x(x0h, x0l, ad[0]);
+                for (int t = 0; t < ntaps; ++t) {
+                    const bool last_tap = t + 1 == ntaps;
+                    int adn[NC16][2];
+                    addr_set(buf_off, roff0 + (last_tap ? t : t + 1) * tap_step, adn);
+                    if (last_tap && last_chunk) wp = wp_next;  // prime the ring with the next tile's first K slabs
+#pragma unroll
+                    for (int u = 0; u < NC16; u += 2) {
+                        load_x(x1h, x1l, ad[u + 1]);
+                        {
+                            const bf16x8 wh = bq[u][0], wl = bq[u][1];
+                            bq[u][0] = wp[u * 128];
+                            bq[u][1] = wp[u * 128 + 64];
+                            mfma_step(x0h, x0l, wh, wl);
+                        }
+                        if (u + 2 < NC16) load_x(x0h, x0l, ad[u + 2]);
+                        else load_x(x0h, x0l, adn[0]);
+                        {
+                            const bf16x8 wh = bq[u + 1][0], wl = bq[u + 1][1];
+                            bq[u + 1][0] = wp[(u + 1) * 128];
+                            bq[u + 1][1] = wp[(u + 1) * 128 + 64];
+                            mfma_step(x1h, x1l, wh, wl);
+                        }
+                    }
+                    wp += NC16 * 128;
+#pragma unroll
+                    for (int u = 0; u < NC16; ++u) {
+                        ad[u][0] = adn[u][0];
+                        ad[u][1] = adn[u][1];
+                    }
+                }
+            } else {
+                for (int t = 0; t < ntaps; ++t) {
+                    if (t + 1 == ntaps && last_chunk) wp = wp_next;
+                    addr_set(buf_off, roff0 + t * tap_step, ad);
+#pragma unroll
+                    for (int u = 0; u < NC16; ++u) {
+                        bf16x8 xh[MI], xl[MI];
+                        load_x(xh, xl, ad[u]);
+                        const bf16x8 wh = bq[u][0], wl = bq[u][1];
+                        bq[u][0] = wp[u * 128];
+                        bq[u][1] = wp[u * 128 + 64];
+                        mfma_step(xh, xl, wh, wl);
+                    }
+                    wp += NC16 * 128;
+                }
+            }
+        }
+        HIFICAR_STAMP(3 * j);
+        if (active) {
+            // hand the raw accumulators to the loader waves through the LDS out-buffer O[time row][channel]:
+            // lane (li, g) holds time column li and channels 8q + 4g + {0..3} in acc[mi][4q..4q+3]
+            float* O = reinterpret_cast<float*>(smem_b + 2 * buf_bytes);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][4 * q + e];
+                    *reinterpret_cast<f32x4*>(&O[(wave_row0 + mi * 32 + li) * OP + wn * 32 + 8 * q + 4 * g]) = v;
+                }
         }
     }
-    if (!active) return;
+    __syncthreads();  // matches the loader waves' final barrier
+}
 
-    // epilogue: lane holds time column t = li and channels co = 8q + 4g + {0..3} in acc[mi][4q .. 4q+3]
-    f32x4 bias4[4];
+// MRF mean + LeakyReLU + split for the upsample convs' input: out = split(lrelu(((x0 + x1) + x2) / n, slope)).
+// Elementwise, HBM-bound; one thread = 8 channels (2 x 16 B in per input, 16 B hi + 16 B lo out).
+struct MrfSplitParams {
+    const float* x0;
+    const float* x1;
+    const float* x2;
+    char* out;
+    int nin;
+    int C;
+    long long rows;
+    float slope;
+};
+
+__global__ __launch_bounds__(256) void mrf_split_kernel(const MrfSplitParams p) {
+    const int c8n = p.C >> 3;
+    const long long total = p.rows * c8n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long row = idx / c8n;
+        const int c8 = (int)(idx - row * c8n);
+        const size_t off = (size_t)row * p.C + c8 * 8;
+        float v[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bias4[q] = *reinterpret_cast<const f32x4*>(p.bias + nb * 32 + 8 * q + 4 * g);
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(p.x0 + off + 4 * h);
+            if (p.nin >= 2) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.x1 + off + 4 * h);
+                if (p.nin == 3) {
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.x2 + off + 4 * h);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int t = t0 + wave_row0 + mi * 32 + li;
-        if (t < p.L) {
-            const size_t off = (seq_base + t) * p.cout_total + nb * 32 + 4 * g;
+                    for (int e = 0; e < 4; ++e) a[e] = ((a[e] + b[e]) + c[e]) / 3.0f;
+                } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mi][4 * q + e] + bias4[q][e];
-                if (p.res) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + off + 8 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    for (int e = 0; e < 4; ++e) a[e] = (a[e] + b[e]) / 2.0f;
                 }
-                *reinterpret_cast<f32x4*>(p.y + off + 8 * q) = v;
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * h + e] = a[e];
         }
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = fmaxf(v[e], v[e] * p.slope);
+            hi[e] = (__bf16)a;
+            lo[e] = (__bf16)(a - (float)hi[e]);
+        }
+        char* orow = p.out + (size_t)row * p.C * 4;
+        *reinterpret_cast<bf16x8*>(orow + c8 * 16) = hi;
+        *reinterpret_cast<bf16x8*>(orow + p.C * 2 + c8 * 16) = lo;
     }
 }
 
@@ -410,7 +658,8 @@ struct FrontParams {
     int64_t c_cstride;
     const float* prev;    // AR context; element (b, i) at prev[b*prev_bstride + i]; null => zeros
     int64_t prev_bstride;
-    float* xin;           // (B, T, cin_pad)
+    float* xin;           // (B, T, cin_pad) fp32 rows, or null
+    char* xin_s;          // (B, T, [hi cin_pad | lo cin_pad]) split rows (no activation: the input conv has none), or null
     int T;
     int cf;               // feature channels
     int cin_pad;
@@ -472,14 +721,19 @@ __global__ __launch_bounds__(256) void front_kernel(const FrontParams p) {
     // act[cur][0:ar_output] now holds the AR features
     const float* feats = act[cur];
     const int n = p.T * p.cin_pad;
-    float* xo = p.xin + (size_t)b * n;
     for (int idx = tid; idx < n; idx += 256) {
         const int t = idx / p.cin_pad;
         const int ch = idx - t * p.cin_pad;
         float v = 0.f;
         if (ch < p.cf) v = p.c[(size_t)b * p.c_bstride + (size_t)ch * p.c_cstride + t];
         else if (p.use_ar && ch < p.cf + p.ar_output) v = feats[ch - p.cf];
-        xo[idx] = v;
+        if (p.xin) p.xin[(size_t)b * n + idx] = v;
+        if (p.xin_s) {
+            __bf16* row = reinterpret_cast<__bf16*>(p.xin_s + ((size_t)b * p.T + t) * p.cin_pad * 4);
+            const __bf16 hi = (__bf16)v;
+            row[ch] = hi;
+            row[p.cin_pad + ch] = (__bf16)(v - (float)hi);
+        }
     }
 }
 

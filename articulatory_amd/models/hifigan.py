@@ -351,11 +351,11 @@ class HiFiGANGenerator(torch.nn.Module):
 
     def profile_end(self):
         """Stop profiling; returns [{name, launches, total_ms, flops, bytes}], slowest kernel first."""
-        stats = (_native.HificarKernelStat * 32)()
+        stats = (_native.HificarKernelStat * 96)()
         n = ctypes.c_int(0)
-        _native.check(self._lib.hificar_profile_end(self._handle, stats, 32, ctypes.byref(n)), "hificar_profile_end")
+        _native.check(self._lib.hificar_profile_end(self._handle, stats, 96, ctypes.byref(n)), "hificar_profile_end")
         return [dict(name=stats[i].name.decode(), launches=int(stats[i].launches), total_ms=float(stats[i].total_ms),
-                     flops=float(stats[i].flops), bytes=float(stats[i].bytes)) for i in range(min(n.value, 32))]
+                     flops=float(stats[i].flops), bytes=float(stats[i].bytes)) for i in range(min(n.value, 96))]
 
     # ------------------------------------------------------------------ forward paths
     def _check_input(self, c):

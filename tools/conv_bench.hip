@@ -1,0 +1,102 @@
+// Developer tool: launches the real bf16x3 wave-specialised conv kernel on a stage-shaped problem, times it and
+// dumps one workgroup's timeline (s_memtime stamps).  Not part of the product.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHIFICAR_TRACE tools/conv_bench.hip -o tools/conv_bench.bin
+#include "../articulatory_amd/csrc/hificar_kernels.hip.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+using namespace hificar;
+
+template <int MI, int WM, int WN, int NC16>
+void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int dil, bool residual, int mode = 0) {
+    constexpr int TM = WM * MI * 32;
+    const int CH = NC16 * 16;
+    float *x, *y[3], *bias;
+    char *xs, *ys[3], *zeros;
+    const size_t n = (size_t)nseq * L * C;
+    hipMalloc(&x, n * 4);
+    hipMalloc(&xs, n * 4);
+    hipMemset(xs, 0x3c, n * 4);
+    hipMalloc(&zeros, 256);
+    hipMemset(zeros, 0, 256);
+    hipMalloc(&bias, C * 4);
+    hipMemset(bias, 0, C * 4);
+    std::vector<float> hx(n);
+    for (size_t i = 0; i < n; ++i) hx[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+    hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice);
+    MultiConvParams mp;
+    memset(&mp, 0, sizeof(mp));
+    int max_halo = 0;
+    double flops = 0;
+    for (int b = 0; b < nbr; ++b) {
+        hipMalloc(&y[b], n * 4);
+        hipMemset(y[b], 0, n * 4);
+        hipMalloc(&ys[b], n * 4);
+        const int K = ks[b], pad = (K - 1) / 2 * dil;
+        const size_t wel = ((size_t)(C / 32) * (C / 16) * K * 2 + 2 * NC16) * 512;
+        uint16_t* w16;
+        hipMalloc(&w16, wel * 2);
+        std::vector<uint16_t> hw(wel);
+        for (size_t i = 0; i < wel; ++i) hw[i] = 0x3c00 + (uint16_t)((i * 40503u) & 0xff);  // small bf16 values
+        hipMemcpy(w16, hw.data(), wel * 2, hipMemcpyHostToDevice);
+        ConvParams& p = mp.p[b];
+        p.x0 = x; p.w16 = reinterpret_cast<const bf16x8*>(w16); p.bias = bias; p.res = residual ? x : nullptr; p.y = residual ? y[b] : nullptr;
+        p.xs = xs; p.ys = (mode & 1) ? nullptr : ys[b]; if (mode & 2) p.y = y[b]; p.zeros = zeros; p.slope_out = 0.1f; p.cout_real = C;
+        p.L = L; p.tiles_per_seq = (L + TM - 1) / TM; p.cin = C; p.cout_total = C; p.chunk = 64;
+        p.n_blocks32 = C / 32; p.nb32_per_phase = C / 32; p.ntaps = K; p.off_min = -pad; p.halo = 2 * pad; p.nin = 1; p.slope = 0.1f;
+        p.tap_step = dil; p.tap_off0[0] = -pad;
+        max_halo = std::max(max_halo, p.halo);
+        flops += 2.0 * nseq * L * (double)C * C * K;
+    }
+    mp.n_branches = nbr;
+    mp.nseq_tiles = nseq * ((L + TM - 1) / TM);
+    mp.ngroups = (C / 32 + WN - 1) / WN;
+    mp.total_tiles = nbr * mp.ngroups * mp.nseq_tiles;
+    mp.buf_bytes = ((TM + max_halo) * (CH * 4) + 1023) / 1024 * 1024;
+    const int G = std::min(mp.total_tiles, 256);
+    unsigned long long* trace;
+    hipMalloc(&trace, (size_t)G * 2 * 64 * 8);
+    hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
+    mp.trace = trace;
+    auto kern = conv_bf16x3_kernel<MI, WM, WN, NC16>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int it = 0; it < 3; ++it) {
+        hipEventRecord(e0);
+        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3(512), 2 * mp.buf_bytes + TM * (WN * 32 + 4) * 4, 0, mp);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("%-28s tiles=%d G=%d lds=%dKB  %.1f us/launch  %.0f TF-alg\n", label, mp.total_tiles, G, 2 * mp.buf_bytes / 1024, ms * 100, flops / (ms * 1e-4) / 1e12);
+    std::vector<unsigned long long> ht((size_t)G * 2 * 64);
+    hipMemcpy(ht.data(), trace, ht.size() * 8, hipMemcpyDeviceToHost);
+    for (int wg : {0, G / 2}) {
+        const unsigned long long* m = &ht[(size_t)wg * 2 * 64];
+        const unsigned long long* l = m + 64;
+        const unsigned long long t0 = std::min(m[0], l[0]);
+        printf("  WG %d MFMA : ", wg);
+        for (int i = 0; i < 40; ++i) printf("%lld ", m[i] ? (long long)(m[i] - t0) / 100 : -1LL);
+        printf("\n  WG %d load : ", wg);
+        for (int i = 0; i < 30; ++i) printf("%lld ", l[i] ? (long long)(l[i] - t0) / 100 : -1LL);
+        printf("  (x100 clk)\n");
+    }
+}
+
+int main() {
+    const int k3[3] = {11, 7, 3};
+    run<4, 1, 4, 4>("stage1 C128 L500 conv1 d1", 64, 500, 128, 3, k3, 1, false);
+    run<4, 1, 4, 4>("stage1 C128 L500 conv2+res", 64, 500, 128, 3, k3, 1, true);
+    run<4, 1, 4, 4>("stage1 C128 L500 conv1 d5", 64, 500, 128, 3, k3, 5, false);
+    run<4, 1, 4, 4>("stage0 C256 L125 conv1 d1", 64, 125, 256, 3, k3, 1, false);
+    run<2, 2, 2, 4>("stage0 C256 L125 TN64", 64, 125, 256, 3, k3, 1, false);
+    run<4, 1, 4, 4>("stage1 conv1 NO outputs", 64, 500, 128, 3, k3, 1, false, 1);
+    run<4, 1, 4, 4>("stage1 conv1 y only", 64, 500, 128, 3, k3, 1, false, 3);
+    run<4, 1, 4, 4>("stage1 conv1 y + ys", 64, 500, 128, 3, k3, 1, false, 2);
+    const int k11[1] = {11};
+    run<4, 1, 4, 4>("stage1 only k11", 64, 500, 128, 1, k11, 1, false);
+    return 0;
+}
