@@ -450,22 +450,28 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 
     // ---------------- MFMA role ----------------
     f32x16 acc[MI];
-    bf16x8 bq[NC16][2];
+    // weight fragments: bq = current tap, bn = next tap; loads run two taps ahead of their use
+    bf16x8 bq[NC16][2], bn[NC16][2];
     auto wstream = [&](const Tile& T) {
         const ConvParams& p = mp.p[T.b];
         const int nb = T.ng * WN + wn;
         return p.w16 + (size_t)(nb < p.n_blocks32 ? nb : 0) * p.ntaps * (p.cin / 16) * 128 + lane;
     };
-    const bf16x8* wp = nullptr;
-    if (my_rounds > 0) {
-        wp = wstream(decode(tile_of(0)));
+    const bf16x8* wp = nullptr;   // where the next tap-group of weight fragments is loaded from
+    int groups_left = 0;          // tap-groups of the current tile's stream not yet requested
+    bool primed = false;          // the ring holds the head of the tile about to be computed
+    auto prime = [&](const Tile& T) {
+        wp = wstream(T);
 #pragma unroll
         for (int u = 0; u < NC16; ++u) {
             bq[u][0] = wp[u * 128];
             bq[u][1] = wp[u * 128 + 64];
+            bn[u][0] = wp[(NC16 + u) * 128];   // a tile always has >= 2 tap-groups (>= 2 chunks)
+            bn[u][1] = wp[(NC16 + u) * 128 + 64];
         }
-        wp += NC16 * 128;
-    }
+        wp += 2 * NC16 * 128;
+        groups_left = nchunks * mp.p[T.b].ntaps - 2;
+    };
     const int wave_row0 = wm * (MI * 32);
 
     // LDS byte addresses of this lane's activation fragments for one tap: [K slab][hi|lo]
@@ -507,7 +513,12 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
         const int tap_step = p.tap_step;
         const int ntaps = p.ntaps;
-        const bf16x8* wp_next = it + 1 < my_rounds ? wstream(decode(tile_of(it + 1))) : wp;
+        // after this tile's stream is exhausted the loads continue with the NEXT tile's first tap-groups, so its ring is
+        // primed when it starts (the last tile re-reads its own head: harmless)
+        const Tile Tn = decode(tile_of(it + 1 < my_rounds ? it + 1 : it));
+        const bf16x8* wp_next = wstream(Tn);
+        const int groups_next = nchunks * mp.p[Tn.b].ntaps;
+        if (active && !primed) prime(T);  // first tile, or this wave sat out the previous tile (partial channel group)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -518,7 +529,6 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             __syncthreads();  // item j is staged
             HIFICAR_STAMP(2 + 3 * j);
             if (!active) continue;  // partial channel group: this wave only keeps the barriers
-            const bool last_chunk = c + 1 == nchunks;
             const int buf_off = (j & 1) * buf_bytes;
             int ad[NC16][2];
             addr_set(buf_off, roff0, ad);
@@ -529,22 +539,30 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     const bool last_tap = t + 1 == ntaps;
                     int adn[NC16][2];
                     addr_set(buf_off, roff0 + (last_tap ? t : t + 1) * tap_step, adn);
-                    if (last_tap && last_chunk) wp = wp_next;  // prime the ring with the next tile's first K slabs
+                    if (groups_left == 0) {  // stream exhausted: continue with the next tile's head
+                        wp = wp_next;
+                        groups_left = groups_next;
+                    }
+                    --groups_left;
 #pragma unroll
                     for (int u = 0; u < NC16; u += 2) {
                         load_x(x1h, x1l, ad[u + 1]);
                         {
                             const bf16x8 wh = bq[u][0], wl = bq[u][1];
-                            bq[u][0] = wp[u * 128];
-                            bq[u][1] = wp[u * 128 + 64];
+                            bq[u][0] = bn[u][0];
+                            bq[u][1] = bn[u][1];
+                            bn[u][0] = wp[u * 128];
+                            bn[u][1] = wp[u * 128 + 64];
                             mfma_step(x0h, x0l, wh, wl);
                         }
                         if (u + 2 < NC16) load_x(x0h, x0l, ad[u + 2]);
                         else load_x(x0h, x0l, adn[0]);
                         {
                             const bf16x8 wh = bq[u + 1][0], wl = bq[u + 1][1];
-                            bq[u + 1][0] = wp[(u + 1) * 128];
-                            bq[u + 1][1] = wp[(u + 1) * 128 + 64];
+                            bq[u + 1][0] = bn[u + 1][0];
+                            bq[u + 1][1] = bn[u + 1][1];
+                            bn[u + 1][0] = wp[(u + 1) * 128];
+                            bn[u + 1][1] = wp[(u + 1) * 128 + 64];
                             mfma_step(x1h, x1l, wh, wl);
                         }
                     }
@@ -557,15 +575,21 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 }
             } else {
                 for (int t = 0; t < ntaps; ++t) {
-                    if (t + 1 == ntaps && last_chunk) wp = wp_next;
+                    if (groups_left == 0) {
+                        wp = wp_next;
+                        groups_left = groups_next;
+                    }
+                    --groups_left;
                     addr_set(buf_off, roff0 + t * tap_step, ad);
 #pragma unroll
                     for (int u = 0; u < NC16; ++u) {
                         bf16x8 xh[MI], xl[MI];
                         load_x(xh, xl, ad[u]);
                         const bf16x8 wh = bq[u][0], wl = bq[u][1];
-                        bq[u][0] = wp[u * 128];
-                        bq[u][1] = wp[u * 128 + 64];
+                        bq[u][0] = bn[u][0];
+                        bq[u][1] = bn[u][1];
+                        bn[u][0] = wp[u * 128];
+                        bn[u][1] = wp[u * 128 + 64];
                         mfma_step(xh, xl, wh, wl);
                     }
                     wp += NC16 * 128;
@@ -573,6 +597,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             }
         }
         HIFICAR_STAMP(3 * j);
+        primed = active;  // an active tile ends with the ring holding the next tile's head
         if (active) {
             // hand the raw accumulators to the loader waves through the LDS out-buffer O[time row][channel]:
             // lane (li, g) holds time column li and channels 8q + 4g + {0..3} in acc[mi][4q..4q+3]

@@ -7,7 +7,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // V bit0: read A from LDS each step; bit1: stream B from global; bit2: barrier per "chunk"
-template <int V, int MI, int NJ>
+template <int V, int MI, int NJ, int ORD = 0>
 __global__ __launch_bounds__(256) void probe(const bf16x8* __restrict__ w, float* out, int ntaps, int nchunks) {
     constexpr int NC16 = 4, CH = 64, PITCH = CH * 4 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void probe(const bf16x8* __restrict__ w, float
                         al[mi] = *reinterpret_cast<const bf16x8*>(arow + mi * 32 * PITCH + CH * 2 + u * 32);
                     }
                 }
+                if (ORD == 0) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -44,6 +45,17 @@ __global__ __launch_bounds__(256) void probe(const bf16x8* __restrict__ w, float
                     for (int mi = 0; mi < MI; ++mi) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[mi], acc[mi][j], 0, 0, 0);
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[mi], acc[mi][j], 0, 0, 0);
+                }
+                } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[mi], acc[mi][j], 0, 0, 0);
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[mi], acc[mi][j], 0, 0, 0);
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[mi], acc[mi][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (V & 2) wp += NC16 * NJ * 128;
@@ -56,14 +68,14 @@ __global__ __launch_bounds__(256) void probe(const bf16x8* __restrict__ w, float
     out[blockIdx.x * 256 + tid] = s;
 }
 
-template <int V, int MI, int NJ>
+template <int V, int MI, int NJ, int ORD = 0>
 void run(const char* name, const bf16x8* w, float* out, int grid, int lds_kb) {
     const int ntaps = 11, nchunks = 16;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<V, MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<V, MI, NJ, ORD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 2; ++it) {
         hipEventRecord(e0);
-        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((probe<V, MI, NJ>), dim3(grid), dim3(256), lds_kb * 1024, 0, w, out, ntaps, nchunks);
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((probe<V, MI, NJ, ORD>), dim3(grid), dim3(256), lds_kb * 1024, 0, w, out, ntaps, nchunks);
         hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -74,6 +86,12 @@ void run(const char* name, const bf16x8* w, float* out, int grid, int lds_kb) {
 int main() {
     bf16x8* w; float* out;
     hipMalloc(&w, 64 << 20); hipMemset(w, 0x11, 64 << 20); hipMalloc(&out, 4096 * 256 * 4);
+    run<0, 4, 1>("mfma only term-major", w, out, 256, 96);
+    run<0, 4, 1, 1>("mfma only chained", w, out, 256, 96);
+    run<3, 4, 1>("A+B term-major 1WG/CU", w, out, 256, 96);
+    run<3, 4, 1, 1>("A+B chained 1WG/CU", w, out, 256, 96);
+    run<0, 4, 2>("mfma only term-major", w, out, 256, 96);
+    run<0, 4, 2, 1>("mfma only chained", w, out, 256, 96);
     run<0, 4, 1>("mfma only", w, out, 512, 48);
     run<1, 4, 1>("+ A from LDS", w, out, 512, 48);
     run<2, 4, 1>("+ B from global", w, out, 512, 48);
