@@ -316,14 +316,15 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 
     constexpr int TN = WN * 32;
     constexpr int OP = TN + 4;  // out-buffer row pitch (floats)
-    // This workgroup's tiles are w, w + G, w + 2G, ... (one per "round"); the walk starts at round (w mod rounds) and
-    // wraps, so that neighbouring CUs sit in different ResBlock branches / phases at any moment and their DMA
-    // bursts and output passes do not all hit the memory system at once.
+    // This workgroup's tiles are w, w + G, w + 2G, ... (one per "round"; rounds run heavy -> light because tile ids
+    // are heaviest-branch-major).  They are walked LIGHT FIRST: the loader waves write a finished tile out while the
+    // MFMA waves compute the next one, and that only hides completely behind a tile at least as heavy.  Odd
+    // workgroups swap their last two rounds so that neighbouring CUs are not in the same phase all the time
+    // (synchronised DMA / output bursts cost ~15 % on this kernel).
     const int my_rounds = (mp.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int rot = my_rounds > 0 ? (int)(blockIdx.x % (unsigned)my_rounds) : 0;
     auto tile_of = [&](int it) {
-        int r = it + rot;
-        if (r >= my_rounds) r -= my_rounds;
+        int r = my_rounds - 1 - it;
+        if ((blockIdx.x & 1) && my_rounds >= 3 && it >= my_rounds - 2) r = it == my_rounds - 1 ? 1 : 0;
         return (int)blockIdx.x + r * (int)gridDim.x;
     };
     if (loader) {

@@ -88,15 +88,15 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
 
 int main() {
     const int k3[3] = {11, 7, 3};
-    run<4, 1, 4, 4>("stage1 C128 L500 conv1 d1", 64, 500, 128, 3, k3, 1, false);
-    run<4, 1, 4, 4>("stage1 C128 L500 conv2+res", 64, 500, 128, 3, k3, 1, true);
-    run<4, 1, 4, 4>("stage1 C128 L500 conv1 d5", 64, 500, 128, 3, k3, 5, false);
-    run<4, 1, 4, 4>("stage0 C256 L125 conv1 d1", 64, 125, 256, 3, k3, 1, false);
-    run<2, 2, 2, 4>("stage0 C256 L125 TN64", 64, 125, 256, 3, k3, 1, false);
-    run<4, 1, 4, 4>("stage1 conv1 NO outputs", 64, 500, 128, 3, k3, 1, false, 1);
-    run<4, 1, 4, 4>("stage1 conv1 y only", 64, 500, 128, 3, k3, 1, false, 3);
-    run<4, 1, 4, 4>("stage1 conv1 y + ys", 64, 500, 128, 3, k3, 1, false, 2);
-    const int k11[1] = {11};
-    run<4, 1, 4, 4>("stage1 only k11", 64, 500, 128, 1, k11, 1, false);
+    run<4, 1, 4, 4>("stage0 TM128 TN128 (4,1,4)", 64, 125, 256, 3, k3, 1, false);
+    run<2, 1, 4, 4>("stage0 TM64 TN128 (2,1,4)", 64, 125, 256, 3, k3, 1, false);
+    run<2, 2, 2, 4>("stage0 TM128 TN64 (2,2,2)", 64, 125, 256, 3, k3, 1, false);
+    run<2, 2, 2, 4>("stage0 (2,2,2) conv2+res", 64, 125, 256, 3, k3, 1, true);
+    run<4, 1, 4, 4>("stage1 (4,1,4) conv1", 64, 500, 128, 3, k3, 1, false);
+    run<4, 1, 4, 4>("stage1 (4,1,4) conv2+res", 64, 500, 128, 3, k3, 1, true);
+    run<4, 2, 2, 2>("stage2 C64 L1000 (4,2,2) conv1", 64, 1000, 64, 3, k3, 1, false);
+    run<4, 2, 2, 2>("stage2 C64 (4,2,2) conv2+res", 64, 1000, 64, 3, k3, 1, true);
+    run<4, 4, 1, 1>("stage3 C32 L2000 (4,4,1) conv1", 64, 2000, 32, 3, k3, 1, false);
+    run<4, 4, 1, 1>("stage3 C32 (4,4,1) conv2+res", 64, 2000, 32, 3, k3, 1, true);
     return 0;
 }
