@@ -63,6 +63,7 @@ struct ConvLayer {
     // bf16x3 path
     int chunk16 = 0, n_blocks32 = 0, nb32_per_phase = 0;
     uint16_t* d_w16 = nullptr;
+    uint16_t* d_w16c = nullptr;  // same fragments packed with one K chunk = all channels (fused pair kernel, C <= 64)
 };
 
 struct hificar_handle {
@@ -70,6 +71,7 @@ struct hificar_handle {
     bool finalized = false;
     int precision = HIFICAR_PREC_F32;
     bool profile_detail = false;   // HIFICAR_PROFILE_DETAIL=1: profile rows carry the layer name
+    bool use_pair = true;          // HIFICAR_PAIR=0: run narrow stages layer by layer (A/B runs)
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
     int cin_pad = 0;  // padded input-conv channels
     int hop = 1;
@@ -221,6 +223,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     hificar_handle* h = new hificar_handle();
     h->cfg = c;
     if (const char* e = getenv("HIFICAR_PROFILE_DETAIL")) h->profile_detail = atoi(e) != 0;
+    if (const char* e = getenv("HIFICAR_PAIR")) h->use_pair = atoi(e) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -378,6 +381,44 @@ static inline float bf16_to_f32(uint16_t b) {
     return f;
 }
 
+// bf16x3 path: weight fragments in MFMA lane order, [n_block32][chunk][tap][c16][hi|lo][lane][8]
+static int pack_w16(hificar_handle* h, const ConvLayer& L, const HostTensor& W, int chunk, uint16_t** out) {
+    const int nc16 = chunk / 16, nchunk = L.cin_pad / chunk;
+    const size_t frag = 64 * 8;  // bf16 elements per fragment
+    std::vector<uint16_t> w16(((size_t)L.n_blocks32 * nchunk * L.ntaps * nc16 * 2 + 4 * nc16) * frag, 0);
+    for (int nb = 0; nb < L.n_blocks32; ++nb) {
+        const int phase = nb / L.nb32_per_phase;
+        const int co0 = (nb % L.nb32_per_phase) * 32;
+        for (int c = 0; c < nchunk; ++c)
+            for (int t = 0; t < L.ntaps; ++t) {
+                const int k = L.tap_k[phase][t];
+                if (k < 0) continue;
+                for (int u = 0; u < nc16; ++u) {
+                    uint16_t* hi = &w16[(((((size_t)nb * nchunk + c) * L.ntaps + t) * nc16 + u) * 2) * frag];
+                    uint16_t* lo = hi + frag;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int g = lane >> 5, n = lane & 31, co = co0 + n;
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = c * chunk + u * 16 + 8 * g + j;
+                            if (ci >= L.cin) continue;
+                            const size_t src = L.transposed ? ((size_t)ci * L.cout + co) * L.K + k : ((size_t)co * L.cin + ci) * L.K + k;
+                            const float v = W.data[src];
+                            const uint16_t vh = f32_to_bf16(v);
+                            hi[lane * 8 + j] = vh;
+                            lo[lane * 8 + j] = f32_to_bf16(v - bf16_to_f32(vh));
+                        }
+                    }
+                }
+            }
+    }
+    void* dp = nullptr;
+    HIP_TRY(hipMalloc(&dp, w16.size() * sizeof(uint16_t)));
+    h->allocs.push_back(dp);
+    HIP_TRY(hipMemcpy(dp, w16.data(), w16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    *out = static_cast<uint16_t*>(dp);
+    return HIFICAR_OK;
+}
+
 static int pack_conv(hificar_handle* h, ConvLayer& L) {
     const HostTensor& W = h->tensors.at(L.name + ".weight");
     std::vector<float> wp((size_t)L.n_blocks * L.ntaps * L.cin_pad * L.NB, 0.f);
@@ -408,40 +449,9 @@ static int pack_conv(hificar_handle* h, ConvLayer& L) {
     if (rc != HIFICAR_OK) return rc;
     if ((rc = upload(h, bias, &L.d_bias)) != HIFICAR_OK) return rc;
 
-    // bf16x3 path: B fragments in MFMA lane order, [n_block32][chunk][tap][c16][hi|lo][lane][8]
-    const int nc16 = L.chunk16 / 16, nchunk = L.cin_pad / L.chunk16;
-    const size_t frag = 64 * 8;  // bf16 elements per fragment
-    std::vector<uint16_t> w16(((size_t)L.n_blocks32 * nchunk * L.ntaps * nc16 * 2 + 2 * nc16) * frag, 0);
-    for (int nb = 0; nb < L.n_blocks32; ++nb) {
-        const int phase = nb / L.nb32_per_phase;
-        const int co0 = (nb % L.nb32_per_phase) * 32;
-        for (int c = 0; c < nchunk; ++c)
-            for (int t = 0; t < L.ntaps; ++t) {
-                const int k = L.tap_k[phase][t];
-                if (k < 0) continue;
-                for (int u = 0; u < nc16; ++u) {
-                    uint16_t* hi = &w16[(((((size_t)nb * nchunk + c) * L.ntaps + t) * nc16 + u) * 2) * frag];
-                    uint16_t* lo = hi + frag;
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int g = lane >> 5, n = lane & 31, co = co0 + n;
-                        for (int j = 0; j < 8; ++j) {
-                            const int ci = c * L.chunk16 + u * 16 + 8 * g + j;
-                            if (ci >= L.cin) continue;
-                            const size_t src = L.transposed ? ((size_t)ci * L.cout + co) * L.K + k : ((size_t)co * L.cin + ci) * L.K + k;
-                            const float v = W.data[src];
-                            const uint16_t vh = f32_to_bf16(v);
-                            hi[lane * 8 + j] = vh;
-                            lo[lane * 8 + j] = f32_to_bf16(v - bf16_to_f32(vh));
-                        }
-                    }
-                }
-            }
-    }
-    void* dp = nullptr;
-    HIP_TRY(hipMalloc(&dp, w16.size() * sizeof(uint16_t)));
-    h->allocs.push_back(dp);
-    HIP_TRY(hipMemcpy(dp, w16.data(), w16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    L.d_w16 = static_cast<uint16_t*>(dp);
+    if ((rc = pack_w16(h, L, W, L.chunk16, &L.d_w16)) != HIFICAR_OK) return rc;
+    if (!L.transposed && L.cin_pad == L.cin && (L.cin == 32 || L.cin == 64) && L.cout == L.cin)
+        if ((rc = pack_w16(h, L, W, L.cin, &L.d_w16c)) != HIFICAR_OK) return rc;
     return HIFICAR_OK;
 }
 
@@ -514,6 +524,10 @@ extern "C" int hificar_finalize(hificar_handle* h) {
     HIP_TRY((set_lds_attr<1, 1, 2, 2>()));
     HIP_TRY((set_lds_attr<1, 1, 1, 4>()));
     HIP_TRY((set_lds_attr<2, 1, 4, 1>()));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<2, 2, 2, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<2, 4, 1, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define HIFICAR_SET_ATTR(mi, wm, wn, nc) HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>()));
     HIFICAR_FOR_BF16_ALL(HIFICAR_SET_ATTR)
 #undef HIFICAR_SET_ATTR
@@ -758,6 +772,74 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
     return HIFICAR_OK;
 }
 
+// Fused conv1 -> LeakyReLU -> conv2 (+ residual) for C = 32 / 64 (conv_pair_bf16x3_kernel).
+struct PairIOB {
+    const char* xs;   // split input of conv1
+    const float* res; // fp32 residual
+    float* y;         // fp32 output (may alias res)
+    char* ys;         // split copy of LeakyReLU(y) for the next pair (must NOT alias xs: neighbouring tiles read xs halos), or null
+};
+
+static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const ConvLayer& b) {
+    return h->use_pair && a.d_w16c && b.d_w16c && a.cin == b.cin && a.ntaps >= 2 && b.ntaps >= 2 && b.dilation == 1 && a.K == b.K;
+}
+
+static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, const ConvLayer* const* l2, int nbr, int nseq, int rows,
+                              const PairIOB* io, float slope, hipStream_t stream) {
+    const int C = l1[0]->cin;
+    const int MI = 2, WM = C == 64 ? 2 : 4;
+    const int TMc = WM * MI * 32, RB = C * 4;
+    PairParams pp;
+    memset(&pp, 0, sizeof(pp));
+    int halo_max = 0;
+    double flops = 0.0, bytes = 0.0;
+    int tile = 0;
+    for (int b = 0; b < nbr; ++b) {
+        const ConvLayer& A = *l1[b];
+        const ConvLayer& B = *l2[b];
+        const float* none[3] = {nullptr, nullptr, nullptr};
+        fill_params(pp.p1[b], A, rows, TMc, none, 0, nullptr, nullptr, 1.0f);
+        fill_params(pp.p2[b], B, rows, TMc, none, 0, io[b].res, io[b].y, 1.0f);
+        pp.p1[b].w16 = reinterpret_cast<const bf16x8*>(A.d_w16c);
+        pp.p2[b].w16 = reinterpret_cast<const bf16x8*>(B.d_w16c);
+        pp.p1[b].xs = io[b].xs;
+        pp.p1[b].zeros = h->d_zeros;
+        pp.p2[b].ys = io[b].ys;
+        pp.p2[b].slope_out = slope;
+        pp.p2[b].cout_real = C;
+        halo_max = std::max(halo_max, A.off_max - A.off_min);
+        const int tmo = TMc - (B.ntaps - 1);
+        pp.tiles_per_seq[b] = (rows + tmo - 1) / tmo;
+        pp.tile_start[b] = tile;
+        tile += nseq * pp.tiles_per_seq[b];
+        const double pos = (double)nseq * rows;
+        flops += 2.0 * pos * C * C * (A.K + B.K);
+        bytes += 4.0 * (pos * C * (3 + (io[b].ys ? 1 : 0)) + (double)C * C * (A.K + B.K));
+    }
+    pp.tile_start[nbr] = tile;
+    pp.n_branches = nbr;
+    pp.nseq = nseq;
+    pp.in_bytes = (int)round_up_sz((size_t)(TMc + halo_max) * RB, 1024);
+    pp.ts_bytes = (TMc + 16) * RB;
+    pp.slope_mid = slope;
+    pp.trace = nullptr;
+    const size_t lds = (size_t)pp.in_bytes + pp.ts_bytes + (size_t)TMc * (C + 4) * sizeof(float);
+    if (lds > 160 * 1024) return fail(HIFICAR_E_INVALID, "internal: pair kernel LDS too large (%zu)", lds);
+    dim3 grid((unsigned)std::min(tile, h->num_cus), 1, 1);
+    char kname[96];
+    snprintf(kname, sizeof(kname), "conv_pair_bf16x3_kernel<%d,%d,%d,%d>", MI, WM, 4 / WM, C / 16);
+    if (h->profile_detail) {
+        const size_t n = strlen(kname);
+        snprintf(kname + n, sizeof(kname) - n, "|%s x%d", l1[0]->name.c_str(), nbr);
+    }
+    ProfScope prof(h, stream, kname, flops, bytes);
+    if (C == 64) hipLaunchKernelGGL((conv_pair_bf16x3_kernel<2, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
+    else hipLaunchKernelGGL((conv_pair_bf16x3_kernel<2, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(HIFICAR_E_HIP, "pair launch (%s) failed: %s", l1[0]->name.c_str(), hipGetErrorString(e));
+    return HIFICAR_OK;
+}
+
 static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows,
                        const float* (*xin)[3], int nin, const float* const* res, float* const* y, float slope,
                        hipStream_t stream) {
@@ -894,20 +976,32 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 const ConvLayer* l1[3];
                 const ConvLayer* l2[3];
                 ConvIOB io1[3], io2[3];
+                PairIOB iop[3];
                 int n = 0;
+                bool fuse = true;
                 for (int oj = 0; oj < nbk; ++oj) {
                     const int j = order[oj];
                     if (d >= cfg.n_dilations[j]) continue;
                     const int ci = conv_index(h, i, j, d);
                     l1[n] = &h->convs1[ci];
                     l2[n] = &h->convs2[ci];
+                    fuse = fuse && pair_eligible(h, *l1[n], *l2[n]);
                     const bool last = d + 1 == cfg.n_dilations[j];
+                    // layer-by-layer: x_s[j] -> xt_s[j] -> x_s[j].  Fused pair: the split stream ping-pongs between x_s[j]
+                    // and xt_s[j] (a tile's output pass must not overwrite rows a neighbouring tile still reads as halo)
+                    const char* in_s = d == 0 ? ws.u_s : ((d & 1) ? ws.x_s[j] : xt_s[j]);
+                    char* out_s = (d & 1) ? xt_s[j] : ws.x_s[j];
                     io1[n] = {d == 0 ? ws.u_s : ws.x_s[j], nullptr, nullptr, xt_s[j]};
                     io2[n] = {xt_s[j], d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : ws.x_s[j]};
+                    iop[n] = {in_s, d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : out_s};
                     ++n;
                 }
-                if ((rc = launch_conv_bf16x3(h, l1, n, B, rows, io1, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
-                if ((rc = launch_conv_bf16x3(h, l2, n, B, rows, io2, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+                if (fuse) {
+                    if ((rc = launch_pair_bf16x3(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+                } else {
+                    if ((rc = launch_conv_bf16x3(h, l1, n, B, rows, io1, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+                    if ((rc = launch_conv_bf16x3(h, l2, n, B, rows, io2, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+                }
             }
         }
     } else {

@@ -617,6 +617,342 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     __syncthreads();  // matches the loader waves' final barrier
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused ResBlock layer pair for narrow stages (C = 32 or 64 channels):
+//     x_new = x + conv2(LeakyReLU(conv1(LeakyReLU(x))))            (residual_block.py:217-221, one dilation)
+// in ONE persistent kernel: the intermediate activation never leaves the CU.  At C <= 64 the layer-by-layer
+// kernels are bound by the CU's memory path (the loader waves), not by the matrix pipe; fusing the pair removes
+// the intermediate's round trip (-1/3 of the bytes) and halves the launches of those stages.
+//
+// Same roles as conv_bf16x3_kernel.  A tile is TMc = WM*MI*32 rows of conv1 output for ALL C channels (TN = C, one
+// K chunk = C): conv1 accumulates from the DMA-staged input buffer, its epilogue applies bias + LeakyReLU + hi/lo
+// split and writes the LDS intermediate TS (zero rows outside the sequence = conv2's padding); conv2 then runs
+// its k taps over TS and drops raw accumulators for the TMc - (k-1) valid rows into the out-buffer.
+// Per tile: barrier A (input landed), barrier B (input buffer free, TS complete).  Loader waves: write_out(previous
+// tile) between A and B (hidden behind conv1), DMA(next tile) after B (hidden behind conv2).
+// ------------------------------------------------------------------------------------------------
+struct PairParams {
+    ConvParams p1[3];      // conv1 of each branch: xs, w16, bias, L, cin (= C), ntaps, tap_step, tap_off0[0], off_min, halo, zeros
+    ConvParams p2[3];      // conv2: w16, bias, ntaps (= k), res, y, ys, slope_out, cout_total = cout_real = C
+    int n_branches;
+    int nseq;
+    int tile_start[4];     // first tile id of each branch; [n_branches] = total
+    int tiles_per_seq[3];  // ceil(L / (TMc - (k_b - 1)))
+    int in_bytes;          // LDS bytes of the input buffer (sized for the widest halo)
+    int ts_bytes;          // LDS bytes of the intermediate
+    float slope_mid;       // LeakyReLU slope between conv1 and conv2
+    unsigned long long* trace;
+};
+
+template <int MI, int WM, int WN, int NC16>
+__global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams mp) {
+    static_assert(WM * WN == 4, "4 MFMA waves per workgroup");
+    static_assert(NC16 == 2 || NC16 == 4, "C = 32 or 64");
+    static_assert(WN * 32 == NC16 * 16, "the workgroup covers all C channels");
+    constexpr int TMc = WM * MI * 32;
+    constexpr int CH = NC16 * 16;
+    constexpr int RB = CH * 4;
+    constexpr int SPR = CH / 4;
+    constexpr int LOG_SPR = NC16 == 4 ? 4 : 3;
+    constexpr int LOG_RPB = 4 - LOG_SPR;
+    constexpr int TN = CH;
+    constexpr int OP = TN + 4;
+    extern __shared__ __attribute__((aligned(1024))) char smem_b[];
+    const int in_bytes = mp.in_bytes;
+    const int ts_off = in_bytes;
+    const int o_off = in_bytes + mp.ts_bytes;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int cw = wave & 3;
+    const int wm = cw / WN;
+    const int wn = cw % WN;
+    const int li = lane & 31;
+    const int g = lane >> 5;
+    const int total_tiles = mp.tile_start[mp.n_branches];
+
+    struct Tile {
+        int b, seq, t0, tmo;
+    };
+    auto decode = [&](int tile) {
+        Tile T;
+        T.b = 0;
+        if (mp.n_branches > 1 && tile >= mp.tile_start[1]) T.b = 1;
+        if (mp.n_branches > 2 && tile >= mp.tile_start[2]) T.b = 2;
+        const int m = tile - mp.tile_start[T.b];
+        const int tps = mp.tiles_per_seq[T.b];
+        T.tmo = TMc - (mp.p2[T.b].ntaps - 1);
+        T.seq = m / tps;
+        T.t0 = (m - T.seq * tps) * T.tmo;
+        return T;
+    };
+    const int my_rounds = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto tile_of = [&](int it) {  // light first, odd workgroups swap their last two rounds (see conv_bf16x3_kernel)
+        int r = my_rounds - 1 - it;
+        if ((blockIdx.x & 1) && my_rounds >= 3 && it >= my_rounds - 2) r = it == my_rounds - 1 ? 1 : 0;
+        return (int)blockIdx.x + r * (int)gridDim.x;
+    };
+
+    if (loader) {
+        const int lw = wave - 4;
+        const int ltid = tid - 256;
+        const float* O = reinterpret_cast<const float*>(smem_b + o_off);
+        auto dma_in = [&](const Tile& T) {
+            const ConvParams& p = mp.p1[T.b];
+            const int pad2 = (mp.p2[T.b].ntaps - 1) >> 1;
+            const int R = TMc + p.halo;
+            const int ninstr = (R * SPR + 63) >> 6;
+            const size_t seq_base = (size_t)T.seq * p.L;
+            const int row_bytes = p.cin * 4;
+            const int tfirst = T.t0 - pad2 + p.off_min;  // time of LDS row 0
+            for (int i = lw; i < ninstr; i += 4) {
+                const int n = i * 64 + lane;
+                const int r = n >> LOG_SPR;
+                const int sl = (n & (SPR - 1)) ^ ((r >> LOG_RPB) & (SPR - 1));
+                const int t = tfirst + r;
+                const char* src = p.zeros;
+                if (r < R && t >= 0 && t < p.L)
+                    src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? sl * 16 : p.cin * 2 + (sl - SPR / 2) * 16);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem_b + i * 1024), 16, 0, 0);
+            }
+        };
+        auto write_out = [&](const Tile& T) {
+            const ConvParams& p = mp.p2[T.b];
+            constexpr int w8 = TN / 8;
+            constexpr int rpp = 256 / w8;
+            const int rr = ltid / w8;
+            const int c8 = (ltid - rr * w8) * 8;
+            const size_t seq_base = (size_t)T.seq * p.L;
+            const float slope_out = p.slope_out;
+            const int rows = min(T.tmo, p.L - T.t0);
+            const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + c8);
+            const f32x4 bv1 = *reinterpret_cast<const f32x4*>(p.bias + c8 + 4);
+            constexpr int UB = 4;
+            for (int r0 = 0; r0 < rows; r0 += rpp * UB) {
+                f32x4 v0[UB], v1[UB], q0[UB], q1[UB];
+#pragma unroll
+                for (int q = 0; q < UB; ++q) {
+                    const int row_l = r0 + q * rpp + rr;
+                    v0[q] = v1[q] = q0[q] = q1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (row_l < rows) {
+                        v0[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8]);
+                        v1[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8 + 4]);
+                        const float* rp = p.res + (seq_base + T.t0 + row_l) * TN + c8;
+                        q0[q] = *reinterpret_cast<const f32x4*>(rp);
+                        q1[q] = *reinterpret_cast<const f32x4*>(rp + 4);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < UB; ++q) {
+                    const int row_l = r0 + q * rpp + rr;
+                    if (row_l < rows) {
+                        const size_t row = seq_base + T.t0 + row_l;
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = (v0[q][e] + bv0[e]) + q0[q][e];
+                            o[4 + e] = (v1[q][e] + bv1[e]) + q1[q][e];
+                        }
+                        float* yp = p.y + row * TN + c8;
+                        *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+                        *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+                        if (p.ys) {
+                            bf16x8 hi, lo;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float a = fmaxf(o[e], o[e] * slope_out);
+                                hi[e] = (__bf16)a;
+                                lo[e] = (__bf16)(a - (float)hi[e]);
+                            }
+                            char* orow = p.ys + row * (size_t)TN * 4 + c8 * 2;
+                            *reinterpret_cast<bf16x8*>(orow) = hi;
+                            *reinterpret_cast<bf16x8*>(orow + TN * 2) = lo;
+                        }
+                    }
+                }
+            }
+        };
+        Tile Tprev;
+        if (my_rounds > 0) dma_in(decode(tile_of(0)));
+        for (int it = 0; it < my_rounds; ++it) {
+            const Tile T = decode(tile_of(it));
+            HIFICAR_STAMP(4 * it);
+            __syncthreads();                 // A: input of tile `it` landed (hipcc drains vmcnt first)
+            HIFICAR_STAMP(4 * it + 1);
+            if (it > 0) write_out(Tprev);    // hidden behind conv1 of this tile
+            HIFICAR_STAMP(4 * it + 2);
+            __syncthreads();                 // B: conv1 done with the input buffer, TS complete
+            HIFICAR_STAMP(4 * it + 3);
+            if (it + 1 < my_rounds) dma_in(decode(tile_of(it + 1)));  // hidden behind conv2
+            Tprev = T;
+        }
+        __syncthreads();                     // Z: the last tile's accumulators are in the out-buffer
+        if (my_rounds > 0) write_out(Tprev);
+        return;
+    }
+
+    // ---------------- MFMA role ----------------
+    f32x16 acc[MI];
+    bf16x8 bq[NC16][2], bn[NC16][2];
+    const bf16x8* wp = nullptr;
+    int groups_left = 0;
+    auto stream1 = [&](const Tile& T) { return mp.p1[T.b].w16 + (size_t)wn * mp.p1[T.b].ntaps * NC16 * 128 + lane; };
+    auto stream2 = [&](const Tile& T) { return mp.p2[T.b].w16 + (size_t)wn * mp.p2[T.b].ntaps * NC16 * 128 + lane; };
+    if (my_rounds > 0) {
+        const Tile T0 = decode(tile_of(0));
+        wp = stream1(T0);
+#pragma unroll
+        for (int u = 0; u < NC16; ++u) {
+            bq[u][0] = wp[u * 128];
+            bq[u][1] = wp[u * 128 + 64];
+            bn[u][0] = wp[(NC16 + u) * 128];  // every conv here has >= 2 taps (checked on the host)
+            bn[u][1] = wp[(NC16 + u) * 128 + 64];
+        }
+        wp += 2 * NC16 * 128;
+        groups_left = mp.p1[T0.b].ntaps - 2;
+    }
+    const int wave_row0 = wm * (MI * 32);
+
+    auto addr_set = [&](int buf_off, int r0, int (&ad)[NC16][2]) {
+        const int swz = (r0 >> LOG_RPB) & (SPR - 1);
+        const int base = buf_off + r0 * RB;
+#pragma unroll
+        for (int u = 0; u < NC16; ++u) {
+            ad[u][0] = base + (((2 * u + g) ^ swz) << 4);
+            ad[u][1] = base + (((SPR / 2 + 2 * u + g) ^ swz) << 4);
+        }
+    };
+    auto load_x = [&](bf16x8 (&xh)[MI], bf16x8 (&xl)[MI], const int (&ad)[2]) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            xh[mi] = *reinterpret_cast<const bf16x8*>(smem_b + ad[0] + mi * 32 * RB);
+            xl[mi] = *reinterpret_cast<const bf16x8*>(smem_b + ad[1] + mi * 32 * RB);
+        }
+    };
+    auto mfma_step = [&](const bf16x8 (&xh)[MI], const bf16x8 (&xl)[MI], const bf16x8& wh, const bf16x8& wl) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[mi], acc[mi], 0, 0, 0);
+    };
+    // one convolution: taps x NC16 K slabs out of the LDS image at buf_off; lane's row for tap t is row0 + t*tap_rows
+    auto run_conv = [&](int buf_off, int row0, int tap_rows, int ntaps, const bf16x8* wp_next, int groups_next) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        int ad[NC16][2];
+        addr_set(buf_off, row0, ad);
+        bf16x8 x0h[MI], x0l[MI], x1h[MI], x1l[MI];
+        load_x(x0h, x0l, ad[0]);
+        for (int t = 0; t < ntaps; ++t) {
+            const bool last_tap = t + 1 == ntaps;
+            int adn[NC16][2];
+            addr_set(buf_off, row0 + (last_tap ? t : t + 1) * tap_rows, adn);
+            if (groups_left == 0) {  // stream exhausted: continue with the next conv's head
+                wp = wp_next;
+                groups_left = groups_next;
+            }
+            --groups_left;
+#pragma unroll
+            for (int u = 0; u < NC16; u += 2) {
+                load_x(x1h, x1l, ad[u + 1]);
+                {
+                    const bf16x8 wh = bq[u][0], wl = bq[u][1];
+                    bq[u][0] = bn[u][0];
+                    bq[u][1] = bn[u][1];
+                    bn[u][0] = wp[u * 128];
+                    bn[u][1] = wp[u * 128 + 64];
+                    mfma_step(x0h, x0l, wh, wl);
+                }
+                if (u + 2 < NC16) load_x(x0h, x0l, ad[u + 2]);
+                else load_x(x0h, x0l, adn[0]);
+                {
+                    const bf16x8 wh = bq[u + 1][0], wl = bq[u + 1][1];
+                    bq[u + 1][0] = bn[u + 1][0];
+                    bq[u + 1][1] = bn[u + 1][1];
+                    bn[u + 1][0] = wp[(u + 1) * 128];
+                    bn[u + 1][1] = wp[(u + 1) * 128 + 64];
+                    mfma_step(x1h, x1l, wh, wl);
+                }
+            }
+            wp += NC16 * 128;
+#pragma unroll
+            for (int u = 0; u < NC16; ++u) {
+                ad[u][0] = adn[u][0];
+                ad[u][1] = adn[u][1];
+            }
+        }
+    };
+
+    for (int it = 0; it < my_rounds; ++it) {
+        const Tile T = decode(tile_of(it));
+        const ConvParams& p1 = mp.p1[T.b];
+        const ConvParams& p2 = mp.p2[T.b];
+        const int k2 = p2.ntaps;
+        const int pad2 = (k2 - 1) >> 1;
+        const Tile Tn = decode(tile_of(it + 1 < my_rounds ? it + 1 : it));
+        HIFICAR_STAMP(6 * it);
+        __syncthreads();  // A: input landed
+        HIFICAR_STAMP(6 * it + 1);
+        // ---- conv1 over TMc rows (time t0 - pad2 + r1) ----
+        run_conv(0, wave_row0 + li + (p1.tap_off0[0] - p1.off_min), p1.tap_step, p1.ntaps, stream2(T), k2);
+        HIFICAR_STAMP(6 * it + 2);
+        {   // bias + LeakyReLU + split -> TS (zero outside the sequence: conv2's padding)
+            const float slope = mp.slope_mid;
+            f32x4 bias4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias4[q] = *reinterpret_cast<const f32x4*>(p1.bias + wn * 32 + 8 * q + 4 * g);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int r1 = wave_row0 + mi * 32 + li;
+                const int t = T.t0 - pad2 + r1;
+                const bool in_seq = t >= 0 && t < p1.L;
+                const int swz = (r1 >> LOG_RPB) & (SPR - 1);
+                char* trow = smem_b + ts_off + r1 * RB + 8 * g;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[mi][4 * q + e] + bias4[q][e];
+                        const float a = in_seq ? fmaxf(v, v * slope) : 0.f;
+                        hi[e] = (__bf16)a;
+                        lo[e] = (__bf16)(a - (float)hi[e]);
+                    }
+                    const int slot = wn * 4 + q;  // 8-channel group of this lane's 4 channels
+                    *reinterpret_cast<bf16x4*>(trow + ((slot ^ swz) << 4)) = hi;
+                    *reinterpret_cast<bf16x4*>(trow + (((SPR / 2 + slot) ^ swz) << 4)) = lo;
+                }
+            }
+        }
+        HIFICAR_STAMP(6 * it + 3);
+        __syncthreads();  // B: input buffer free, TS complete
+        HIFICAR_STAMP(6 * it + 4);
+        // ---- conv2 over TS: output row r2 reads TS rows r2 .. r2 + k2 - 1 ----
+        run_conv(ts_off, wave_row0 + li, 1, k2, stream1(Tn), mp.p1[Tn.b].ntaps);
+        HIFICAR_STAMP(6 * it + 5);
+        {
+            float* O = reinterpret_cast<float*>(smem_b + o_off);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][4 * q + e];
+                    *reinterpret_cast<f32x4*>(&O[(wave_row0 + mi * 32 + li) * OP + wn * 32 + 8 * q + 4 * g]) = v;
+                }
+        }
+    }
+    __syncthreads();  // Z
+}
+
 // MRF mean + LeakyReLU + split for the upsample convs' input: out = split(lrelu(((x0 + x1) + x2) / n, slope)).
 // Elementwise, HBM-bound; one thread = 8 channels (2 x 16 B in per input, 16 B hi + 16 B lo out).
 struct MrfSplitParams {

@@ -260,3 +260,25 @@ def test_precisions_agree_and_switch_in_place(car):
         g.set_precision(orig)
     assert not torch.equal(y32, y16)
     assert rel_err(y16.cpu().numpy(), y32.cpu().numpy()) < TOLS["bf16x3"] < NORTH_STAR_TOL
+
+
+def test_fused_pair_kernel_matches_layer_by_layer(monkeypatch):
+    """Narrow stages (C = 32 / 64) run conv1 -> conv2 as one fused kernel; HIFICAR_PAIR=0 runs them layer by layer.
+    Both are the same arithmetic in a different tiling, so they must agree to bf16x3 rounding noise."""
+    params = dict(E2W_PARAMS)
+    c = torch.from_numpy(synth_features(3, 40, 13, seed=123)).permute(0, 2, 1).contiguous().cuda()
+    ar = torch.from_numpy(synth_features(3, 512, 1, seed=124)[:, :, 0] * 0.3).reshape(3, 1, 512).cuda()
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HIFICAR_PAIR", flag)  # read by hificar_create
+        g, w = make(params, "bf16x3")
+        with torch.no_grad():
+            outs[flag] = g(c, ar=ar).cpu()
+            g.profile_begin()
+            g(c, ar=ar)
+            names = {s["name"].split("<")[0] for s in g.profile_end()}
+        assert ("conv_pair_bf16x3_kernel" in names) == (flag == "1")
+    with torch.no_grad():
+        ref = O.generator_forward(w, params, c.cpu(), ar.cpu())
+    assert rel_err(outs["1"].numpy(), outs["0"].numpy()) < TOLS["bf16x3"]
+    assert rel_err(outs["1"].numpy(), ref.numpy()) < TOLS["bf16x3"]

@@ -86,7 +86,83 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
     }
 }
 
+template <int MI, int WM, int WN, int NC16>
+void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks, int dil) {
+    constexpr int TMc = WM * MI * 32;
+    float *x, *y[3], *bias;
+    char *xs, *ys[3], *zeros;
+    const size_t n = (size_t)nseq * L * C;
+    hipMalloc(&x, n * 4); hipMemset(x, 0, n * 4);
+    hipMalloc(&xs, n * 4); hipMemset(xs, 0x3c, n * 4);
+    hipMalloc(&zeros, 256); hipMemset(zeros, 0, 256);
+    hipMalloc(&bias, C * 4); hipMemset(bias, 0, C * 4);
+    PairParams pp;
+    memset(&pp, 0, sizeof(pp));
+    int halo_max = 0, tile = 0;
+    double flops = 0;
+    for (int b = 0; b < nbr; ++b) {
+        hipMalloc(&y[b], n * 4); hipMalloc(&ys[b], n * 4);
+        const int K = ks[b], pad = (K - 1) / 2 * dil;
+        const size_t wel = ((size_t)(C / 32) * (C / 16) * K * 2 + 4 * NC16) * 512;
+        uint16_t *w1, *w2;
+        hipMalloc(&w1, wel * 2); hipMalloc(&w2, wel * 2);
+        std::vector<uint16_t> hw(wel);
+        for (size_t i = 0; i < wel; ++i) hw[i] = 0x3c00 + (uint16_t)((i * 40503u) & 0xff);
+        hipMemcpy(w1, hw.data(), wel * 2, hipMemcpyHostToDevice);
+        hipMemcpy(w2, hw.data(), wel * 2, hipMemcpyHostToDevice);
+        ConvParams& p = pp.p1[b];
+        p.xs = xs; p.w16 = reinterpret_cast<const bf16x8*>(w1); p.bias = bias; p.zeros = zeros;
+        p.L = L; p.cin = C; p.cout_total = C; p.n_blocks32 = C / 32; p.nb32_per_phase = C / 32; p.ntaps = K; p.off_min = -pad; p.halo = 2 * pad;
+        p.tap_step = dil; p.tap_off0[0] = -pad;
+        ConvParams& q = pp.p2[b];
+        q.w16 = reinterpret_cast<const bf16x8*>(w2); q.bias = bias; q.res = x; q.y = y[b]; q.ys = ys[b]; q.slope_out = 0.1f;
+        q.L = L; q.cin = C; q.cout_total = C; q.cout_real = C; q.ntaps = K; q.n_blocks32 = C / 32;
+        halo_max = std::max(halo_max, p.halo);
+        const int tmo = TMc - (K - 1);
+        pp.tiles_per_seq[b] = (L + tmo - 1) / tmo;
+        pp.tile_start[b] = tile;
+        tile += nseq * pp.tiles_per_seq[b];
+        flops += 2.0 * nseq * L * (double)C * C * K * 2;
+    }
+    pp.tile_start[nbr] = tile; pp.n_branches = nbr; pp.nseq = nseq;
+    pp.in_bytes = ((TMc + halo_max) * C * 4 + 1023) / 1024 * 1024;
+    pp.ts_bytes = (TMc + 16) * C * 4;
+    pp.slope_mid = 0.1f;
+    const int G = std::min(tile, 256);
+    unsigned long long* trace;
+    hipMalloc(&trace, (size_t)G * 2 * 64 * 8); hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
+    pp.trace = trace;
+    auto kern = conv_pair_bf16x3_kernel<MI, WM, WN, NC16>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t lds = pp.in_bytes + pp.ts_bytes + (size_t)TMc * (C + 4) * 4;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int it = 0; it < 3; ++it) {
+        hipEventRecord(e0);
+        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3(512), lds, 0, pp);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("%-28s tiles=%d G=%d lds=%zuKB  %.1f us/launch(pair)  %.0f TF-alg\n", label, tile, G, lds / 1024, ms * 100, flops / (ms * 1e-4) / 1e12);
+    std::vector<unsigned long long> ht((size_t)G * 2 * 64);
+    hipMemcpy(ht.data(), trace, ht.size() * 8, hipMemcpyDeviceToHost);
+    for (int wg : {0}) {
+        const unsigned long long* m = &ht[(size_t)wg * 2 * 64];
+        const unsigned long long* l = m + 64;
+        const unsigned long long t0 = std::min(m[0] ? m[0] : ~0ull, l[0] ? l[0] : ~0ull);
+        printf("  WG %d MFMA [A? A conv1 epi B conv2]x : ", wg);
+        for (int i = 0; i < 60; ++i) printf("%lld ", m[i] ? (long long)(m[i] - t0) / 100 : -1LL);
+        printf("\n  WG %d load [A? A wout B]x : ", wg);
+        for (int i = 0; i < 44; ++i) printf("%lld ", l[i] ? (long long)(l[i] - t0) / 100 : -1LL);
+        printf("\n");
+    }
+}
+
 int main() {
+    {
+        const int k3[3] = {11, 7, 3};
+        run_pair<2, 2, 2, 4>("PAIR stage2 C64 L1000", 64, 1000, 64, 3, k3, 1);
+        run_pair<2, 4, 1, 2>("PAIR stage3 C32 L2000", 64, 2000, 32, 3, k3, 1);
+    }
     const int k3[3] = {11, 7, 3};
     run<4, 1, 4, 4>("stage0 TM128 TN128 (4,1,4)", 64, 125, 256, 3, k3, 1, false);
     run<2, 1, 4, 4>("stage0 TM64 TN128 (2,1,4)", 64, 125, 256, 3, k3, 1, false);
