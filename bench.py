@@ -96,8 +96,10 @@ def main():
         raise SystemExit("bench.py needs a MI355X: no GPU visible (the generator has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torchrun the RCCL path is exercised even at world size 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm
 
     params = dict(CAR_PARAMS)
@@ -112,16 +114,16 @@ def main():
     n_samples = B * T * HOP
     # synthetic 13-dim pitch+EMA, seed 20260929 + config index 3 + rank
     feats = torch.from_numpy(synth_features(B, T, 13, seed=20260929 + 3 + 1000 * rank)).permute(0, 2, 1).contiguous().to(dev)
-    gathered = torch.empty((world * B, T * HOP), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, T * HOP), dtype=torch.float32, device=dev) if use_dist else None
 
     def step():
         y = g.ar_synthesis(feats, args.chunk_frames)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, y)  # waveform collection only
         return y
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -134,10 +136,12 @@ def main():
             y = step()
         fence()
         dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the gathered block of this rank must be its own waveform (collection only, no arithmetic)
+        assert torch.equal(gathered[rank * B:(rank + 1) * B], y), "all-gather returned a different waveform"
     assert bool(torch.isfinite(y).all()), "non-finite output"
 
     ms_per_step = dt / args.steps * 1e3
@@ -187,6 +191,8 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
+            # bf16x3 issues 3 bf16 MFMAs per algorithmic MAC: the matrix pipe itself runs at 3x `achieved`
+            "mfma_issue_tflops": round(achieved * (3 if args.precision == "bf16x3" else 1), 2),
             "launches": dom["launches"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
             "flops_per_launch": round(dom["flops"] / dom["launches"], 1),
             "kernel_time_share": round(dom["total_ms"] / total_ms, 4),
@@ -194,7 +200,7 @@ def main():
                              "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2)} for s in stats],
             "events_pass_ms_per_step": round(te / args.steps * 1e3, 3),
         }
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -202,7 +208,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
