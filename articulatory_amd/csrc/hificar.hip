@@ -72,6 +72,7 @@ struct hificar_handle {
     int precision = HIFICAR_PREC_F32;
     bool profile_detail = false;   // HIFICAR_PROFILE_DETAIL=1: profile rows carry the layer name
     bool use_pair = true;          // HIFICAR_PAIR=0: run narrow stages layer by layer (A/B runs)
+    bool use_lpt = true;           // HIFICAR_LPT=0: round-robin tile walk instead of the host LPT schedule (A/B runs)
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
     int cin_pad = 0;  // padded input-conv channels
     int hop = 1;
@@ -90,6 +91,12 @@ struct hificar_handle {
     float* d_mlp_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs;
     char* d_zeros = nullptr;  // 256 bytes of zeros: source of padding rows for the LDS DMA
+    // tile schedules (LPT assignment of tiles to workgroups), cached per launch shape
+    struct Sched {
+        int* d_start = nullptr;
+        int* d_tiles = nullptr;
+    };
+    std::map<std::string, Sched> scheds;
     // profiling (hificar_profile_begin/end)
     bool profiling = false;
     struct ProfRec {
@@ -224,6 +231,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     h->cfg = c;
     if (const char* e = getenv("HIFICAR_PROFILE_DETAIL")) h->profile_detail = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_PAIR")) h->use_pair = atoi(e) != 0;
+    if (const char* e = getenv("HIFICAR_LPT")) h->use_lpt = atoi(e) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -671,6 +679,56 @@ static hipError_t launch_conv_t(const MultiConvParams& mp, dim3 grid, size_t lds
 }
 
 // Launch nbr (1..3) same-shape conv layers ("branches") as one grid; branch = blockIdx.z.
+// Longest-processing-time-first assignment of `costs.size()` tiles to G workgroups; each workgroup's list is then
+// ordered light -> heavy (the kernel walks it in that order).  Uploaded once per launch shape and cached.
+static int get_schedule(hificar_handle* h, const std::string& key, const std::vector<double>& costs, int G,
+                        const int** d_start, const int** d_tiles) {
+    auto it = h->scheds.find(key);
+    if (it == h->scheds.end()) {
+        const int n = (int)costs.size();
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return costs[a] > costs[b]; });
+        std::vector<std::vector<int>> lists(G);
+        // min-heap of (load, workgroup)
+        std::vector<std::pair<double, int>> heap;
+        for (int w = 0; w < G; ++w) heap.push_back({0.0, w});
+        auto cmp = [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
+            return a.first > b.first || (a.first == b.first && a.second > b.second);
+        };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        for (int t : order) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            auto& top = heap.back();
+            lists[top.second].push_back(t);
+            top.first += costs[t];
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+        std::vector<int> start(G + 1, 0), tiles;
+        tiles.reserve(n);
+        for (int w = 0; w < G; ++w) {
+            std::reverse(lists[w].begin(), lists[w].end());  // heavy-first insertion order -> light first
+            start[w] = (int)tiles.size();
+            tiles.insert(tiles.end(), lists[w].begin(), lists[w].end());
+        }
+        start[G] = (int)tiles.size();
+        hificar_handle::Sched sc;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, start.size() * sizeof(int)));
+        h->allocs.push_back(p);
+        sc.d_start = static_cast<int*>(p);
+        HIP_TRY(hipMalloc(&p, std::max<size_t>(tiles.size(), 1) * sizeof(int)));
+        h->allocs.push_back(p);
+        sc.d_tiles = static_cast<int*>(p);
+        HIP_TRY(hipMemcpy(sc.d_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(sc.d_tiles, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
+        it = h->scheds.emplace(key, sc).first;
+    }
+    *d_start = it->second.d_start;
+    *d_tiles = it->second.d_tiles;
+    return HIFICAR_OK;
+}
+
 struct TileCfgB {
     int MI, WM, WN;
 };
@@ -711,16 +769,18 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
         const long long total = tiles_per_branch * nbr;
         const int G = (int)std::min<long long>(total, h->num_cus);
         const int nchunks = L0.cin_pad / L0.chunk16;
-        double worst = 0.0;
-        // workgroups 0 and G-1 bracket the load (earlier ids get the extra tile of a partial round)
-        for (int w : {0, G - 1}) {
-            double acc = 0.0;
-            for (long long i = w; i < total; i += G) {
-                const ConvLayer& Lb = *layers[i / tiles_per_branch];
-                acc += (double)Lb.ntaps * (L0.cin_pad / 16) * 3 * t.MI * 32 / 0.75 + 2500.0 + 400.0 * nchunks;
-            }
-            worst = std::max(worst, acc);
+        // LPT makespan estimate: max(heaviest tile, total / G), plus one light tile when the count does not divide
+        double total_cost = 0.0, heaviest = 0.0, lightest = 1e300;
+        for (int b = 0; b < nbr; ++b) {
+            const double c = (double)layers[b]->ntaps * (L0.cin_pad / 16) * 3 * t.MI * 32 / 0.75 + 2500.0 + 400.0 * nchunks;
+            total_cost += c * tiles_per_branch;
+            heaviest = std::max(heaviest, c);
+            lightest = std::min(lightest, c);
         }
+        double worst = std::max(heaviest, total_cost / G);
+        if (total % G != 0) worst = std::max(worst, total_cost / G + 0.5 * lightest);
+        // shorter wave tiles re-read the weight stream more often per MFMA (MI = 2 measured ~10 % slower per flop)
+        if (t.MI < 4) worst *= (t.MI == 2 ? 1.10 : 1.25);
         if (worst < best * 0.98) {  // near-ties keep the earlier (taller) shape
             best = worst;
             tc = t;
@@ -755,7 +815,19 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
     mp.total_tiles = nbr * mp.ngroups * mp.nseq_tiles;
     mp.buf_bytes = (int)buf_bytes;
     mp.trace = nullptr;
-    dim3 grid((unsigned)std::min(mp.total_tiles, h->num_cus), 1, 1);  // persistent: one workgroup per CU walks the tile list
+    dim3 grid((unsigned)std::min(mp.total_tiles, h->num_cus), 1, 1);  // persistent: one workgroup per CU walks its tile list
+    if (h->use_lpt && mp.total_tiles > (int)grid.x) {
+        std::vector<double> costs((size_t)mp.total_tiles);
+        const int tpb = mp.ngroups * mp.nseq_tiles;
+        std::string key = "c";
+        for (int b = 0; b < nbr; ++b) {
+            key += "|" + layers[b]->name;
+            for (int i = 0; i < tpb; ++i) costs[(size_t)b * tpb + i] = layers[b]->ntaps + 1.0;  // + fixed per-tile overhead
+        }
+        key += "|" + std::to_string(nseq) + "x" + std::to_string(rows) + "t" + std::to_string(TM) + "w" + std::to_string(tc.WN);
+        int rc2 = get_schedule(h, key, costs, (int)grid.x, &mp.sched_start, &mp.sched_tiles);
+        if (rc2 != HIFICAR_OK) return rc2;
+    }
     char kname[96];
     snprintf(kname, sizeof(kname), "conv_bf16x3_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, nc16);
     if (h->profile_detail) {  // per-layer rows in the profile (tools/layer_profile.py)
@@ -826,6 +898,17 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
     const size_t lds = (size_t)pp.in_bytes + pp.ts_bytes + (size_t)TMc * (C + 4) * sizeof(float);
     if (lds > 160 * 1024) return fail(HIFICAR_E_INVALID, "internal: pair kernel LDS too large (%zu)", lds);
     dim3 grid((unsigned)std::min(tile, h->num_cus), 1, 1);
+    if (h->use_lpt && tile > (int)grid.x) {
+        std::vector<double> costs((size_t)tile);
+        std::string key = "p";
+        for (int b = 0; b < nbr; ++b) {
+            key += "|" + l1[b]->name;
+            for (int i = pp.tile_start[b]; i < pp.tile_start[b + 1]; ++i) costs[i] = l1[b]->ntaps + l2[b]->ntaps + 2.0;
+        }
+        key += "|" + std::to_string(nseq) + "x" + std::to_string(rows);
+        int rc2 = get_schedule(h, key, costs, (int)grid.x, &pp.sched_start, &pp.sched_tiles);
+        if (rc2 != HIFICAR_OK) return rc2;
+    }
     char kname[96];
     snprintf(kname, sizeof(kname), "conv_pair_bf16x3_kernel<%d,%d,%d,%d>", MI, WM, 4 / WM, C / 16);
     if (h->profile_detail) {

@@ -76,6 +76,10 @@ struct MultiConvParams {
     int ngroups;      // ceil(n_blocks32 / WN)
     int total_tiles;  // n_branches * ngroups * nseq_tiles
     int buf_bytes;    // bytes of one LDS staging buffer (sized for the widest halo among the branches)
+    // host-computed schedule (longest-processing-time assignment of tiles to workgroups, each list ordered light
+    // first): workgroup w walks sched_tiles[sched_start[w] .. sched_start[w+1]).  Null: round-robin w, w+G, ...
+    const int* sched_start;
+    const int* sched_tiles;
     unsigned long long* trace;  // dev tool only (tools/conv_bench.hip, -DHIFICAR_TRACE): per-workgroup timeline
 };
 
@@ -316,16 +320,19 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 
     constexpr int TN = WN * 32;
     constexpr int OP = TN + 4;  // out-buffer row pitch (floats)
-    // This workgroup's tiles are w, w + G, w + 2G, ... (one per "round"; rounds run heavy -> light because tile ids
-    // are heaviest-branch-major).  They are walked LIGHT FIRST: the loader waves write a finished tile out while the
-    // MFMA waves compute the next one, and that only hides completely behind a tile at least as heavy.  Odd
-    // workgroups swap their last two rounds so that neighbouring CUs are not in the same phase all the time
-    // (synchronised DMA / output bursts cost ~15 % on this kernel).
-    const int my_rounds = (mp.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // Tile walk.  With a host schedule: the tiles assigned to this workgroup, already ordered light -> heavy.
+    // Without: tiles w, w+G, w+2G, ... (rounds run heavy -> light because tile ids are heaviest-branch-major), walked
+    // LIGHT FIRST: the loader waves write a finished tile out while the MFMA waves compute the next one, and that only
+    // hides completely behind a tile at least as heavy.  Odd workgroups swap their last two tiles so that
+    // neighbouring CUs are not in the same phase all the time (synchronised DMA / output bursts cost ~15 % here).
+    const int sched_lo = mp.sched_start ? mp.sched_start[blockIdx.x] : 0;
+    const int my_rounds = mp.sched_start ? mp.sched_start[blockIdx.x + 1] - sched_lo
+                                         : (mp.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     auto tile_of = [&](int it) {
-        int r = my_rounds - 1 - it;
-        if ((blockIdx.x & 1) && my_rounds >= 3 && it >= my_rounds - 2) r = it == my_rounds - 1 ? 1 : 0;
-        return (int)blockIdx.x + r * (int)gridDim.x;
+        int i = it;
+        if ((blockIdx.x & 1) && my_rounds >= 3 && it >= my_rounds - 2) i = it == my_rounds - 1 ? my_rounds - 2 : my_rounds - 1;
+        if (mp.sched_start) return mp.sched_tiles[sched_lo + i];
+        return (int)blockIdx.x + (my_rounds - 1 - i) * (int)gridDim.x;
     };
     if (loader) {
         // ---------------- loader role: LDS-DMA of split rows + the finished tile's output pass ----------------
@@ -641,6 +648,8 @@ struct PairParams {
     int in_bytes;          // LDS bytes of the input buffer (sized for the widest halo)
     int ts_bytes;          // LDS bytes of the intermediate
     float slope_mid;       // LeakyReLU slope between conv1 and conv2
+    const int* sched_start;  // host-computed schedule, as in MultiConvParams
+    const int* sched_tiles;
     unsigned long long* trace;
 };
 
@@ -688,13 +697,16 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         T.t0 = (m - T.seq * tps) * T.tmo;
         return T;
     };
-    const int my_rounds = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    auto tile_of = [&](int it) {  // light first, odd workgroups swap their last two rounds (see conv_bf16x3_kernel)
-        int r = my_rounds - 1 - it;
-        if ((blockIdx.x & 1) && my_rounds >= 3 && it >= my_rounds - 2) r = it == my_rounds - 1 ? 1 : 0;
-        return (int)blockIdx.x + r * (int)gridDim.x;
+    // tile walk: host schedule or round-robin, light first (see conv_bf16x3_kernel)
+    const int sched_lo = mp.sched_start ? mp.sched_start[blockIdx.x] : 0;
+    const int my_rounds = mp.sched_start ? mp.sched_start[blockIdx.x + 1] - sched_lo
+                                         : (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto tile_of = [&](int it) {
+        int i = it;
+        if ((blockIdx.x & 1) && my_rounds >= 3 && it >= my_rounds - 2) i = it == my_rounds - 1 ? my_rounds - 2 : my_rounds - 1;
+        if (mp.sched_start) return mp.sched_tiles[sched_lo + i];
+        return (int)blockIdx.x + (my_rounds - 1 - i) * (int)gridDim.x;
     };
-
     if (loader) {
         const int lw = wave - 4;
         const int ltid = tid - 256;
