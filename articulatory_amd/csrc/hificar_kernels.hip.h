@@ -334,84 +334,84 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         if (mp.sched_start) return mp.sched_tiles[sched_lo + i];
         return (int)blockIdx.x + (my_rounds - 1 - i) * (int)gridDim.x;
     };
+    const float* O = reinterpret_cast<const float*>(smem_b + 2 * buf_bytes);
+    // Output pass of a finished tile: the MFMA waves left the raw accumulators in the LDS out-buffer as
+    // O[time row][channel]; the participating threads (the 256 loader threads, or all 512 for the last tile) walk it row-major (a wave-instruction covers whole 512-byte
+    // row segments), add bias and residual, and write the fp32 rows and/or the activated split rows.
+    auto write_out = [&](const Tile& T, int ltid, int nthr) {
+        // A CU retires roughly one vector-store wave-instruction per ~70 cycles whatever its width, so every store
+        // here is 16 bytes per lane: a thread owns 8 adjacent channels of a row (2 x float4 in, 16 B hi + 16 B lo out).
+        const ConvParams& p = mp.p[T.b];
+        const int vc_base = T.ng * TN;                            // first virtual channel of the tile
+        const int width = min(TN, p.n_blocks32 * 32 - vc_base);  // a partial channel group is narrower (32 | width)
+        const int w8 = width >> 3;                                // 4, 8, 12 or 16 units per row
+        const int rpp = nthr / w8;                                // rows per pass of the participating threads
+        const int rr = ltid / w8;
+        const int c8 = (ltid - rr * w8) * 8;                      // this thread's channels: the same in every pass
+        const bool lane_on = rr < rpp;                            // w8 = 12 leaves a few threads idle
+        const size_t seq_base = (size_t)T.seq * p.L;
+        const float slope_out = p.slope_out;
+        const int rows = min(TM, p.L - T.t0);
+        const int vc = vc_base + c8;
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + vc);
+        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(p.bias + vc + 4);
+        // split rows: virtual channel -> (real row within the virtual row, channel); 8 | cout_real
+        const int ph_row = vc / p.cout_real;
+        const int split_off = ph_row * p.cout_real * 4 + (vc - ph_row * p.cout_real) * 2;
+        constexpr int UB = 4;  // rows in flight per thread: LDS reads and residual loads are issued before any is used
+        for (int r0 = 0; r0 < rows; r0 += rpp * UB) {
+            f32x4 v0[UB], v1[UB], q0[UB], q1[UB];
+#pragma unroll
+            for (int q = 0; q < UB; ++q) {
+                const int row_l = r0 + q * rpp + rr;
+                v0[q] = v1[q] = q0[q] = q1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (lane_on && row_l < rows) {
+                    v0[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8]);
+                    v1[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8 + 4]);
+                    if (p.res) {
+                        const float* rp = p.res + (seq_base + T.t0 + row_l) * p.cout_total + vc;
+                        q0[q] = *reinterpret_cast<const f32x4*>(rp);
+                        q1[q] = *reinterpret_cast<const f32x4*>(rp + 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < UB; ++q) {
+                const int row_l = r0 + q * rpp + rr;
+                if (lane_on && row_l < rows) {
+                    const size_t row = seq_base + T.t0 + row_l;
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (v0[q][e] + bv0[e]) + q0[q][e];
+                        o[4 + e] = (v1[q][e] + bv1[e]) + q1[q][e];
+                    }
+                    if (p.y) {
+                        float* yp = p.y + row * p.cout_total + vc;
+                        *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+                        *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+                    }
+                    if (p.ys) {
+                        bf16x8 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a = fmaxf(o[e], o[e] * slope_out);  // LeakyReLU, 0 <= slope <= 1
+                            hi[e] = (__bf16)a;
+                            lo[e] = (__bf16)(a - (float)hi[e]);
+                        }
+                        char* orow = p.ys + row * (size_t)p.cout_total * 4 + split_off;
+                        *reinterpret_cast<bf16x8*>(orow) = hi;
+                        *reinterpret_cast<bf16x8*>(orow + p.cout_real * 2) = lo;
+                    }
+                }
+            }
+        }
+    };
     if (loader) {
         // ---------------- loader role: LDS-DMA of split rows + the finished tile's output pass ----------------
         const int lw = wave - 4;
         const int ltid = tid - 256;
-        const float* O = reinterpret_cast<const float*>(smem_b + 2 * buf_bytes);
 
-        // Output pass of a finished tile: the MFMA waves left the raw accumulators in the LDS out-buffer as
-        // O[time row][channel]; the 256 loader threads walk it row-major (a wave-instruction covers whole 512-byte
-        // row segments), add bias and residual, and write the fp32 rows and/or the activated split rows.
-        auto write_out = [&](const Tile& T) {
-            // A CU retires roughly one vector-store wave-instruction per ~70 cycles whatever its width, so every store
-            // here is 16 bytes per lane: a thread owns 8 adjacent channels of a row (2 x float4 in, 16 B hi + 16 B lo out).
-            const ConvParams& p = mp.p[T.b];
-            const int vc_base = T.ng * TN;                            // first virtual channel of the tile
-            const int width = min(TN, p.n_blocks32 * 32 - vc_base);  // a partial channel group is narrower (32 | width)
-            const int w8 = width >> 3;                                // 4, 8, 12 or 16 units per row
-            const int rpp = 256 / w8;                                 // rows per pass of the 256 loader threads
-            const int rr = ltid / w8;
-            const int c8 = (ltid - rr * w8) * 8;                      // this thread's channels: the same in every pass
-            const bool lane_on = rr < rpp;                            // w8 = 12 leaves a few threads idle
-            const size_t seq_base = (size_t)T.seq * p.L;
-            const float slope_out = p.slope_out;
-            const int rows = min(TM, p.L - T.t0);
-            const int vc = vc_base + c8;
-            const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + vc);
-            const f32x4 bv1 = *reinterpret_cast<const f32x4*>(p.bias + vc + 4);
-            // split rows: virtual channel -> (real row within the virtual row, channel); 8 | cout_real
-            const int ph_row = vc / p.cout_real;
-            const int split_off = ph_row * p.cout_real * 4 + (vc - ph_row * p.cout_real) * 2;
-            constexpr int UB = 4;  // rows in flight per thread: LDS reads and residual loads are issued before any is used
-            for (int r0 = 0; r0 < rows; r0 += rpp * UB) {
-                f32x4 v0[UB], v1[UB], q0[UB], q1[UB];
-#pragma unroll
-                for (int q = 0; q < UB; ++q) {
-                    const int row_l = r0 + q * rpp + rr;
-                    v0[q] = v1[q] = q0[q] = q1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (lane_on && row_l < rows) {
-                        v0[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8]);
-                        v1[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8 + 4]);
-                        if (p.res) {
-                            const float* rp = p.res + (seq_base + T.t0 + row_l) * p.cout_total + vc;
-                            q0[q] = *reinterpret_cast<const f32x4*>(rp);
-                            q1[q] = *reinterpret_cast<const f32x4*>(rp + 4);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < UB; ++q) {
-                    const int row_l = r0 + q * rpp + rr;
-                    if (lane_on && row_l < rows) {
-                        const size_t row = seq_base + T.t0 + row_l;
-                        float o[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            o[e] = (v0[q][e] + bv0[e]) + q0[q][e];
-                            o[4 + e] = (v1[q][e] + bv1[e]) + q1[q][e];
-                        }
-                        if (p.y) {
-                            float* yp = p.y + row * p.cout_total + vc;
-                            *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
-                            *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
-                        }
-                        if (p.ys) {
-                            bf16x8 hi, lo;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float a = fmaxf(o[e], o[e] * slope_out);  // LeakyReLU, 0 <= slope <= 1
-                                hi[e] = (__bf16)a;
-                                lo[e] = (__bf16)(a - (float)hi[e]);
-                            }
-                            char* orow = p.ys + row * (size_t)p.cout_total * 4 + split_off;
-                            *reinterpret_cast<bf16x8*>(orow) = hi;
-                            *reinterpret_cast<bf16x8*>(orow + p.cout_real * 2) = lo;
-                        }
-                    }
-                }
-            }
-        };
         auto dma_item = [&](const Tile& T, int c, int jj) {
             const ConvParams& p = mp.p[T.b];
             const int R = TM + p.halo;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 dma_item(T, c, j);
                 // the tile that finished with item j-2 published its accumulators at barrier j-1 (nchunks >= 2, so the
                 // MFMA waves cannot overwrite the out-buffer before barrier j+1)
-                if (c == 1 && have_prev) write_out(Tprev);
+                if (c == 1 && have_prev) write_out(Tprev, ltid, 256);
                 HIFICAR_STAMP(1 + 2 * j);
                 __syncthreads();  // item j landed (hipcc drains vmcnt before the barrier); MFMA waves are done with item j-1's buffer
                 HIFICAR_STAMP(2 + 2 * j);
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             have_prev = true;
         }
         __syncthreads();  // the last tile's accumulators are in the out-buffer
-        if (have_prev) write_out(Tprev);
+        if (have_prev) write_out(Tprev, tid, 512);  // all eight waves share the final output pass (nothing left to hide it behind)
         return;
     }
 
@@ -622,6 +622,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         }
     }
     __syncthreads();  // matches the loader waves' final barrier
+    if (my_rounds > 0) write_out(decode(tile_of(my_rounds - 1)), tid, 512);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -707,10 +708,66 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         if (mp.sched_start) return mp.sched_tiles[sched_lo + i];
         return (int)blockIdx.x + (my_rounds - 1 - i) * (int)gridDim.x;
     };
+    const float* O = reinterpret_cast<const float*>(smem_b + o_off);
+    auto write_out = [&](const Tile& T, int ltid, int nthr) {
+        const ConvParams& p = mp.p2[T.b];
+        constexpr int w8 = TN / 8;
+        const int rpp = nthr / w8;
+        const int rr = ltid / w8;
+        const int c8 = (ltid - rr * w8) * 8;
+        const size_t seq_base = (size_t)T.seq * p.L;
+        const float slope_out = p.slope_out;
+        const int rows = min(T.tmo, p.L - T.t0);
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + c8);
+        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(p.bias + c8 + 4);
+        constexpr int UB = 4;
+        for (int r0 = 0; r0 < rows; r0 += rpp * UB) {
+            f32x4 v0[UB], v1[UB], q0[UB], q1[UB];
+#pragma unroll
+            for (int q = 0; q < UB; ++q) {
+                const int row_l = r0 + q * rpp + rr;
+                v0[q] = v1[q] = q0[q] = q1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row_l < rows) {
+                    v0[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8]);
+                    v1[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8 + 4]);
+                    const float* rp = p.res + (seq_base + T.t0 + row_l) * TN + c8;
+                    q0[q] = *reinterpret_cast<const f32x4*>(rp);
+                    q1[q] = *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < UB; ++q) {
+                const int row_l = r0 + q * rpp + rr;
+                if (row_l < rows) {
+                    const size_t row = seq_base + T.t0 + row_l;
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (v0[q][e] + bv0[e]) + q0[q][e];
+                        o[4 + e] = (v1[q][e] + bv1[e]) + q1[q][e];
+                    }
+                    float* yp = p.y + row * TN + c8;
+                    *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+                    if (p.ys) {
+                        bf16x8 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a = fmaxf(o[e], o[e] * slope_out);
+                            hi[e] = (__bf16)a;
+                            lo[e] = (__bf16)(a - (float)hi[e]);
+                        }
+                        char* orow = p.ys + row * (size_t)TN * 4 + c8 * 2;
+                        *reinterpret_cast<bf16x8*>(orow) = hi;
+                        *reinterpret_cast<bf16x8*>(orow + TN * 2) = lo;
+                    }
+                }
+            }
+        }
+    };
     if (loader) {
         const int lw = wave - 4;
         const int ltid = tid - 256;
-        const float* O = reinterpret_cast<const float*>(smem_b + o_off);
         auto dma_in = [&](const Tile& T) {
             const ConvParams& p = mp.p1[T.b];
             const int pad2 = (mp.p2[T.b].ntaps - 1) >> 1;
@@ -731,62 +788,6 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
                                                  (__attribute__((address_space(3))) void*)(smem_b + i * 1024), 16, 0, 0);
             }
         };
-        auto write_out = [&](const Tile& T) {
-            const ConvParams& p = mp.p2[T.b];
-            constexpr int w8 = TN / 8;
-            constexpr int rpp = 256 / w8;
-            const int rr = ltid / w8;
-            const int c8 = (ltid - rr * w8) * 8;
-            const size_t seq_base = (size_t)T.seq * p.L;
-            const float slope_out = p.slope_out;
-            const int rows = min(T.tmo, p.L - T.t0);
-            const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + c8);
-            const f32x4 bv1 = *reinterpret_cast<const f32x4*>(p.bias + c8 + 4);
-            constexpr int UB = 4;
-            for (int r0 = 0; r0 < rows; r0 += rpp * UB) {
-                f32x4 v0[UB], v1[UB], q0[UB], q1[UB];
-#pragma unroll
-                for (int q = 0; q < UB; ++q) {
-                    const int row_l = r0 + q * rpp + rr;
-                    v0[q] = v1[q] = q0[q] = q1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (row_l < rows) {
-                        v0[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8]);
-                        v1[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8 + 4]);
-                        const float* rp = p.res + (seq_base + T.t0 + row_l) * TN + c8;
-                        q0[q] = *reinterpret_cast<const f32x4*>(rp);
-                        q1[q] = *reinterpret_cast<const f32x4*>(rp + 4);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < UB; ++q) {
-                    const int row_l = r0 + q * rpp + rr;
-                    if (row_l < rows) {
-                        const size_t row = seq_base + T.t0 + row_l;
-                        float o[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            o[e] = (v0[q][e] + bv0[e]) + q0[q][e];
-                            o[4 + e] = (v1[q][e] + bv1[e]) + q1[q][e];
-                        }
-                        float* yp = p.y + row * TN + c8;
-                        *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
-                        *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
-                        if (p.ys) {
-                            bf16x8 hi, lo;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float a = fmaxf(o[e], o[e] * slope_out);
-                                hi[e] = (__bf16)a;
-                                lo[e] = (__bf16)(a - (float)hi[e]);
-                            }
-                            char* orow = p.ys + row * (size_t)TN * 4 + c8 * 2;
-                            *reinterpret_cast<bf16x8*>(orow) = hi;
-                            *reinterpret_cast<bf16x8*>(orow + TN * 2) = lo;
-                        }
-                    }
-                }
-            }
-        };
         Tile Tprev;
         if (my_rounds > 0) dma_in(decode(tile_of(0)));
         for (int it = 0; it < my_rounds; ++it) {
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
             HIFICAR_STAMP(4 * it);
             __syncthreads();                 // A: input of tile `it` landed (hipcc drains vmcnt first)
             HIFICAR_STAMP(4 * it + 1);
-            if (it > 0) write_out(Tprev);    // hidden behind conv1 of this tile
+            if (it > 0) write_out(Tprev, ltid, 256);    // hidden behind conv1 of this tile
             HIFICAR_STAMP(4 * it + 2);
             __syncthreads();                 // B: conv1 done with the input buffer, TS complete
             HIFICAR_STAMP(4 * it + 3);
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
             Tprev = T;
         }
         __syncthreads();                     // Z: the last tile's accumulators are in the out-buffer
-        if (my_rounds > 0) write_out(Tprev);
+        if (my_rounds > 0) write_out(Tprev, tid, 512);  // all eight waves share the final output pass
         return;
     }
 
@@ -963,6 +964,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         }
     }
     __syncthreads();  // Z
+    if (my_rounds > 0) write_out(decode(tile_of(my_rounds - 1)), tid, 512);
 }
 
 // MRF mean + LeakyReLU + split for the upsample convs' input: out = split(lrelu(((x0 + x1) + x2) / n, slope)).
@@ -1144,19 +1146,31 @@ __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p)
     float* ws = smem + R * P;  // weights [k][C]
     for (int i = tid; i < p.K * p.C; i += 256) ws[i] = p.w[i];
     const size_t base = (size_t)seq * p.L;
-    for (int idx = tid; idx < R * p.C; idx += 256) {
-        const int r = idx / p.C;
-        const int ch = idx - r * p.C;
+    const int c4n = p.C >> 2;  // C is a multiple of 32: 16-byte loads
+    for (int idx = tid; idx < R * c4n; idx += 256) {
+        const int r = idx / c4n;
+        const int ch = (idx - r * c4n) * 4;
         const int t = t0 - pad + r;
-        float v = 0.f;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (t >= 0 && t < p.L) {
             const size_t off = (base + t) * p.C + ch;
-            v = p.x0[off];
-            if (p.nin == 3) v = ((v + p.x1[off]) + p.x2[off]) / 3.0f;
-            else if (p.nin == 2) v = (v + p.x1[off]) / 2.0f;
-            v = lrelu(v, p.slope);
+            v = *reinterpret_cast<const f32x4*>(p.x0 + off);
+            if (p.nin >= 2) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.x1 + off);
+                if (p.nin == 3) {
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.x2 + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((v[e] + b[e]) + c[e]) / 3.0f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] + b[e]) / 2.0f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], p.slope);
         }
-        smem[r * P + ch] = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) smem[r * P + ch + e] = v[e];
     }
     __syncthreads();
     const int t = t0 + tid;
