@@ -532,9 +532,9 @@ extern "C" int hificar_finalize(hificar_handle* h) {
     HIP_TRY((set_lds_attr<1, 1, 2, 2>()));
     HIP_TRY((set_lds_attr<1, 1, 1, 4>()));
     HIP_TRY((set_lds_attr<2, 1, 4, 1>()));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<2, 2, 2, 4>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 2, 2, 4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<2, 4, 1, 2>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 4, 1, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define HIFICAR_SET_ATTR(mi, wm, wn, nc) HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>()));
     HIFICAR_FOR_BF16_ALL(HIFICAR_SET_ATTR)
@@ -859,7 +859,7 @@ static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const Con
 static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, const ConvLayer* const* l2, int nbr, int nseq, int rows,
                               const PairIOB* io, float slope, hipStream_t stream) {
     const int C = l1[0]->cin;
-    const int MI = 2, WM = C == 64 ? 2 : 4;
+    const int MI = 4, WM = C == 64 ? 2 : 4;
     const int TMc = WM * MI * 32, RB = C * 4;
     PairParams pp;
     memset(&pp, 0, sizeof(pp));
@@ -892,10 +892,10 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
     pp.n_branches = nbr;
     pp.nseq = nseq;
     pp.in_bytes = (int)round_up_sz((size_t)(TMc + halo_max) * RB, 1024);
-    pp.ts_bytes = (TMc + 16) * RB;
+    pp.ts_bytes = (int)std::max<size_t>((size_t)(TMc + 16) * RB, (size_t)TMc * (C + 4) * sizeof(float));  // TS and out-buffer alias
     pp.slope_mid = slope;
     pp.trace = nullptr;
-    const size_t lds = (size_t)pp.in_bytes + pp.ts_bytes + (size_t)TMc * (C + 4) * sizeof(float);
+    const size_t lds = (size_t)pp.in_bytes + pp.ts_bytes;
     if (lds > 160 * 1024) return fail(HIFICAR_E_INVALID, "internal: pair kernel LDS too large (%zu)", lds);
     dim3 grid((unsigned)std::min(tile, h->num_cus), 1, 1);
     if (h->use_lpt && tile > (int)grid.x) {
@@ -916,8 +916,8 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
         snprintf(kname + n, sizeof(kname) - n, "|%s x%d", l1[0]->name.c_str(), nbr);
     }
     ProfScope prof(h, stream, kname, flops, bytes);
-    if (C == 64) hipLaunchKernelGGL((conv_pair_bf16x3_kernel<2, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
-    else hipLaunchKernelGGL((conv_pair_bf16x3_kernel<2, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
+    if (C == 64) hipLaunchKernelGGL((conv_pair_bf16x3_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
+    else hipLaunchKernelGGL((conv_pair_bf16x3_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(HIFICAR_E_HIP, "pair launch (%s) failed: %s", l1[0]->name.c_str(), hipGetErrorString(e));
     return HIFICAR_OK;

@@ -636,8 +636,12 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 // K chunk = C): conv1 accumulates from the DMA-staged input buffer, its epilogue applies bias + LeakyReLU + hi/lo
 // split and writes the LDS intermediate TS (zero rows outside the sequence = conv2's padding); conv2 then runs
 // its k taps over TS and drops raw accumulators for the TMc - (k-1) valid rows into the out-buffer.
-// Per tile: barrier A (input landed), barrier B (input buffer free, TS complete).  Loader waves: write_out(previous
-// tile) between A and B (hidden behind conv1), DMA(next tile) after B (hidden behind conv2).
+// The out-buffer ALIASES the intermediate (LDS is what limits the tile height, and a taller tile halves the weight
+// traffic per MFMA): four barriers per tile —
+//   A  input landed                      | loaders: write_out(previous tile) out of the shared region, hidden behind conv1
+//   F  shared region free (write_out done) -> conv1's epilogue writes TS
+//   B  TS complete, input buffer free    | loaders: DMA(next tile), hidden behind conv2
+//   C  every wave done reading TS        -> conv2's accumulators overwrite the region as the out-buffer.
 // ------------------------------------------------------------------------------------------------
 struct PairParams {
     ConvParams p1[3];      // conv1 of each branch: xs, w16, bias, L, cin (= C), ntaps, tap_step, tap_off0[0], off_min, halo, zeros
@@ -647,7 +651,7 @@ struct PairParams {
     int tile_start[4];     // first tile id of each branch; [n_branches] = total
     int tiles_per_seq[3];  // ceil(L / (TMc - (k_b - 1)))
     int in_bytes;          // LDS bytes of the input buffer (sized for the widest halo)
-    int ts_bytes;          // LDS bytes of the intermediate
+    int ts_bytes;          // LDS bytes of the region shared by the intermediate and the out-buffer
     float slope_mid;       // LeakyReLU slope between conv1 and conv2
     const int* sched_start;  // host-computed schedule, as in MultiConvParams
     const int* sched_tiles;
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
     extern __shared__ __attribute__((aligned(1024))) char smem_b[];
     const int in_bytes = mp.in_bytes;
     const int ts_off = in_bytes;
-    const int o_off = in_bytes + mp.ts_bytes;
+    const int o_off = in_bytes;  // the out-buffer aliases the intermediate (see the barrier protocol above)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -795,11 +799,13 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
             HIFICAR_STAMP(4 * it);
             __syncthreads();                 // A: input of tile `it` landed (hipcc drains vmcnt first)
             HIFICAR_STAMP(4 * it + 1);
-            if (it > 0) write_out(Tprev, ltid, 256);    // hidden behind conv1 of this tile
+            if (it > 0) write_out(Tprev, ltid, 256);  // hidden behind conv1 of this tile
             HIFICAR_STAMP(4 * it + 2);
-            __syncthreads();                 // B: conv1 done with the input buffer, TS complete
+            __syncthreads();                 // F: shared region free
+            __syncthreads();                 // B: TS complete, input buffer free
             HIFICAR_STAMP(4 * it + 3);
             if (it + 1 < my_rounds) dma_in(decode(tile_of(it + 1)));  // hidden behind conv2
+            __syncthreads();                 // C: conv2 done reading TS
             Tprev = T;
         }
         __syncthreads();                     // Z: the last tile's accumulators are in the out-buffer
@@ -916,6 +922,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         // ---- conv1 over TMc rows (time t0 - pad2 + r1) ----
         run_conv(0, wave_row0 + li + (p1.tap_off0[0] - p1.off_min), p1.tap_step, p1.ntaps, stream2(T), k2);
         HIFICAR_STAMP(6 * it + 2);
+        __syncthreads();  // F: the loaders are done with the previous tile's out-buffer (same LDS region as TS)
         {   // bias + LeakyReLU + split -> TS (zero outside the sequence: conv2's padding)
             const float slope = mp.slope_mid;
             f32x4 bias4[4];
@@ -950,6 +957,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         // ---- conv2 over TS: output row r2 reads TS rows r2 .. r2 + k2 - 1 ----
         run_conv(ts_off, wave_row0 + li, 1, k2, stream1(Tn), mp.p1[Tn.b].ntaps);
         HIFICAR_STAMP(6 * it + 5);
+        __syncthreads();  // C: every wave is done reading TS; its region becomes the out-buffer
         {
             float* O = reinterpret_cast<float*>(smem_b + o_off);
 #pragma unroll

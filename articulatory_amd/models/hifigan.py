@@ -19,6 +19,7 @@ NotImplementedError.
 import ctypes
 import logging
 import math
+import os
 
 import numpy as np
 import torch
@@ -141,7 +142,7 @@ class HiFiGANGenerator(torch.nn.Module):
         use_ph_loss=False,
         final_scale=None,  # present in e2w_hifigan_car.yaml:42; unused by the network
         extra_art=None,  # present in e2w_hifigan_car.yaml:54; only read by the WSOLA driver
-        precision="f32",
+        precision=None,  # "bf16x3" (default; or $HIFICAR_PRECISION) | "f32": conv arithmetic, see DESIGN.md §3
     ):
         super().__init__()
         # same validity checks as the reference (hifigan.py:78-80)
@@ -155,6 +156,8 @@ class HiFiGANGenerator(torch.nn.Module):
         for name, val in (("paddings", paddings), ("output_paddings", output_paddings)):
             if val is not None and any(v != "default" for v in val):
                 raise NotImplementedError(f"{name}: only None / 'default' entries are supported (as in the reference)")
+        if precision is None:
+            precision = os.environ.get("HIFICAR_PRECISION", "bf16x3")
         if precision not in _native.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_native.PRECISIONS)}")
 

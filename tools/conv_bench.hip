@@ -126,7 +126,7 @@ void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks,
     }
     pp.tile_start[nbr] = tile; pp.n_branches = nbr; pp.nseq = nseq;
     pp.in_bytes = ((TMc + halo_max) * C * 4 + 1023) / 1024 * 1024;
-    pp.ts_bytes = (TMc + 16) * C * 4;
+    pp.ts_bytes = std::max((TMc + 16) * C * 4, TMc * (C + 4) * 4);
     pp.slope_mid = 0.1f;
     const int G = std::min(tile, 256);
     unsigned long long* trace;
@@ -134,7 +134,7 @@ void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks,
     pp.trace = trace;
     auto kern = conv_pair_bf16x3_kernel<MI, WM, WN, NC16>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    const size_t lds = pp.in_bytes + pp.ts_bytes + (size_t)TMc * (C + 4) * 4;
+    const size_t lds = pp.in_bytes + pp.ts_bytes;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int it = 0; it < 3; ++it) {
@@ -160,8 +160,8 @@ void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks,
 int main() {
     {
         const int k3[3] = {11, 7, 3};
-        run_pair<2, 2, 2, 4>("PAIR stage2 C64 L1000", 64, 1000, 64, 3, k3, 1);
-        run_pair<2, 4, 1, 2>("PAIR stage3 C32 L2000", 64, 2000, 32, 3, k3, 1);
+        run_pair<4, 2, 2, 4>("PAIR stage2 C64 L1000", 64, 1000, 64, 3, k3, 1);
+        run_pair<4, 4, 1, 2>("PAIR stage3 C32 L2000", 64, 2000, 32, 3, k3, 1);
     }
     const int k3[3] = {11, 7, 3};
     run<4, 1, 4, 4>("stage0 TM128 TN128 (4,1,4)", 64, 125, 256, 3, k3, 1, false);

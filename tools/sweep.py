@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Throughput sweep over BASELINE.json's configurations: HiFi-CAR (chunk 25 / 100) and non-AR 12-dim, batch 1/8/64,
+10-s clips, for both arithmetics.  python tools/sweep.py [--precisions bf16x3 f32]"""
+import argparse
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+
+from articulatory_amd.models import HiFiGANGenerator  # noqa: E402
+from articulatory_amd.utils.synth import synth_features, synth_state_dict  # noqa: E402
+from bench import CAR_PARAMS  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--precisions", nargs="+", default=["bf16x3", "f32"])
+ap.add_argument("--batches", nargs="+", type=int, default=[1, 8, 64])
+a = ap.parse_args()
+
+
+def make(params, prec):
+    sd = synth_state_dict(params, seed=1234)
+    g = HiFiGANGenerator(**params, precision=prec)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    g.remove_weight_norm()
+    return g.eval().cuda()
+
+
+def timeit(fn, n_samples, reps=3):
+    with torch.no_grad():
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return n_samples / dt, dt
+
+
+print("| model | arithmetic | batch | samples/s | x real time | ms per 10 s batch |")
+print("|---|---|---:|---:|---:|---:|")
+T = 2000
+for prec in a.precisions:
+    car = make(dict(CAR_PARAMS), prec)
+    nonar = make(dict(CAR_PARAMS, in_channels=12, use_ar=False), prec)
+    for B in a.batches:
+        x13 = torch.from_numpy(synth_features(B, T, 13, seed=5)).permute(0, 2, 1).contiguous().cuda()
+        x12 = torch.from_numpy(synth_features(B, T, 12, seed=6)).permute(0, 2, 1).contiguous().cuda()
+        for name, fn in (("HiFi-CAR chunk 25", lambda: car.ar_synthesis(x13, 25)),
+                         ("HiFi-CAR chunk 100", lambda: car.ar_synthesis(x13, 100)),
+                         ("HiFi-GAN non-AR 12-dim", lambda: nonar(x12))):
+            sps, dt = timeit(fn, B * T * 80)
+            print(f"| {name} | {prec} | {B} | {sps / 1e6:.2f} M | {sps / 16000:.0f} | {dt * 1e3:.1f} |", flush=True)
