@@ -1004,7 +1004,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
         const double mlp_macs = cfg.use_ar ? (double)cfg.ar_input * cfg.ar_hidden + 3.0 * cfg.ar_hidden * cfg.ar_hidden +
                                                  (double)cfg.ar_hidden * cfg.ar_output : 0.0;
         ProfScope prof(h, stream, "front_kernel", 2.0 * B * mlp_macs, 4.0 * B * (mlp_macs + (double)T * (h->cf + h->cin_pad)));
-        hipLaunchKernelGGL(front_kernel, dim3(B), dim3(256), 0, stream, fp);
+        hipLaunchKernelGGL(front_kernel, dim3(B), dim3(512), 0, stream, fp);
     }
     HIP_TRY(hipGetLastError());
 

@@ -1053,27 +1053,28 @@ struct FrontParams {
     const float* bs[5];
 };
 
-__global__ __launch_bounds__(256) void front_kernel(const FrontParams p) {
+__global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
+    constexpr int NW = 8;  // waves = K slices
     __shared__ __attribute__((aligned(16))) float act[2][1024];
-    __shared__ __attribute__((aligned(16))) float part[4][1024];
+    __shared__ __attribute__((aligned(16))) float part[NW][1024];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int ks = tid >> 6;  // wave index = K slice: each wave reduces a quarter of the input dimension
+    const int ks = tid >> 6;  // wave index = K slice: each wave reduces an eighth of the input dimension
     int cur = 0;
     if (p.use_ar) {
-        for (int i = tid; i < p.ar_input; i += 256) act[0][i] = p.prev ? p.prev[(size_t)b * p.prev_bstride + i] : 0.f;
+        for (int i = tid; i < p.ar_input; i += 512) act[0][i] = p.prev ? p.prev[(size_t)b * p.prev_bstride + i] : 0.f;
         __syncthreads();
         int din = p.ar_input;
         for (int layer = 0; layer < 5; ++layer) {
             const int dout = layer == 4 ? p.ar_output : p.ar_hidden;
             const float* wt = p.wt[layer];
             const float* x = act[cur];
-            const int i0 = (din * ks) / 4, i1 = (din * (ks + 1)) / 4;
+            const int i0 = (din * ks) / NW, i1 = (din * (ks + 1)) / NW;
             for (int j4 = lane * 4; j4 < dout; j4 += 256) {  // dims are multiples of 4 (checked at create)
                 f32x4 s = {0.f, 0.f, 0.f, 0.f};
                 int i = i0;
-                for (; i + 8 <= i1; i += 8) {  // 8 independent 16-byte loads in flight per lane
+                for (; i + 8 <= i1; i += 8) {  // 8 independent 16-byte loads in flight per lane, 64 KB per CU
                     f32x4 w[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(wt + (size_t)(i + q) * dout + j4);
@@ -1093,8 +1094,10 @@ __global__ __launch_bounds__(256) void front_kernel(const FrontParams p) {
                 *reinterpret_cast<f32x4*>(&part[ks][j4]) = s;
             }
             __syncthreads();
-            for (int j = tid; j < dout; j += 256) {
-                const float v = ((part[0][j] + part[1][j]) + (part[2][j] + part[3][j])) + p.bs[layer][j];
+            for (int j = tid; j < dout; j += 512) {
+                float v = p.bs[layer][j];
+#pragma unroll
+                for (int q = 0; q < NW; ++q) v += part[q][j];
                 act[cur ^ 1][j] = layer < 4 ? lrelu(v, 0.1f) : v;
             }
             __syncthreads();
@@ -1105,7 +1108,7 @@ __global__ __launch_bounds__(256) void front_kernel(const FrontParams p) {
     // act[cur][0:ar_output] now holds the AR features
     const float* feats = act[cur];
     const int n = p.T * p.cin_pad;
-    for (int idx = tid; idx < n; idx += 256) {
+    for (int idx = tid; idx < n; idx += 512) {
         const int t = idx / p.cin_pad;
         const int ch = idx - t * p.cin_pad;
         float v = 0.f;

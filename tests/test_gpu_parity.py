@@ -282,3 +282,14 @@ def test_fused_pair_kernel_matches_layer_by_layer(monkeypatch):
         ref = O.generator_forward(w, params, c.cpu(), ar.cpu())
     assert rel_err(outs["1"].numpy(), outs["0"].numpy()) < TOLS["bf16x3"]
     assert rel_err(outs["1"].numpy(), ref.numpy()) < TOLS["bf16x3"]
+
+
+def test_repeated_runs_are_bit_identical(car):
+    """Race screen for the LDS ring / out-buffer hand-offs of the persistent kernels: 12 back-to-back syntheses of the
+    same batch (different tile timing every time) must give bit-identical waveforms."""
+    g, _ = car
+    feats = torch.from_numpy(synth_features(24, 100, 13, seed=99)).permute(0, 2, 1).contiguous().cuda()
+    with torch.no_grad():
+        first = g.ar_synthesis(feats, 25).clone()
+        for _ in range(11):
+            assert torch.equal(g.ar_synthesis(feats, 25), first)
