@@ -340,6 +340,10 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
 extern "C" void hificar_destroy(hificar_handle* h) {
     if (!h) return;
     for (void* p : h->allocs) (void)hipFree(p);
+    for (auto& kv : h->scheds) {
+        (void)hipFree(kv.second.d_start);
+        (void)hipFree(kv.second.d_tiles);
+    }
     delete h;
 }
 
@@ -685,6 +689,16 @@ static int get_schedule(hificar_handle* h, const std::string& key, const std::ve
                         const int** d_start, const int** d_tiles) {
     auto it = h->scheds.find(key);
     if (it == h->scheds.end()) {
+        if (h->scheds.size() >= 1024) {
+            // many distinct launch shapes (e.g. non-AR inference over utterances of every length): drop the cache.
+            // Kernels still in flight may be reading old schedules, so drain the device first (rare, off the hot path).
+            HIP_TRY(hipDeviceSynchronize());
+            for (auto& kv : h->scheds) {
+                (void)hipFree(kv.second.d_start);
+                (void)hipFree(kv.second.d_tiles);
+            }
+            h->scheds.clear();
+        }
         const int n = (int)costs.size();
         std::vector<int> order(n);
         for (int i = 0; i < n; ++i) order[i] = i;
@@ -715,10 +729,8 @@ static int get_schedule(hificar_handle* h, const std::string& key, const std::ve
         hificar_handle::Sched sc;
         void* p = nullptr;
         HIP_TRY(hipMalloc(&p, start.size() * sizeof(int)));
-        h->allocs.push_back(p);
         sc.d_start = static_cast<int*>(p);
         HIP_TRY(hipMalloc(&p, std::max<size_t>(tiles.size(), 1) * sizeof(int)));
-        h->allocs.push_back(p);
         sc.d_tiles = static_cast<int*>(p);
         HIP_TRY(hipMemcpy(sc.d_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(sc.d_tiles, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
