@@ -1,13 +1,27 @@
-"""Autoregressive chunk driver — counterpart of ``ar_loop`` in the reference's
-articulatory/bin/decode.py:31-83 (non-WSOLA, a2w branch).
+#!/usr/bin/env python3
+"""Decoding drivers — counterparts of the reference's articulatory/bin/decode.py.
 
-The reference loop is batch-1 Python: one generator forward per chunk with a host round trip for
-``prev_samples``.  Here the whole loop (all chunks, PastFCEncoder included, feedback taken straight
-from the output buffer) is enqueued on the device by one C-ABI call; ``ar_loop_batch`` runs B
-equal-length utterances side by side, which the reference cannot.
+* ``ar_loop`` (reference decode.py:31-100): the chunked autoregressive driver.  The reference loop is
+  batch-1 Python with one generator forward and one host round trip of ``prev_samples`` per chunk; here
+  the whole non-WSOLA loop (all chunks, PastFCEncoder included, feedback taken straight from the output
+  buffer) is enqueued on the device by ONE C-ABI call.  ``ar_loop_batch`` runs B equal-length utterances
+  side by side, which the reference cannot.  The WSOLA variant (``do_wsola``: half-overlapping chunks,
+  decode.py:84-100) is a per-chunk loop over ``model.forward`` as in the reference, since each chunk's
+  context comes from the *middle* of the previous chunk.
+* ``main`` (reference decode.py:103-358, console script ``articulatory-decode``): same flags, config
+  merge, scp / dump-dir inputs (``.npy`` features), ``--normalize-before``, PCM_16 ``<utt>_gen.wav``
+  outputs and RTF report, for the a2w dataset modes of the HiFi-GAN / HiFi-CAR generator.
 """
 
+import argparse
+import glob
+import logging
+import os
+import time
+
+import numpy as np
 import torch
+import yaml
 
 
 def _chunk_frames(config, params_key="generator_params"):
@@ -17,19 +31,158 @@ def _chunk_frames(config, params_key="generator_params"):
 
 
 def ar_loop(model, x, config, do_wsola=False, modality=None, generator2=False):
-    """x: (art_len, num_feats) tensor on the model's device -> (audio_len,) tensor."""
-    if do_wsola or modality is not None or generator2:
-        raise NotImplementedError("ar_loop: WSOLA / multi-modality / generator2 variants are not built (SURVEY.md §8 f3)")
+    """x: (art_len, num_feats) tensor on the model's device -> (audio_len,) tensor
+    (``do_wsola``: -> (list of chunk waveforms, list of chunk inputs), as the reference returns)."""
+    if modality is not None or generator2:
+        raise NotImplementedError("ar_loop: multi-modality / generator2 variants are not built (SURVEY.md §8 f3)")
     if config.get("dataset_mode", "a2w") == "w2a":
         raise NotImplementedError("ar_loop: w2a (inversion) models are out of scope")
-    in_chunk_len, _ = _chunk_frames(config)
+    in_chunk_len, past_out_len = _chunk_frames(config)
     if x.dim() == 1:
         x = x.unsqueeze(1)
-    c = x.transpose(0, 1).unsqueeze(0)  # (1, num_feats, art_len)
-    return model.ar_synthesis(c, in_chunk_len)[0]
+    if not do_wsola:
+        c = x.transpose(0, 1).unsqueeze(0)  # (1, num_feats, art_len)
+        return model.ar_synthesis(c, in_chunk_len)[0]
+
+    # decode.py:84-100: chunks start every in_chunk_len/2 frames and are in_chunk_len (+ extra_art) long
+    extra_art = config["generator_params"]["extra_art"]
+    audio_chunk_len = config["batch_max_steps"]
+    assert in_chunk_len % 2 == 0
+    ins = [x[i:i + in_chunk_len + int(extra_art)] for i in range(0, len(x), int(in_chunk_len / 2))]
+    prev_samples = torch.zeros((1, 1, past_out_len), dtype=x.dtype, device=x.device)
+    outs = []
+    for art_i, art in enumerate(ins):
+        signal = model(art.unsqueeze(0).permute(0, 2, 1), ar=prev_samples)  # (1, 1, audio_chunk_length)
+        outs.append(signal[0][0])
+        if art_i < len(ins) - 1:
+            prev_samples = signal[:, :, int(audio_chunk_len / 2) - past_out_len:int(audio_chunk_len / 2)]
+            assert prev_samples.shape[2] == past_out_len
+    return outs, ins
 
 
 def ar_loop_batch(model, xs, config):
     """xs: (B, art_len, num_feats) equal-length utterances -> (B, audio_len)."""
     in_chunk_len, _ = _chunk_frames(config)
     return model.ar_synthesis(xs.permute(0, 2, 1), in_chunk_len)
+
+
+# ----------------------------------------------------------------------------------------------
+# articulatory-decode counterpart
+# ----------------------------------------------------------------------------------------------
+_A2W_MODES = ("default", "m2w", "a2w", "a2w_pcd")
+
+
+def iter_features(feats_scp=None, dumpdir=None, fmt="npy"):
+    """(utt_id, (T, C) ndarray) pairs from a kaldi-style ``utt_id path.npy`` scp (the reference's NpyScpLoader,
+    utils/utils.py:240-291) or from a dump dir of ``<utt_id>-feats.npy`` files (decode.py:207-222)."""
+    if (feats_scp is not None) == (dumpdir is not None):
+        raise ValueError("Please specify either --dumpdir or --feats-scp.")
+    if feats_scp is not None:
+        with open(feats_scp) as f:
+            for line in f:
+                parts = line.strip().split()
+                if len(parts) < 2:
+                    continue
+                if not parts[1].endswith(".npy"):
+                    raise ValueError("Not supported feats.scp type (only 'utt_id /path/to/utt_id.npy' entries are read here).")
+                yield parts[0], np.load(parts[1])
+    else:
+        if fmt != "npy":
+            raise ValueError("Support only npy format here (h5py is not available in this image).")
+        for path in sorted(glob.glob(os.path.join(dumpdir, "**", "*-feats.npy"), recursive=True)):
+            yield os.path.basename(path)[: -len("-feats.npy")], np.load(path)
+
+
+def get_parser():
+    parser = argparse.ArgumentParser(description="Decode dumped features with trained generator.")
+    parser.add_argument("--feats-scp", "--scp", default=None, type=str,
+                        help="kaldi-style feats.scp file. you need to specify either feats-scp or dumpdir.")
+    parser.add_argument("--dumpdir", default=None, type=str,
+                        help="directory including feature files. you need to specify either feats-scp or dumpdir.")
+    parser.add_argument("--outdir", type=str, required=True, help="directory to save generated speech.")
+    parser.add_argument("--checkpoint", type=str, required=True, help="checkpoint file to be loaded.")
+    parser.add_argument("--config", default=None, type=str,
+                        help="yaml format configuration file. if not explicitly provided, "
+                             "it will be searched in the checkpoint directory. (default=None)")
+    parser.add_argument("--normalize-before", default=False, action="store_true",
+                        help="whether to perform feature normalization before input to the model.")
+    parser.add_argument("--verbose", type=int, default=1, help="logging level. higher is more logging. (default=1)")
+    return parser
+
+
+def decode_dataset(model, items, config, device, outdir, normalize_before=False, writer=None):
+    """The generation loop of decode.py:292-351 for the a2w modes.  Returns (n_utterances, average RTF)."""
+    from articulatory_amd.bin.predict_wav import write_wav
+
+    writer = writer or write_wav
+    use_ar = bool(config["generator_params"].get("use_ar", False))
+    do_wsola = bool(config.get("wsola", False))
+    total_rtf, n = 0.0, 0
+    with torch.no_grad():
+        for utt_id, c in items:
+            c = torch.tensor(c, dtype=torch.float).to(device)
+            start = time.time()
+            if use_ar:
+                y = ar_loop(model, c, config, do_wsola=do_wsola)
+            else:
+                y = model.inference(c, normalize_before=normalize_before).view(-1)
+            if not do_wsola:
+                y = y.cpu().numpy()  # device -> host: also the synchronisation point the RTF needs
+                rtf = (time.time() - start) / (len(y) / config["sampling_rate"])
+                total_rtf += rtf
+                writer(os.path.join(outdir, f"{utt_id}_gen.wav"), y, config["sampling_rate"])
+            else:
+                signals, arts = y
+                for cyi, cy in enumerate(signals):
+                    cy = cy.cpu().numpy()
+                    rtf = (time.time() - start) / (len(cy) / config["sampling_rate"])
+                    total_rtf += rtf
+                    writer(os.path.join(outdir, "%s_%d_gen.wav" % (utt_id, cyi)), cy, config["sampling_rate"])
+                    np.save(os.path.join(outdir, "%s_%d.npy" % (utt_id, cyi)), arts[cyi].cpu().numpy())
+            n += 1
+    return n, (total_rtf / n if n else float("nan"))
+
+
+def main(argv=None):
+    from articulatory_amd.utils import load_model
+
+    args = get_parser().parse_args(argv)
+    level = logging.DEBUG if args.verbose > 1 else logging.INFO if args.verbose > 0 else logging.WARN
+    logging.basicConfig(level=level, format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    if args.verbose <= 0:
+        logging.warning("Skip DEBUG/INFO messages")
+    if not os.path.exists(args.outdir):
+        os.makedirs(args.outdir)
+    if args.config is None:
+        args.config = os.path.join(os.path.dirname(args.checkpoint), "config.yml")
+    with open(args.config) as f:
+        config = yaml.load(f, Loader=yaml.Loader)
+    config.update(vars(args))
+    if (args.feats_scp is not None and args.dumpdir is not None) or (args.feats_scp is None and args.dumpdir is None):
+        raise ValueError("Please specify either --dumpdir or --feats-scp.")
+    dataset_mode = config.setdefault("dataset_mode", "default")
+    if dataset_mode not in _A2W_MODES:
+        raise NotImplementedError(f"dataset_mode {dataset_mode!r}: only the articulatory/mel -> waveform modes "
+                                  f"{_A2W_MODES} are built (SURVEY.md §8 f3)")
+    if config.get("transform") or config.get("input_transform"):
+        raise NotImplementedError("feature transforms are not built")
+    items = list(iter_features(args.feats_scp, args.dumpdir, config.get("format", "npy")))
+    logging.info(f"The number of features to be decoded = {len(items)}.")
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("decode: no GPU visible; this package has no CPU synthesis path")
+    device = torch.device("cuda")
+    model = load_model(args.checkpoint, config)
+    logging.info(f"Loaded model parameters from {args.checkpoint}.")
+    if args.normalize_before:
+        assert hasattr(model, "mean"), "Feature stats are not registered."
+        assert hasattr(model, "scale"), "Feature stats are not registered."
+    model.remove_weight_norm()
+    model = model.eval().to(device)
+    print(sum(p.numel() for p in model.parameters() if p.requires_grad))
+    n, rtf = decode_dataset(model, items, config, device, config["outdir"], normalize_before=args.normalize_before)
+    logging.info(f"Finished generation of {n} utterances (RTF = {rtf:.03f}).")
+
+
+if __name__ == "__main__":
+    main()

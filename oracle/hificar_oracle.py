@@ -167,6 +167,25 @@ def ar_loop(w, params, x, batch_max_steps, hop_size):
     return torch.cat(outs, dim=0)
 
 
+def ar_loop_wsola(w, params, x, batch_max_steps, hop_size, extra_art=0):
+    """decode.py:84-100 (do_wsola branch): half-overlapping chunks, each conditioned on the ar_input samples that end
+    at the middle of the previous chunk.  Returns (list of chunk waveforms, list of chunk inputs)."""
+    p = _cfg(params)
+    in_chunk = int(batch_max_steps / hop_size)
+    past = p["ar_input"]
+    assert in_chunk % 2 == 0
+    ins = [x[i:i + in_chunk + int(extra_art)] for i in range(0, len(x), int(in_chunk / 2))]
+    prev = torch.zeros((1, 1, past), dtype=x.dtype)
+    outs = []
+    for art_i, art in enumerate(ins):
+        signal = generator_forward(w, p, art.unsqueeze(0).permute(0, 2, 1), ar=prev)
+        outs.append(signal[0][0])
+        if art_i < len(ins) - 1:
+            prev = signal[:, :, int(batch_max_steps / 2) - past:int(batch_max_steps / 2)]
+            assert prev.shape[2] == past
+    return outs, ins
+
+
 def _shift_prev(prev, cout, in_chunk):
     # decode.py:79-81 (only reached when the chunk's audio is shorter than ar_input)
     prev = prev.clone()

@@ -165,6 +165,15 @@ def main():
         res[f"out_bms{bms}"] = yy.numpy()
     np.savez_compressed(os.path.join(outdir, "gold_arloop.npz"), **res)
 
+    # ---- (4b) the WSOLA driver variant (decode.py:84-100): half-overlapping chunks of 100 frames -------------
+    conf = dict(cfg, batch_max_steps=8000)
+    conf["generator_params"] = dict(conf["generator_params"], extra_art=False)
+    with torch.no_grad():
+        outs, ins = ref_ar_loop(gfull, torch.from_numpy(x), conf, do_wsola=True)
+    np.savez_compressed(os.path.join(outdir, "gold_arloop_wsola.npz"), x=x,
+                        n=np.array(len(outs)), **{f"out{i}": o.numpy() for i, o in enumerate(outs)},
+                        **{f"in_len{i}": np.array(len(a)) for i, a in enumerate(ins)})
+
     # ---- (3) non-AR 12-dim model through .inference() -------------------------------------------
     nonar_params = dict(full_params, in_channels=12, use_ar=False)
     gn, _ = build(nonar_params)

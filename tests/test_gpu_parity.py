@@ -293,3 +293,16 @@ def test_repeated_runs_are_bit_identical(car):
         first = g.ar_synthesis(feats, 25).clone()
         for _ in range(11):
             assert torch.equal(g.ar_synthesis(feats, 25), first)
+
+
+def test_golden_ar_loop_wsola(car):
+    """The WSOLA driver variant (decode.py:84-100) through model.forward, against the reference's own chunks."""
+    from articulatory_amd.bin.decode import ar_loop
+    g, _ = car
+    gold = np.load(os.path.join(GOLDEN, "gold_arloop_wsola.npz"))
+    config = dict(batch_max_steps=8000, hop_size=80, generator_params=dict(E2W_PARAMS, extra_art=False), dataset_mode="a2w")
+    with torch.no_grad():
+        outs, ins = ar_loop(g, torch.from_numpy(gold["x"]).cuda(), config, do_wsola=True)
+    assert len(outs) == int(gold["n"])
+    for i, o in enumerate(outs):
+        assert rel_err(o.cpu().numpy(), gold[f"out{i}"]) < 2 * g.tol, i

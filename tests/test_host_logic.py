@@ -134,6 +134,9 @@ class _OracleBackedModel:
         self.calls.append((tuple(c.shape), chunk_frames))
         return O.ar_loop_batched(self.w, self.params, c.permute(0, 2, 1), chunk_frames * 80, 80)
 
+    def __call__(self, c, ar=None):
+        return O.generator_forward(self.w, self.params, c, ar)
+
 
 def test_predict_wav_plumbing_matches_reference_pin(tmp_path):
     """configs[0]: one (700, 13) utterance through the predict_wav counterpart; the waveform handed to the
@@ -186,7 +189,47 @@ def test_predict_wav_batches_equal_lengths(tmp_path):
 
 def test_ar_loop_rejects_unbuilt_variants():
     with pytest.raises(NotImplementedError):
-        D.ar_loop(None, torch.zeros(10, 13), dict(batch_max_steps=2000, hop_size=80, generator_params=E2W_PARAMS), do_wsola=True)
+        D.ar_loop(None, torch.zeros(10, 13), dict(batch_max_steps=2000, hop_size=80, generator_params=E2W_PARAMS), modality=0)
     with pytest.raises(NotImplementedError):
         D.ar_loop(None, torch.zeros(10, 13), dict(batch_max_steps=2000, hop_size=80, generator_params=E2W_PARAMS,
                                                    dataset_mode="w2a"))
+
+
+def test_decode_cli_plumbing(tmp_path):
+    """articulatory-decode counterpart: scp and dump-dir inputs, <utt>_gen.wav naming, RTF; WSOLA chunk files."""
+    import wave
+    gold = np.load(os.path.join(GOLDEN, "gold_arloop.npz"))
+    sd = synth_state_dict(E2W_PARAMS, seed=1234)
+    model = _OracleBackedModel(E2W_PARAMS, sd)
+    dump = tmp_path / "dump"
+    dump.mkdir()
+    np.save(dump / "uttA-feats.npy", gold["x"])
+    scp = tmp_path / "feats.scp"
+    scp.write_text(f"uttA {dump / 'uttA-feats.npy'}\n")
+    assert [u for u, _ in D.iter_features(dumpdir=str(dump))] == ["uttA"]
+    assert [u for u, _ in D.iter_features(feats_scp=str(scp))] == ["uttA"]
+    with pytest.raises(ValueError, match="either"):
+        list(D.iter_features())
+    config = dict(generator_params=dict(E2W_PARAMS, extra_art=False), sampling_rate=16000, hop_size=80,
+                  batch_max_steps=2000, dataset_mode="a2w")
+    out = tmp_path / "out"
+    out.mkdir()
+    got = {}
+    n, rtf = D.decode_dataset(model, D.iter_features(feats_scp=str(scp)), config, "cpu", str(out),
+                              writer=lambda p, y, sr: (got.__setitem__(os.path.basename(p), y), PW.write_wav(p, y, sr)))
+    assert n == 1 and rtf > 0
+    assert rel_err(got["uttA_gen.wav"], gold["out_bms2000"]) < 2e-5
+    with wave.open(str(out / "uttA_gen.wav")) as f:
+        assert f.getnframes() == 20800 and f.getsampwidth() == 2
+    # WSOLA variant: half-overlapping 100-frame chunks, one wav + one input .npy per chunk
+    gw = np.load(os.path.join(GOLDEN, "gold_arloop_wsola.npz"))
+    config_w = dict(config, batch_max_steps=8000, wsola=True)
+    got.clear()
+    D.decode_dataset(model, D.iter_features(feats_scp=str(scp)), config_w, "cpu", str(out),
+                     writer=lambda p, y, sr: got.__setitem__(os.path.basename(p), y))
+    assert len(got) == int(gw["n"])
+    for i in range(int(gw["n"])):
+        assert rel_err(got[f"uttA_{i}_gen.wav"], gw[f"out{i}"]) < 2e-5
+        assert np.load(out / f"uttA_{i}.npy").shape[0] == int(gw[f"in_len{i}"])
+    with pytest.raises(AssertionError):  # odd chunk length: the reference asserts too (decode.py:87)
+        D.ar_loop(model, torch.from_numpy(gold["x"]), dict(config, wsola=True), do_wsola=True)

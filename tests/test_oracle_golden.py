@@ -162,3 +162,14 @@ def test_predict_wav_pin(full_w):
         y = O.ar_loop(full_w, E2W_PARAMS, torch.from_numpy(g["x"]), 8000, 80)
     assert y.shape == (56000,)
     assert rel_err(y.numpy(), g["out"]) < 2e-5
+
+
+def test_ar_loop_wsola_variant(full_w):
+    g = np.load(os.path.join(GOLDEN, "gold_arloop_wsola.npz"))
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        outs, ins = O.ar_loop_wsola(full_w, E2W_PARAMS, x, 8000, 80)
+    assert len(outs) == int(g["n"]) == 6
+    for i, (o, a) in enumerate(zip(outs, ins)):
+        assert len(a) == int(g[f"in_len{i}"])
+        assert rel_err(o.numpy(), g[f"out{i}"]) < 2e-5, i
