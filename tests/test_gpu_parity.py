@@ -306,3 +306,20 @@ def test_golden_ar_loop_wsola(car):
     assert len(outs) == int(gold["n"])
     for i, o in enumerate(outs):
         assert rel_err(o.cpu().numpy(), gold[f"out{i}"]) < 2 * g.tol, i
+
+
+def test_inference_normalize_before(prec, tmp_path):
+    """register_stats + inference(normalize_before=True) (hifigan.py:280-314) on a non-AR generator."""
+    params = dict(E2W_PARAMS, in_channels=12, use_ar=False, channels=128, upsample_scales=[4, 2], upsample_kernel_sizes=[8, 4])
+    g, w = make(params, prec, seed=7)
+    mean = np.linspace(-0.5, 0.5, 12).astype(np.float32)
+    scale = np.linspace(0.5, 2.0, 12).astype(np.float32)
+    np.save(tmp_path / "stats.npy", np.stack([mean, scale]))
+    g.register_stats(str(tmp_path / "stats.npy"))
+    g = g.to("cuda:0")
+    x = synth_features(1, 90, 12, seed=8)[0]
+    with torch.no_grad():
+        y = g.inference(x, normalize_before=True).cpu()
+        y_ref = O.inference(w, params, x, torch.from_numpy(mean), torch.from_numpy(scale))
+    assert y.shape == y_ref.shape == (720, 1)
+    assert rel_err(y.numpy(), y_ref.numpy()) < TOLS[prec]
