@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--chunk-frames", type=int, default=25, help="batch_max_steps // hop_size (e2w_hifigan_car.yaml: 2000/80)")
     ap.add_argument("--precision", default=os.environ.get("HIFICAR_PRECISION", "bf16x3"), choices=["f32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-check", action="store_true",
+                    help="skip the extra leg that re-runs the batch with the exact-fp32 arithmetic (N=1 only)")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -202,6 +204,27 @@ def main():
         }
     if use_dist:
         dist.barrier()
+
+    if rank == 0 and world == 1 and args.precision != "f32" and not args.no_exact_check:
+        # Same batch through the exact-fp32 MFMA arithmetic of the same library: its throughput, and how far the
+        # default (split-bf16) arithmetic is from it on this very input — the parity figure that goes with `value`.
+        with torch.no_grad():
+            y_fast = g.ar_synthesis(feats, args.chunk_frames)
+            g.set_precision("f32")
+            y_exact = g.ar_synthesis(feats, args.chunk_frames)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                g.ar_synthesis(feats, args.chunk_frames)
+            torch.cuda.synchronize()
+            dte = (time.perf_counter() - t0) / 2
+            g.set_precision(args.precision)
+        out["exact_f32"] = {
+            "value": round(n_samples / dte, 1), "unit": "samples/s", "x_realtime": round(n_samples / dte / SAMPLING_RATE, 1),
+            "algorithmic_tflops": round(2.0 * macs_step / dte / 1e12, 2),
+            "max_rel_diff_of_default_arithmetic": float((y_fast - y_exact).abs().max() / y_exact.abs().max()),
+            "tolerance": 1e-3,
+        }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, sd, args.chunk_frames, seed=20260929)
