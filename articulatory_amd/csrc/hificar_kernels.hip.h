@@ -1,17 +1,22 @@
 // HIP kernels for the HiFi-GAN / HiFi-CAR generator forward pass on gfx950 (CDNA4, wave64).
 //
-// Internal activation layout is CHANNELS-LAST: (sequence, time, channel) fp32 with the channel
-// axis contiguous.  The reference's (B, C, T) layout exists only at the C-ABI boundary (feature
-// input, waveform output), which `front_kernel` / `output_conv_kernel` convert on the fly.
-// Channels-last makes every halo a whole-row affair (zero rows outside [0, L) reproduce the
-// reference's per-conv zero padding exactly), keeps global loads 16-byte aligned for any tap
-// offset, and puts the GEMM reduction axis (input channels) contiguous for MFMA operand reads.
+// Internal activation layout is CHANNELS-LAST: (sequence, time, channel) with the channel axis contiguous.
+// The reference's (B, C, T) layout exists only at the C-ABI boundary (feature input, waveform output), which
+// `front_kernel` / `output_conv_kernel` convert on the fly.  Channels-last makes every halo a whole-row affair
+// (zero rows outside [0, L) reproduce the reference's per-conv zero padding exactly), keeps global accesses
+// 16-byte aligned for any tap offset, and puts the GEMM reduction axis (input channels) contiguous for MFMA
+// operand fragments.
 //
-// Every Conv1d and every ConvTranspose1d of the generator runs through ONE implicit-GEMM kernel
-// family (`conv_mfma_f32_kernel`):  D[t, co] = sum_{tap} sum_{ci} act(X)[t + off(tap), ci] * W[tap][ci][co]
-// with M = time, N = output channels, K = taps x input channels.  A ConvTranspose1d with K = 2*stride
-// is the same contraction with N = stride*Cout "virtual" channels (phase-major) and per-phase tap
-// lists, because out[(q*s + r), co] in channels-last memory IS row q, column r*Cout + co.
+// Every Conv1d and every ConvTranspose1d of the generator is the same implicit GEMM
+//     D[t, co] = sum_{tap} sum_{ci} act(X)[t + off(tap), ci] * W[tap][ci][co]        (K = taps x input channels)
+// A ConvTranspose1d with K = 2*stride is that contraction with N = stride*Cout "virtual" channels (phase-major) and
+// per-phase tap lists, because out[(q*s + r), co] in channels-last memory IS row q, column r*Cout + co.
+//
+// Two arithmetics:
+//   conv_mfma_f32_kernel       exact fp32 products (v_mfma_f32_32x32x2_f32); fp32 rows; activation applied while staging
+//   conv_bf16x3_kernel         fp32 operands split hi+lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per K slab; "split rows";
+//   conv_pair_bf16x3_kernel    persistent, wave-specialised, LDS-DMA staged; the pair kernel fuses conv1 -> conv2 at C <= 64
+// plus front_kernel (PastFCEncoder + input assembly), mrf_split_kernel (MRF mean + split), output_conv_kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,7 +32,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kMaxPhase = 8;
 constexpr int kMaxTaps = 16;
 
-// The A operand (activations) is produced while staging into LDS from `nin` inputs:
+// f32 path: the activation operand is produced while staging into LDS from `nin` inputs:
 //   nin = 1: x0;  nin = 2: (x0 + x1) / 2;  nin = 3: ((x0 + x1) + x2) / 3
 // (the MRF mean `cs / num_blocks` of reference hifigan.py:226-230, summed in the reference's order).
 
@@ -36,7 +41,7 @@ struct ConvParams {
     const float* x1;
     const float* x2;
     const float* w;     // f32 path: packed [n_block][tap][ci][NB]
-    const bf16x8* w16;  // bf16x3 path: packed MFMA B fragments [n_block32][chunk][tap][c16][hi|lo][lane], 16 B each
+    const bf16x8* w16;  // bf16x3 path: packed MFMA weight fragments [n_block32][chunk][tap][c16][hi|lo][lane], 16 B each
     const float* bias;  // [cout_total] (never null; zeros when the layer has no bias)
     const float* res;   // residual, same layout as y, or null
     float* y;           // fp32 output (bf16x3 path: may be null when only the split copy is consumed)
