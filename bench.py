@@ -42,25 +42,43 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}  # /opt/skills/guides/MI355X_MICR
 
 
 def cpu_baseline(params, sd, chunk_frames, seed):
-    """CPU oracle (torch fp32 restatement, pinned to the reference's golden vectors) on a bounded sample."""
+    """CPU oracle (torch fp32 restatement, pinned to the reference's golden vectors) on a bounded sample.
+
+    The reference recipe runs single-threaded (egs/ema/voc1/path.sh:13, OMP_NUM_THREADS=1); torch's intra-op
+    parallelism helps these small convolutions only up to a point (using every core of a big host is ~10x SLOWER
+    than 16 threads), so a few thread counts are timed on a small sample and the best one is re-timed on a larger one.
+    """
     import torch
 
     from articulatory_amd.utils.synth import synth_features
     from oracle import hificar_oracle as O
 
-    cores = torch.get_num_threads()
+    all_cores = torch.get_num_threads()
     w = O.fold_weight_norm(sd)
-    B, T = 8, 250  # 8 utterances x 1.25 s = 10 chunks of 25 frames each
-    x = torch.from_numpy(synth_features(B, T, 13, seed=seed))
-    with torch.no_grad():
-        O.ar_loop_batched(w, params, x[:, :chunk_frames], chunk_frames * HOP, HOP)  # warm-up: one chunk
-        t0 = time.perf_counter()
-        y = O.ar_loop_batched(w, params, x, chunk_frames * HOP, HOP)
-        dt = time.perf_counter() - t0
+
+    def run(B, T, threads):
+        torch.set_num_threads(threads)
+        x = torch.from_numpy(synth_features(B, T, 13, seed=seed))
+        with torch.no_grad():
+            O.ar_loop_batched(w, params, x[:, :chunk_frames], chunk_frames * HOP, HOP)  # warm-up: one chunk
+            t0 = time.perf_counter()
+            y = O.ar_loop_batched(w, params, x, chunk_frames * HOP, HOP)
+            dt = time.perf_counter() - t0
+        return y.numel() / dt, dt
+
+    by_threads = {}
+    for nt in sorted({1, 8, 16, 32, all_cores}):
+        if nt <= all_cores:
+            by_threads[nt] = run(8, 5 * chunk_frames, nt)[0]
+    best = max(by_threads, key=by_threads.get)
+    B, T = 64, 20 * chunk_frames  # 64 utterances x 2.5 s = 20 chunks of 25 frames each (~5 s of CPU work)
+    value, dt = run(B, T, best)
+    torch.set_num_threads(all_cores)
     return {
-        "value": round(y.numel() / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+        "value": round(value, 1), "unit": "samples/s", "cores": best, "kind": "port",
         "sample": f"oracle.ar_loop_batched, batch {B} x {T} frames ({T // chunk_frames} chunks of {chunk_frames}), "
-                  f"torch {torch.__version__} CPU fp32, {cores} threads, {dt:.1f} s",
+                  f"torch {torch.__version__} CPU fp32, best of the thread counts tried = {best} of {all_cores} host threads, {dt:.1f} s",
+        "by_threads": {str(k): round(v, 1) for k, v in by_threads.items()},
     }
 
 
