@@ -462,6 +462,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     }
 
     // ---------------- MFMA role ----------------
+    __builtin_amdgcn_s_setprio(1);  // the MFMA wave outranks the loader wave sharing its SIMD for issue slots
     f32x16 acc[MI];
     // weight fragments: bq = current tap, bn = next tap; loads run two taps ahead of their use
     bf16x8 bq[NC16][2], bn[NC16][2];
@@ -819,6 +820,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
     }
 
     // ---------------- MFMA role ----------------
+    __builtin_amdgcn_s_setprio(1);  // the MFMA wave outranks the loader wave sharing its SIMD for issue slots
     f32x16 acc[MI];
     bf16x8 bq[NC16][2], bn[NC16][2];
     const bf16x8* wp = nullptr;
