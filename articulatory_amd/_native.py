@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhificar.so")
+# HIFICAR_LIB: developer override (A/B runs of two builds of the same ABI inside one gpurun call)
+LIB_PATH = os.environ.get("HIFICAR_LIB") or os.path.join(_HERE, "libhificar.so")
 
 MAX_STAGES = 8
 MAX_BLOCKS = 4

@@ -433,8 +433,9 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 const char* src = p.zeros;
                 if (r < R && t >= 0 && t < p.L)
                     src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
+                // aux = 2: non-temporal — an activation row is staged by one or two CUs only (+2.3 % end to end)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
             }
         };
         // items are numbered j = 0.. over (tile, chunk); the DMA of item j+1 runs while the MFMA waves compute item j
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
                 if (r < R && t >= 0 && t < p.L)
                     src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? sl * 16 : p.cin * 2 + (sl - SPR / 2) * 16);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(smem_b + i * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(smem_b + i * 1024), 16, 0, 2);
             }
         };
         Tile Tprev;
