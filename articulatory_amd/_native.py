@@ -30,6 +30,7 @@ SYMBOLS = (
     "hificar_forward",
     "hificar_ar_loop",
     "hificar_macs",
+    "hificar_pcm16",
     "hificar_profile_begin",
     "hificar_profile_end",
     "hificar_destroy",
@@ -105,6 +106,8 @@ def load_library():
     lib.hificar_ar_loop.restype = ctypes.c_int
     lib.hificar_macs.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.hificar_macs.restype = ctypes.c_double
+    lib.hificar_pcm16.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    lib.hificar_pcm16.restype = ctypes.c_int
     lib.hificar_profile_begin.argtypes = [vp]
     lib.hificar_profile_begin.restype = ctypes.c_int
     lib.hificar_profile_end.argtypes = [vp, ctypes.POINTER(HificarKernelStat), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]

@@ -23,8 +23,11 @@ from articulatory_amd.utils import load_model
 
 def write_wav(path, y, sampling_rate):
     """float waveform in [-1, 1] -> mono PCM_16 WAV (what sf.write's default subtype produces for .wav)."""
-    y = np.asarray(y, dtype=np.float64).reshape(-1)
-    pcm = np.clip(np.rint(y * 32767.0), -32768, 32767).astype("<i2")
+    y = np.asarray(y).reshape(-1)
+    if y.dtype == np.int16:  # already converted on the device (articulatory_amd.utils.pcm16)
+        pcm = y.astype("<i2")
+    else:
+        pcm = np.clip(np.rint(y.astype(np.float64) * 32767.0), -32768, 32767).astype("<i2")
     with wave.open(path, "wb") as f:
         f.setnchannels(1)
         f.setsampwidth(2)

@@ -1262,3 +1262,12 @@ extern "C" int hificar_profile_end(hificar_handle* h, hificar_kernel_stat* stats
     for (int i = 0; i < (int)agg.size() && i < max_stats && stats; ++i) stats[i] = agg[i];
     return HIFICAR_OK;
 }
+
+extern "C" int hificar_pcm16(const float* x, int16_t* y, size_t n, void* stream) {
+    if (!x || !y) return fail(HIFICAR_E_INVALID, "hificar_pcm16: null pointer");
+    if (n == 0) return HIFICAR_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(pcm16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n);
+    HIP_TRY(hipGetLastError());
+    return HIFICAR_OK;
+}

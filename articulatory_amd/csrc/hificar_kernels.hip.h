@@ -1204,4 +1204,12 @@ __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p)
     }
 }
 
+// float waveform -> PCM_16 (reference: sf.write(..., "PCM_16") on the host, decode.py:319-324)
+__global__ __launch_bounds__(256) void pcm16_kernel(const float* __restrict__ x, int16_t* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = rint((double)x[i] * 32767.0);  // the product is exact in fp64: bit-identical to the host writer
+        y[i] = (int16_t)fmin(fmax(v, -32768.0), 32767.0);
+    }
+}
+
 }  // namespace hificar

@@ -12,6 +12,7 @@
  *   hificar_finalize        model.eval().to(device)              egs/ema/voc1/local/predict_wav.py:114-115
  *   hificar_forward         HiFiGANGenerator.forward             articulatory/models/hifigan.py:198-239
  *   hificar_ar_loop         ar_loop (non-WSOLA branch), batched  articulatory/bin/decode.py:31-83
+ *   hificar_pcm16           sf.write(..., "PCM_16") sample conversion articulatory/bin/decode.py:319-324
  *   hificar_workspace_bytes (torch's caching allocator does this implicitly in the reference)
  *   hificar_last_error      Python exceptions / assert           articulatory/models/hifigan.py:78-80
  *
@@ -109,6 +110,12 @@ int hificar_forward(hificar_handle* h, const float* c, const float* ar, float* o
  * Requires ar_input <= hop*chunk_frames (the only case in which the reference's loop is well formed). */
 int hificar_ar_loop(hificar_handle* h, const float* c, float* out, int B, int T_total, int chunk_frames,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* float waveform in [-1, 1] -> 16-bit PCM on the device: y = clip(round_half_even(x * 32767), -32768, 32767).
+ * What the reference's sf.write(..., "PCM_16") does on the host after the device->host copy
+ * (articulatory/bin/decode.py:319-324); doing it before the copy / the multi-GPU gather halves the bytes moved.
+ * x, y: device pointers, n elements. */
+int hificar_pcm16(const float* x, int16_t* y, size_t n, void* stream);
 
 /* Algorithmic multiply-accumulates of one forward of B x T frames (conv + MLP MACs; bias/activation
  * excluded) — the constant SURVEY.md §8(d) defines; used by bench.py for the roofline figure. */

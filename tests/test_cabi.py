@@ -26,7 +26,7 @@ def _full_params(**over):
 def test_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(REPO, "include", "hificar.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(hificar_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(hificar_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_native.SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym

@@ -323,3 +323,18 @@ def test_inference_normalize_before(prec, tmp_path):
         y_ref = O.inference(w, params, x, torch.from_numpy(mean), torch.from_numpy(scale))
     assert y.shape == y_ref.shape == (720, 1)
     assert rel_err(y.numpy(), y_ref.numpy()) < TOLS[prec]
+
+
+def test_pcm16_on_device_matches_host_writer(tmp_path):
+    from articulatory_amd.bin.predict_wav import write_wav
+    from articulatory_amd.utils import pcm16
+    import wave
+    y = torch.from_numpy(np.concatenate([np.linspace(-1.2, 1.2, 4001), [0.5 / 32767, 1.5 / 32767, -2.5 / 32767]]).astype(np.float32))
+    got = pcm16(y.cuda()).cpu().numpy()
+    want = np.clip(np.rint(y.numpy().astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    assert got.dtype == np.int16
+    assert np.array_equal(got, want)  # integer output: bit-exact with the host writer
+    write_wav(str(tmp_path / "a.wav"), got, 16000)
+    with wave.open(str(tmp_path / "a.wav")) as f:
+        assert f.getnframes() == y.numel() and f.getsampwidth() == 2
+        assert np.array_equal(np.frombuffer(f.readframes(y.numel()), dtype="<i2"), got)
