@@ -26,7 +26,8 @@ def synthesize_sharded(synth_fn, feats, group=None):
     waveforms (B, n_samples) in the original utterance order.
 
     synth_fn: (feats_shard) -> (B/W, n_samples) tensor on the compute device, e.g.
-              ``lambda x: ar_loop_batch(model, x, config)``.
+              ``lambda x: ar_loop_batch(model, x, config)``, or ``lambda x: pcm16(ar_loop_batch(model, x, config))``
+              to collect PCM_16 (half the bytes on the links).
     """
     if not dist.is_available() or not dist.is_initialized():
         return synth_fn(feats)
@@ -35,5 +36,9 @@ def synthesize_sharded(synth_fn, feats, group=None):
     lo, hi = shard_range(feats.shape[0], world, rank)
     y = synth_fn(feats[lo:hi]).contiguous()
     out = torch.empty((world * y.shape[0],) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
-    dist.all_gather_into_tensor(out, y, group=group)
+    if y.dtype == torch.int16:
+        # PCM_16 shards (utils.pcm16): neither RCCL nor gloo has a 16-bit integer type; the gather moves bytes
+        dist.all_gather_into_tensor(out.view(torch.uint8), y.view(torch.uint8), group=group)
+    else:
+        dist.all_gather_into_tensor(out, y, group=group)
     return out

@@ -44,6 +44,14 @@ def _worker(rank, world, port, q):
             with torch.no_grad():
                 full = O.ar_loop_batched(w, params, feats, 2000, 80)
             q.put(("ok", float((y - full).abs().max()), tuple(y.shape)))
+        # PCM_16 collection (half the bytes on the wire): the gather is dtype-agnostic; on the GPU the conversion is
+        # articulatory_amd.utils.pcm16 (hificar_pcm16), here its arithmetic restated in torch
+        def synth_pcm(x):
+            return torch.clamp(torch.round(synth(x).double() * 32767.0), -32768, 32767).to(torch.int16)
+
+        y16 = synthesize_sharded(synth_pcm, feats)
+        assert y16.dtype == torch.int16 and tuple(y16.shape) == tuple(y.shape)
+        assert int((y16.int() - torch.round(y.double() * 32767.0).int()).abs().max()) == 0
         with pytest.raises(ValueError):
             synthesize_sharded(synth, feats[:3])
     except Exception as e:  # pragma: no cover
