@@ -188,6 +188,35 @@ def test_baseline_size_properties(car):
         assert rel_err(yc[u, k * 2000:(k + 1) * 2000].numpy(), ref[0, 0].numpy()) < g.tol
 
 
+_FULL_ORACLE = {}
+
+
+def _full_oracle(chunk_frames, n_utt):
+    """The CPU oracle on whole 10-s utterances of BASELINE config 3, computed once per chunk size."""
+    if chunk_frames not in _FULL_ORACLE:
+        x = synth_features(64, 2000, 13, seed=20260929 + 3)[:n_utt]
+        w = O.fold_weight_norm(synth_state_dict(dict(E2W_PARAMS), seed=1234))
+        torch.set_num_threads(min(16, os.cpu_count() or 1))  # the oracle's best thread count on the GPU box's host
+        with torch.no_grad():
+            _FULL_ORACLE[chunk_frames] = (x, O.ar_loop_batched(w, E2W_PARAMS, torch.from_numpy(x), 80 * chunk_frames, 80))
+    return _FULL_ORACLE[chunk_frames]
+
+
+@pytest.mark.parametrize("chunk_frames,n_utt", [(25, 64), (100, 16)])
+def test_baseline_size_every_sample_vs_oracle(car, chunk_frames, n_utt):
+    """BASELINE config 3 at full size against the oracle on every one of the 10.24 M samples (80 chained AR steps:
+    the whole feedback path is inside the comparison); 16 utterances at chunk 100 (the oracle is slow there)."""
+    g, _ = car
+    x, ref = _full_oracle(chunk_frames, n_utt)
+    with torch.no_grad():
+        y = g.ar_synthesis(torch.from_numpy(x).permute(0, 2, 1).contiguous().cuda(), chunk_frames).cpu()
+    assert y.shape == ref.shape == (n_utt, 160000)
+    assert rel_err(y.numpy(), ref.numpy()) < g.tol
+    # per utterance too: no single utterance may hide behind the loudest one
+    per_utt = (y - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)
+    assert float(per_utt.max()) < NORTH_STAR_TOL
+
+
 def test_nonar_baseline_size_vs_oracle_window(prec):
     """BASELINE config 2 (non-AR 12-dim, batch 8, 10 s): full-size run; oracle comparison on one utterance's
     interior window computed from a halo'd excerpt (receptive field of the whole generator < 60 frames)."""
