@@ -40,8 +40,9 @@ def timeit(fn, n_samples, reps=3):
     return n_samples / dt, dt
 
 
-print("| model | arithmetic | batch | samples/s | x real time | ms per 10 s batch |")
-print("|---|---|---:|---:|---:|---:|")
+PEAK = {"bf16x3": 2500.0, "f32": 157.3}  # dense MFMA peak of the arithmetic's instruction, TFLOP/s
+print("| model | arithmetic | batch | samples/s | x real time | ms per 10 s batch | algorithmic TFLOP/s | of MFMA peak |")
+print("|---|---|---:|---:|---:|---:|---:|---:|")
 T = 2000
 for prec in a.precisions:
     car = make(dict(CAR_PARAMS), prec)
@@ -49,8 +50,10 @@ for prec in a.precisions:
     for B in a.batches:
         x13 = torch.from_numpy(synth_features(B, T, 13, seed=5)).permute(0, 2, 1).contiguous().cuda()
         x12 = torch.from_numpy(synth_features(B, T, 12, seed=6)).permute(0, 2, 1).contiguous().cuda()
-        for name, fn in (("HiFi-CAR chunk 25", lambda: car.ar_synthesis(x13, 25)),
-                         ("HiFi-CAR chunk 100", lambda: car.ar_synthesis(x13, 100)),
-                         ("HiFi-GAN non-AR 12-dim", lambda: nonar(x12))):
+        for name, fn, macs in (("HiFi-CAR chunk 25", lambda: car.ar_synthesis(x13, 25), 80 * car.macs(B, 25)),
+                               ("HiFi-CAR chunk 100", lambda: car.ar_synthesis(x13, 100), 20 * car.macs(B, 100)),
+                               ("HiFi-GAN non-AR 12-dim", lambda: nonar(x12), nonar.macs(B, T))):
             sps, dt = timeit(fn, B * T * 80)
-            print(f"| {name} | {prec} | {B} | {sps / 1e6:.2f} M | {sps / 16000:.0f} | {dt * 1e3:.1f} |", flush=True)
+            tf = 2.0 * macs / dt / 1e12
+            print(f"| {name} | {prec} | {B} | {sps / 1e6:.2f} M | {sps / 16000:.0f} | {dt * 1e3:.1f} | {tf:.1f} | {tf / PEAK[prec]:.3f} |",
+                  flush=True)
