@@ -64,6 +64,7 @@ struct ConvLayer {
     int chunk16 = 0, n_blocks32 = 0, nb32_per_phase = 0;
     uint16_t* d_w16 = nullptr;
     uint16_t* d_w16c = nullptr;  // same fragments packed with one K chunk = all channels (fused pair kernel, C <= 64)
+    float* d_w32 = nullptr;      // exact-fp32 arithmetic: fp32 fragments in the same order
 };
 
 struct hificar_handle {
@@ -73,6 +74,7 @@ struct hificar_handle {
     bool profile_detail = false;   // HIFICAR_PROFILE_DETAIL=1: profile rows carry the layer name
     bool use_pair = true;          // HIFICAR_PAIR=0: run narrow stages layer by layer (A/B runs)
     bool use_lpt = true;           // HIFICAR_LPT=0: round-robin tile walk instead of the host LPT schedule (A/B runs)
+    bool f32_old = false;          // HIFICAR_F32_OLD=1: the first-generation fp32 kernel (A/B runs)
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
     int cin_pad = 0;  // padded input-conv channels
     int hop = 1;
@@ -232,6 +234,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (const char* e = getenv("HIFICAR_PROFILE_DETAIL")) h->profile_detail = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_PAIR")) h->use_pair = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_LPT")) h->use_lpt = atoi(e) != 0;
+    if (const char* e = getenv("HIFICAR_F32_OLD")) h->f32_old = atoi(e) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -431,6 +434,37 @@ static int pack_w16(hificar_handle* h, const ConvLayer& L, const HostTensor& W, 
     return HIFICAR_OK;
 }
 
+// exact-fp32 arithmetic: fp32 weight fragments, [n_block32][chunk][tap][c16][half][lane][4]: lane (n = lane & 31, g = lane >> 5)
+// holds channels 16*c16 + 8*half + 4*g + {0..3} of output channel n (one v_mfma_f32_32x32x2_f32 step per element)
+static int pack_w32(hificar_handle* h, const ConvLayer& L, const HostTensor& W, int chunk, float** out) {
+    const int nc16 = chunk / 16, nchunk = L.cin_pad / chunk;
+    const size_t frag = 64 * 4;  // floats per fragment
+    std::vector<float> w32(((size_t)L.n_blocks32 * nchunk * L.ntaps * nc16 * 2 + 4 * nc16) * frag, 0.f);
+    for (int nb = 0; nb < L.n_blocks32; ++nb) {
+        const int phase = nb / L.nb32_per_phase;
+        const int co0 = (nb % L.nb32_per_phase) * 32;
+        for (int c = 0; c < nchunk; ++c)
+            for (int t = 0; t < L.ntaps; ++t) {
+                const int k = L.tap_k[phase][t];
+                if (k < 0) continue;
+                for (int u = 0; u < nc16; ++u)
+                    for (int v = 0; v < 2; ++v) {
+                        float* f = &w32[((((((size_t)nb * nchunk + c) * L.ntaps + t) * nc16 + u) * 2) + v) * frag];
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int g = lane >> 5, n = lane & 31, co = co0 + n;
+                            for (int j = 0; j < 4; ++j) {
+                                const int ci = c * chunk + u * 16 + 8 * v + 4 * g + j;
+                                if (ci >= L.cin) continue;
+                                const size_t src = L.transposed ? ((size_t)ci * L.cout + co) * L.K + k : ((size_t)co * L.cin + ci) * L.K + k;
+                                f[lane * 4 + j] = W.data[src];
+                            }
+                        }
+                    }
+            }
+    }
+    return upload(h, w32, out);
+}
+
 static int pack_conv(hificar_handle* h, ConvLayer& L) {
     const HostTensor& W = h->tensors.at(L.name + ".weight");
     std::vector<float> wp((size_t)L.n_blocks * L.ntaps * L.cin_pad * L.NB, 0.f);
@@ -462,6 +496,7 @@ static int pack_conv(hificar_handle* h, ConvLayer& L) {
     if ((rc = upload(h, bias, &L.d_bias)) != HIFICAR_OK) return rc;
 
     if ((rc = pack_w16(h, L, W, L.chunk16, &L.d_w16)) != HIFICAR_OK) return rc;
+    if ((rc = pack_w32(h, L, W, L.chunk16, &L.d_w32)) != HIFICAR_OK) return rc;
     if (!L.transposed && L.cin_pad == L.cin && (L.cin == 32 || L.cin == 64) && L.cout == L.cin)
         if ((rc = pack_w16(h, L, W, L.cin, &L.d_w16c)) != HIFICAR_OK) return rc;
     return HIFICAR_OK;
@@ -476,6 +511,12 @@ static hipError_t set_lds_attr() {
 template <int MI, int WM, int WN, int NC16>
 static hipError_t set_lds_attr_b() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MI, WM, WN, NC16>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+template <int MI, int WM, int WN, int NC16>
+static hipError_t set_lds_attr_f() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_kernel<MI, WM, WN, NC16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -540,7 +581,9 @@ extern "C" int hificar_finalize(hificar_handle* h) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 4, 1, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#define HIFICAR_SET_ATTR(mi, wm, wn, nc) HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>()));
+#define HIFICAR_SET_ATTR(mi, wm, wn, nc)         \
+    HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>())); \
+    HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>()));
     HIFICAR_FOR_BF16_ALL(HIFICAR_SET_ATTR)
 #undef HIFICAR_SET_ATTR
     HIP_TRY(hipDeviceSynchronize());
@@ -749,8 +792,9 @@ static size_t out_buf_bytes(const TileCfgB& t) { return (size_t)(t.WM * t.MI * 3
 static const TileCfgB kTileCfgsB[9] = {{4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {2, 1, 4}, {2, 2, 2}, {2, 4, 1}, {1, 1, 4}, {1, 2, 2}, {1, 4, 1}};
 
 template <int MI, int WM, int WN, int NC16>
-static hipError_t launch_conv_b(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((conv_bf16x3_kernel<MI, WM, WN, NC16>), grid, dim3(512), lds, stream, mp);
+static hipError_t launch_conv_b(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
+    if (f32) hipLaunchKernelGGL((conv_f32_kernel<MI, WM, WN, NC16>), grid, dim3(512), lds, stream, mp);
+    else hipLaunchKernelGGL((conv_bf16x3_kernel<MI, WM, WN, NC16>), grid, dim3(512), lds, stream, mp);
     return hipGetLastError();
 }
 
@@ -766,6 +810,7 @@ struct ConvIOB {
 static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows, const ConvIOB* io,
                               float slope_out, hipStream_t stream) {
     const ConvLayer& L0 = *layers[0];
+    const bool f32 = h->precision == HIFICAR_PREC_F32;  // rows are plain fp32 LeakyReLU(x) instead of split rows
     int halo_all = 0;
     for (int b = 0; b < nbr; ++b) halo_all = std::max(halo_all, layers[b]->off_max - layers[b]->off_min);
     const int RB = L0.chunk16 * 4;
@@ -784,7 +829,9 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
         // LPT makespan estimate: max(heaviest tile, total / G), plus one light tile when the count does not divide
         double total_cost = 0.0, heaviest = 0.0, lightest = 1e300;
         for (int b = 0; b < nbr; ++b) {
-            const double c = (double)layers[b]->ntaps * (L0.cin_pad / 16) * 3 * t.MI * 32 / 0.75 + 2500.0 + 400.0 * nchunks;
+            // MFMA issue cycles per 16-channel slab and 32x32 accumulator: 3 x 32 (bf16x3, ~75 % sustained) or 8 x 64 (fp32)
+            const double slab = f32 ? 8 * 64.0 : 3 * 32 / 0.75;
+            const double c = (double)layers[b]->ntaps * (L0.cin_pad / 16) * slab * t.MI + 2500.0 + 400.0 * nchunks;
             total_cost += c * tiles_per_branch;
             heaviest = std::max(heaviest, c);
             lightest = std::min(lightest, c);
@@ -792,7 +839,7 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
         double worst = std::max(heaviest, total_cost / G);
         if (total % G != 0) worst = std::max(worst, total_cost / G + 0.5 * lightest);
         // shorter wave tiles re-read the weight stream more often per MFMA (MI = 2 measured ~10 % slower per flop)
-        if (t.MI < 4) worst *= (t.MI == 2 ? 1.10 : 1.25);
+        if (t.MI < 4) worst *= f32 ? (t.MI == 2 ? 1.02 : 1.05) : (t.MI == 2 ? 1.10 : 1.25);
         if (worst < best * 0.98) {  // near-ties keep the earlier (taller) shape
             best = worst;
             tc = t;
@@ -814,6 +861,7 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
         mp.p[b].zeros = h->d_zeros;
         mp.p[b].slope_out = slope_out;
         mp.p[b].cout_real = Lb.cout;
+        if (f32) mp.p[b].w16 = reinterpret_cast<const bf16x8*>(Lb.d_w32);
         const double pos = (double)nseq * rows;
         flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K;
         bytes += 4.0 * (pos * Lb.cin_pad + pos * Lb.cout_total * ((io[b].res ? 1 : 0) + (io[b].y ? 1 : 0) + (io[b].ys ? 1 : 0)) +
@@ -831,7 +879,7 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
     if (h->use_lpt && mp.total_tiles > (int)grid.x) {
         std::vector<double> costs((size_t)mp.total_tiles);
         const int tpb = mp.ngroups * mp.nseq_tiles;
-        std::string key = "c";
+        std::string key = f32 ? "f" : "c";
         for (int b = 0; b < nbr; ++b) {
             key += "|" + layers[b]->name;
             for (int i = 0; i < tpb; ++i) costs[(size_t)b * tpb + i] = layers[b]->ntaps + 1.0;  // + fixed per-tile overhead
@@ -841,7 +889,7 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
         if (rc2 != HIFICAR_OK) return rc2;
     }
     char kname[96];
-    snprintf(kname, sizeof(kname), "conv_bf16x3_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, nc16);
+    snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_f32_kernel" : "conv_bf16x3_kernel", tc.MI, tc.WM, tc.WN, nc16);
     if (h->profile_detail) {  // per-layer rows in the profile (tools/layer_profile.py)
         const size_t n = strlen(kname);
         snprintf(kname + n, sizeof(kname) - n, "|%s x%d", L0.name.c_str(), nbr);
@@ -849,7 +897,7 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
     ProfScope prof(h, stream, kname, flops, bytes);
     hipError_t e = hipErrorInvalidValue;
 #define HIFICAR_DISPATCH_B(mi, wm, wn, nc) \
-    if (tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_b<mi, wm, wn, nc>(mp, grid, lds, stream);
+    if (tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_b<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
     HIFICAR_FOR_BF16_ALL(HIFICAR_DISPATCH_B)
 #undef HIFICAR_DISPATCH_B
     if (e != hipSuccess) return fail(HIFICAR_E_HIP, "conv launch (%s, %s) failed: %s", L0.name.c_str(), kname, hipGetErrorString(e));
@@ -865,7 +913,7 @@ struct PairIOB {
 };
 
 static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const ConvLayer& b) {
-    return h->use_pair && a.d_w16c && b.d_w16c && a.cin == b.cin && a.ntaps >= 2 && b.ntaps >= 2 && b.dilation == 1 && a.K == b.K;
+    return h->use_pair && h->precision == HIFICAR_PREC_BF16X3 && a.d_w16c && b.d_w16c && a.cin == b.cin && a.ntaps >= 2 && b.ntaps >= 2 && b.dilation == 1 && a.K == b.K;
 }
 
 static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, const ConvLayer* const* l2, int nbr, int nseq, int rows,
@@ -998,9 +1046,12 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     fp.c_cstride = c_cstride;
     fp.prev = prev;
     fp.prev_bstride = prev_bstride;
-    const bool split = h->precision == HIFICAR_PREC_BF16X3;
-    fp.xin = split ? nullptr : ws.xin;
-    fp.xin_s = split ? reinterpret_cast<char*>(ws.xin) : nullptr;
+    const bool f32 = h->precision == HIFICAR_PREC_F32;
+    // "split" flow: activations travel between layers already activated (split rows for bf16x3, plain fp32 rows for the
+    // exact-fp32 arithmetic) and are staged by LDS-DMA
+    const bool split = !(f32 && h->f32_old);
+    fp.xin = f32 ? ws.xin : nullptr;
+    fp.xin_s = f32 ? nullptr : reinterpret_cast<char*>(ws.xin);
     fp.T = T;
     fp.cf = h->cf;
     fp.cin_pad = h->cin_pad;
@@ -1052,6 +1103,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 mq.C = stage_channels(cfg, i);
                 mq.rows = (long long)B * rows;
                 mq.slope = cfg.lrelu_slope;
+                mq.f32 = f32 ? 1 : 0;
                 const long long units = mq.rows * (mq.C / 8);
                 const unsigned blocks = (unsigned)std::min<long long>((units + 255) / 256, 8LL * h->num_cus);
                 {

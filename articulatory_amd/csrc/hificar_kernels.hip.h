@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace hificar {
 
@@ -283,8 +284,14 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const MultiConvParam
 //   activations the B operand (lane l -> time row l&31, channels 8*(l>>5)+j = 16 contiguous bytes), software-
 //   pipelined one K slab ahead.  So a lane ends with 4 adjacent channels per register quad: 16-byte stores.
 // ------------------------------------------------------------------------------------------------
-template <int MI, int WM, int WN, int NC16>
-__global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams mp) {
+//
+// F32 = true is the exact-fp32 arithmetic on the same skeleton: rows are plain fp32 LeakyReLU(x) (same 4*C bytes), a
+// 16-channel K slab is two 8-channel halves (lane (li, g) holds channels 8v + 4g + {0..3} of its time row: one
+// ds_read_b128 = four v_mfma_f32_32x32x2_f32 steps), weights are fp32 fragments in the same [slab][half][lane][16 B]
+// order.  8 MFMAs of 64 cycles per slab and accumulator instead of 3 of 32: staging, weight stream and output pass
+// vanish behind the matrix pipe.
+template <int MI, int WM, int WN, int NC16, bool F32>
+__device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     static_assert(WM * WN == 4, "4 MFMA waves per workgroup");
     static_assert(NC16 == 1 || NC16 == 2 || NC16 == 4, "chunk of 16, 32 or 64 channels");
     constexpr int TM = WM * MI * 32;
@@ -397,16 +404,25 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                         *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
                     }
                     if (p.ys) {
-                        bf16x8 hi, lo;
+                        if constexpr (F32) {
+                            float a[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float a = fmaxf(o[e], o[e] * slope_out);  // LeakyReLU, 0 <= slope <= 1
-                            hi[e] = (__bf16)a;
-                            lo[e] = (__bf16)(a - (float)hi[e]);
+                            for (int e = 0; e < 8; ++e) a[e] = fmaxf(o[e], o[e] * slope_out);  // LeakyReLU, 0 <= slope <= 1
+                            float* orow = reinterpret_cast<float*>(p.ys) + row * (size_t)p.cout_total + vc;
+                            *reinterpret_cast<f32x4*>(orow) = f32x4{a[0], a[1], a[2], a[3]};
+                            *reinterpret_cast<f32x4*>(orow + 4) = f32x4{a[4], a[5], a[6], a[7]};
+                        } else {
+                            bf16x8 hi, lo;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float a = fmaxf(o[e], o[e] * slope_out);  // LeakyReLU, 0 <= slope <= 1
+                                hi[e] = (__bf16)a;
+                                lo[e] = (__bf16)(a - (float)hi[e]);
+                            }
+                            char* orow = p.ys + row * (size_t)p.cout_total * 4 + split_off;
+                            *reinterpret_cast<bf16x8*>(orow) = hi;
+                            *reinterpret_cast<bf16x8*>(orow + p.cout_real * 2) = lo;
                         }
-                        char* orow = p.ys + row * (size_t)p.cout_total * 4 + split_off;
-                        *reinterpret_cast<bf16x8*>(orow) = hi;
-                        *reinterpret_cast<bf16x8*>(orow + p.cout_real * 2) = lo;
                     }
                 }
             }
@@ -431,8 +447,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 const int sl = (n & (SPR - 1)) ^ ((r >> LOG_RPB) & (SPR - 1));  // logical slot stored at this position
                 const int t = T.t0 + p.off_min + r;
                 const char* src = p.zeros;
-                if (r < R && t >= 0 && t < p.L)
-                    src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
+                if (r < R && t >= 0 && t < p.L) {
+                    if constexpr (F32) src = p.xs + (seq_base + t) * row_bytes + 2 * c0b + sl * 16;
+                    else src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
+                }
                 // aux = 2: non-temporal — an activation row is staged by one or two CUs only (+2.3 % end to end)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
@@ -466,13 +484,14 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     __builtin_amdgcn_s_setprio(1);  // the MFMA wave outranks the loader wave sharing its SIMD for issue slots
     f32x16 acc[MI];
     // weight fragments: bq = current tap, bn = next tap; loads run two taps ahead of their use
-    bf16x8 bq[NC16][2], bn[NC16][2];
+    using frag_t = typename std::conditional<F32, f32x4, bf16x8>::type;  // 16 bytes per lane either way
+    frag_t bq[NC16][2], bn[NC16][2];
     auto wstream = [&](const Tile& T) {
         const ConvParams& p = mp.p[T.b];
         const int nb = T.ng * WN + wn;
-        return p.w16 + (size_t)(nb < p.n_blocks32 ? nb : 0) * p.ntaps * (p.cin / 16) * 128 + lane;
+        return reinterpret_cast<const frag_t*>(p.w16) + (size_t)(nb < p.n_blocks32 ? nb : 0) * p.ntaps * (p.cin / 16) * 128 + lane;
     };
-    const bf16x8* wp = nullptr;   // where the next tap-group of weight fragments is loaded from
+    const frag_t* wp = nullptr;   // where the next tap-group of weight fragments is loaded from
     int groups_left = 0;          // tap-groups of the current tile's stream not yet requested
     bool primed = false;          // the ring holds the head of the tile about to be computed
     auto prime = [&](const Tile& T) {
@@ -496,25 +515,42 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         const int base = buf_off + r0 * RB;
 #pragma unroll
         for (int u = 0; u < NC16; ++u) {
-            ad[u][0] = base + (((2 * u + g) ^ swz) << 4);
-            ad[u][1] = base + (((SPR / 2 + 2 * u + g) ^ swz) << 4);
+            if constexpr (F32) {  // slab u = slots 4u .. 4u+3: half v, half-wave g
+                ad[u][0] = base + (((4 * u + g) ^ swz) << 4);
+                ad[u][1] = base + (((4 * u + 2 + g) ^ swz) << 4);
+            } else {              // [hi | lo] halves of the row
+                ad[u][0] = base + (((2 * u + g) ^ swz) << 4);
+                ad[u][1] = base + (((SPR / 2 + 2 * u + g) ^ swz) << 4);
+            }
         }
     };
-    auto load_x = [&](bf16x8 (&xh)[MI], bf16x8 (&xl)[MI], const int (&ad)[2]) {
+    auto load_x = [&](frag_t (&xh)[MI], frag_t (&xl)[MI], const int (&ad)[2]) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {  // +32 rows keeps the swizzle (32 % 16 == 0): immediate offsets
-            xh[mi] = *reinterpret_cast<const bf16x8*>(smem_b + ad[0] + mi * 32 * RB);
-            xl[mi] = *reinterpret_cast<const bf16x8*>(smem_b + ad[1] + mi * 32 * RB);
+            xh[mi] = *reinterpret_cast<const frag_t*>(smem_b + ad[0] + mi * 32 * RB);
+            xl[mi] = *reinterpret_cast<const frag_t*>(smem_b + ad[1] + mi * 32 * RB);
         }
     };
-    auto mfma_step = [&](const bf16x8 (&xh)[MI], const bf16x8 (&xl)[MI], const bf16x8& wh, const bf16x8& wl) {
-        // term-major order: consecutive MFMAs never share an accumulator
+    auto mfma_step = [&](const frag_t (&xh)[MI], const frag_t (&xl)[MI], const frag_t& wh, const frag_t& wl) {
+        // consecutive MFMAs never share an accumulator (MI > 1)
+        if constexpr (F32) {
+            // (xh, wh) = channels 0..7 of the slab, (xl, wl) = channels 8..15; step s multiplies channels s and 4 + s
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[mi], acc[mi], 0, 0, 0);
+            for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[mi], acc[mi], 0, 0, 0);
+                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[s4], xh[mi][s4], acc[mi], 0, 0, 0);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[mi], acc[mi], 0, 0, 0);
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[s4], xl[mi][s4], acc[mi], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[mi], acc[mi], 0, 0, 0);
+        }
     };
 
     int j = 0;
@@ -531,7 +567,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         // after this tile's stream is exhausted the loads continue with the NEXT tile's first tap-groups, so its ring is
         // primed when it starts (the last tile re-reads its own head: harmless)
         const Tile Tn = decode(tile_of(it + 1 < my_rounds ? it + 1 : it));
-        const bf16x8* wp_next = wstream(Tn);
+        const frag_t* wp_next = wstream(Tn);
         const int groups_next = nchunks * mp.p[Tn.b].ntaps;
         if (active && !primed) prime(T);  // first tile, or this wave sat out the previous tile (partial channel group)
 #pragma unroll
@@ -548,7 +584,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             int ad[NC16][2];
             addr_set(buf_off, roff0, ad);
             if constexpr (NC16 % 2 == 0) {
-                bf16x8 x0h[MI], x0l[MI], x1h[MI], x1l[MI];
+                frag_t x0h[MI], x0l[MI], x1h[MI], x1l[MI];
                 load_x(x0h, x0l, ad[0]);
                 for (int t = 0; t < ntaps; ++t) {
                     const bool last_tap = t + 1 == ntaps;
@@ -563,7 +599,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     for (int u = 0; u < NC16; u += 2) {
                         load_x(x1h, x1l, ad[u + 1]);
                         {
-                            const bf16x8 wh = bq[u][0], wl = bq[u][1];
+                            const frag_t wh = bq[u][0], wl = bq[u][1];
                             bq[u][0] = bn[u][0];
                             bq[u][1] = bn[u][1];
                             bn[u][0] = wp[u * 128];
@@ -573,7 +609,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                         if (u + 2 < NC16) load_x(x0h, x0l, ad[u + 2]);
                         else load_x(x0h, x0l, adn[0]);
                         {
-                            const bf16x8 wh = bq[u + 1][0], wl = bq[u + 1][1];
+                            const frag_t wh = bq[u + 1][0], wl = bq[u + 1][1];
                             bq[u + 1][0] = bn[u + 1][0];
                             bq[u + 1][1] = bn[u + 1][1];
                             bn[u + 1][0] = wp[(u + 1) * 128];
@@ -598,9 +634,9 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     addr_set(buf_off, roff0 + t * tap_step, ad);
 #pragma unroll
                     for (int u = 0; u < NC16; ++u) {
-                        bf16x8 xh[MI], xl[MI];
+                        frag_t xh[MI], xl[MI];
                         load_x(xh, xl, ad[u]);
-                        const bf16x8 wh = bq[u][0], wl = bq[u][1];
+                        const frag_t wh = bq[u][0], wl = bq[u][1];
                         bq[u][0] = bn[u][0];
                         bq[u][1] = bn[u][1];
                         bn[u][0] = wp[u * 128];
@@ -630,6 +666,16 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     }
     __syncthreads();  // matches the loader waves' final barrier
     if (my_rounds > 0) write_out(decode(tile_of(my_rounds - 1)), tid, 512);
+}
+
+template <int MI, int WM, int WN, int NC16>
+__global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams mp) {
+    conv_ws_body<MI, WM, WN, NC16, false>(mp);
+}
+
+template <int MI, int WM, int WN, int NC16>
+__global__ __launch_bounds__(512) void conv_f32_kernel(const MultiConvParams mp) {
+    conv_ws_body<MI, WM, WN, NC16, true>(mp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -994,6 +1040,7 @@ struct MrfSplitParams {
     int C;
     long long rows;
     float slope;
+    int f32;  // 1: write plain fp32 rows of LeakyReLU(mean) (exact-fp32 arithmetic) instead of split rows
 };
 
 __global__ __launch_bounds__(256) void mrf_split_kernel(const MrfSplitParams p) {
@@ -1021,6 +1068,14 @@ __global__ __launch_bounds__(256) void mrf_split_kernel(const MrfSplitParams p) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 * h + e] = a[e];
         }
+        char* orow = p.out + (size_t)row * p.C * 4;
+        if (p.f32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * p.slope);
+            *reinterpret_cast<f32x4*>(orow + c8 * 32) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(orow + c8 * 32 + 16) = f32x4{v[4], v[5], v[6], v[7]};
+            continue;
+        }
         bf16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1028,7 +1083,6 @@ __global__ __launch_bounds__(256) void mrf_split_kernel(const MrfSplitParams p) 
             hi[e] = (__bf16)a;
             lo[e] = (__bf16)(a - (float)hi[e]);
         }
-        char* orow = p.out + (size_t)row * p.C * 4;
         *reinterpret_cast<bf16x8*>(orow + c8 * 16) = hi;
         *reinterpret_cast<bf16x8*>(orow + p.C * 2 + c8 * 16) = lo;
     }
