@@ -54,15 +54,13 @@ struct ConvLayer {
     int K = 0, dilation = 1, stride = 1, padding = 0;
     bool has_bias = true;
     // derived
-    int n_phase = 1, ntaps = 0, NJ = 4, NB = 128, n_blocks = 0, nb_per_phase = 0, cout_total = 0;
-    int off_min = 0, off_max = 0, chunk = 0;
+    int n_phase = 1, ntaps = 0, cout_total = 0;
+    int off_min = 0, off_max = 0;
     int tap_off[kMaxPhase][kMaxTaps];
     int tap_k[kMaxPhase][kMaxTaps];  // which kernel index each (phase, tap) uses; -1 = zero weights
-    float* d_w = nullptr;
     float* d_bias = nullptr;
-    // bf16x3 path
     int chunk16 = 0, n_blocks32 = 0, nb32_per_phase = 0;
-    uint16_t* d_w16 = nullptr;
+    uint16_t* d_w16 = nullptr;   // bf16x3 arithmetic: hi/lo bf16 weight fragments in MFMA lane order
     uint16_t* d_w16c = nullptr;  // same fragments packed with one K chunk = all channels (fused pair kernel, C <= 64)
     float* d_w32 = nullptr;      // exact-fp32 arithmetic: fp32 fragments in the same order
 };
@@ -74,7 +72,6 @@ struct hificar_handle {
     bool profile_detail = false;   // HIFICAR_PROFILE_DETAIL=1: profile rows carry the layer name
     bool use_pair = true;          // HIFICAR_PAIR=0: run narrow stages layer by layer (A/B runs)
     bool use_lpt = true;           // HIFICAR_LPT=0: round-robin tile walk instead of the host LPT schedule (A/B runs)
-    bool f32_old = false;          // HIFICAR_F32_OLD=1: the first-generation fp32 kernel (A/B runs)
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
     int cin_pad = 0;  // padded input-conv channels
     int hop = 1;
@@ -149,9 +146,6 @@ static int plan_layer(ConvLayer& L) {
     if (L.cout % 32 != 0)
         return fail(HIFICAR_E_INVALID, "%s: output channels (%d) must be a multiple of 32 for the MFMA kernels",
                     L.name.c_str(), L.cout);
-    L.NB = std::min(128, L.cout);
-    if (L.cout % L.NB != 0) L.NB = (L.cout % 64 == 0) ? 64 : 32;
-    L.NJ = L.NB / 32;
     if (!L.transposed) {
         if (L.K > kMaxTaps) return fail(HIFICAR_E_INVALID, "%s: kernel size %d > %d", L.name.c_str(), L.K, kMaxTaps);
         L.n_phase = 1;
@@ -193,12 +187,6 @@ static int plan_layer(ConvLayer& L) {
             L.off_max = std::max(L.off_max, L.tap_off[r][t]);
         }
     L.cout_total = L.cout * L.n_phase;
-    L.nb_per_phase = L.cout / L.NB;
-    L.n_blocks = L.nb_per_phase * L.n_phase;
-    // input-channel chunk: largest multiple of 8 dividing cin_pad, <= 64
-    L.chunk = 8;
-    for (int c = 8; c <= 64; c += 8)
-        if (L.cin_pad % c == 0) L.chunk = c;
     // 16/32/64 channels per LDS item (XOR-swizzled rows), and at least two items per tile (out-buffer hand-off)
     L.chunk16 = (L.cin_pad % 64 == 0 && L.cin_pad >= 128) ? 64 : (L.cin_pad % 32 == 0 && L.cin_pad >= 64) ? 32 : 16;
     L.n_blocks32 = L.cout_total / 32;
@@ -234,7 +222,6 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (const char* e = getenv("HIFICAR_PROFILE_DETAIL")) h->profile_detail = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_PAIR")) h->use_pair = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_LPT")) h->use_lpt = atoi(e) != 0;
-    if (const char* e = getenv("HIFICAR_F32_OLD")) h->f32_old = atoi(e) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -467,45 +454,20 @@ static int pack_w32(hificar_handle* h, const ConvLayer& L, const HostTensor& W, 
 
 static int pack_conv(hificar_handle* h, ConvLayer& L) {
     const HostTensor& W = h->tensors.at(L.name + ".weight");
-    std::vector<float> wp((size_t)L.n_blocks * L.ntaps * L.cin_pad * L.NB, 0.f);
-    for (int nb = 0; nb < L.n_blocks; ++nb) {
-        const int phase = nb / L.nb_per_phase;
-        const int co0 = (nb % L.nb_per_phase) * L.NB;
-        for (int t = 0; t < L.ntaps; ++t) {
-            const int k = L.tap_k[phase][t];
-            if (k < 0) continue;
-            for (int ci = 0; ci < L.cin; ++ci) {
-                float* dst = &wp[(((size_t)nb * L.ntaps + t) * L.cin_pad + ci) * L.NB];
-                for (int n = 0; n < L.NB; ++n) {
-                    const int co = co0 + n;
-                    // Conv1d weight (Cout, Cin, K); ConvTranspose1d weight (Cin, Cout, K)
-                    const size_t src = L.transposed ? ((size_t)ci * L.cout + co) * L.K + k : ((size_t)co * L.cin + ci) * L.K + k;
-                    dst[n] = W.data[src];
-                }
-            }
-        }
-    }
     std::vector<float> bias((size_t)L.cout_total, 0.f);
     if (L.has_bias) {
         const HostTensor& Bv = h->tensors.at(L.name + ".bias");
         for (int r = 0; r < L.n_phase; ++r)
             for (int co = 0; co < L.cout; ++co) bias[(size_t)r * L.cout + co] = Bv.data[co];
     }
-    int rc = upload(h, wp, &L.d_w);
+    int rc = upload(h, bias, &L.d_bias);
     if (rc != HIFICAR_OK) return rc;
-    if ((rc = upload(h, bias, &L.d_bias)) != HIFICAR_OK) return rc;
 
     if ((rc = pack_w16(h, L, W, L.chunk16, &L.d_w16)) != HIFICAR_OK) return rc;
     if ((rc = pack_w32(h, L, W, L.chunk16, &L.d_w32)) != HIFICAR_OK) return rc;
     if (!L.transposed && L.cin_pad == L.cin && (L.cin == 32 || L.cin == 64) && L.cout == L.cin)
         if ((rc = pack_w16(h, L, W, L.cin, &L.d_w16c)) != HIFICAR_OK) return rc;
     return HIFICAR_OK;
-}
-
-template <int MI, int NJ, int WM, int WN>
-static hipError_t set_lds_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<MI, NJ, WM, WN>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 template <int MI, int WM, int WN, int NC16>
@@ -565,18 +527,6 @@ extern "C" int hificar_finalize(hificar_handle* h) {
         HIP_TRY(hipMemset(z, 0, 256));
         h->d_zeros = static_cast<char*>(z);
     }
-    HIP_TRY((set_lds_attr<1, 4, 4, 1>()));
-    HIP_TRY((set_lds_attr<1, 4, 2, 2>()));
-    HIP_TRY((set_lds_attr<1, 4, 1, 4>()));
-    HIP_TRY((set_lds_attr<2, 4, 4, 1>()));
-    HIP_TRY((set_lds_attr<1, 2, 4, 1>()));
-    HIP_TRY((set_lds_attr<1, 2, 2, 2>()));
-    HIP_TRY((set_lds_attr<1, 2, 1, 4>()));
-    HIP_TRY((set_lds_attr<2, 2, 4, 1>()));
-    HIP_TRY((set_lds_attr<1, 1, 4, 1>()));
-    HIP_TRY((set_lds_attr<1, 1, 2, 2>()));
-    HIP_TRY((set_lds_attr<1, 1, 1, 4>()));
-    HIP_TRY((set_lds_attr<2, 1, 4, 1>()));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 2, 2, 4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 4, 1, 2>),
@@ -605,13 +555,14 @@ extern "C" int hificar_set_precision(hificar_handle* h, int precision) {
 // workspace plan
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-    float* xin;    // f32 path: (B, T, cin_pad); bf16x3 path: the same bytes hold split rows
-    float* h0;     // input conv output (f32 rows / split rows)
+    // "activated rows" = LeakyReLU(x) as split rows (bf16x3) or plain fp32 rows (exact fp32): 4 bytes per element either way
+    float* xin;    // (B, T, cin_pad) assembled input rows (no activation in front of the input conv)
+    float* h0;     // input conv output, activated rows
     float* u;      // upsample output, fp32 (residual of the first ResBlock layer)
     float* x[3];   // per-branch residual stream, fp32
-    float* xt[3];  // f32 path: conv1 output fp32; bf16x3 path: conv1 output as split rows
-    char* u_s;     // bf16x3 path: split copy of LeakyReLU(u)
-    char* x_s[3];  // bf16x3 path: split copy of LeakyReLU(x_j)
+    float* xt[3];  // conv1 output, activated rows ([0] also holds the activated MRF mean for the next upsampler)
+    char* u_s;     // activated rows of u
+    char* x_s[3];  // activated rows of x_j
     size_t bytes;
 };
 
@@ -624,7 +575,7 @@ static size_t stage_elems(const hificar_handle* h, int B, int T) {
     return mx * (size_t)B;
 }
 
-// One layout for both arithmetics (set_precision may switch a live handle): split rows are 4 bytes per element too.
+// One layout for both arithmetics (set_precision may switch a live handle).
 static Workspace plan_workspace(const hificar_handle* h, int B, int T, void* base) {
     Workspace w;
     size_t off = 0;
@@ -669,34 +620,7 @@ extern "C" double hificar_macs(const hificar_handle* h, int B, int T) {
 // ------------------------------------------------------------------------------------------------
 // launches
 // ------------------------------------------------------------------------------------------------
-struct TileCfg {
-    int MI, WM, WN;
-};
-static const TileCfg kTileCfgs[4] = {{2, 4, 1}, {1, 4, 1}, {1, 2, 2}, {1, 1, 4}};
-
-static TileCfg pick_tile(const ConvLayer& L, int rows) {
-    TileCfg best = kTileCfgs[1];
-    double best_cost = 1e300;
-    for (const TileCfg& t : kTileCfgs) {
-        const int TM = t.WM * t.MI * 32;
-        if (t.MI == 2 && L.NJ > 2) continue;  // MI=2 only where channels are few (register budget)
-        const double padded_rows = (double)((rows + TM - 1) / TM) * TM;
-        const double padded_blocks = (double)((L.n_blocks + t.WN - 1) / t.WN) * t.WN;
-        const double cost = padded_rows * padded_blocks;
-        if (cost < best_cost - 0.5) {  // ties keep the earlier (larger-TM) entry
-            best_cost = cost;
-            best = t;
-        }
-    }
-    return best;
-}
-
-static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, const float* const* xin, int nin,
-                        const float* res, float* y, float slope) {
-    p.x0 = nin > 0 ? xin[0] : nullptr;
-    p.x1 = nin > 1 ? xin[1] : nullptr;
-    p.x2 = nin > 2 ? xin[2] : nullptr;
-    p.w = L.d_w;
+static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, const float* res, float* y) {
     p.w16 = reinterpret_cast<const bf16x8*>(L.d_w16);
     p.n_blocks32 = L.n_blocks32;
     p.nb32_per_phase = L.nb32_per_phase;
@@ -707,22 +631,11 @@ static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, con
     p.tiles_per_seq = (rows + TM - 1) / TM;
     p.cin = L.cin_pad;
     p.cout_total = L.cout_total;
-    p.chunk = L.chunk;
-    p.n_blocks = L.n_blocks;
-    p.nb_per_phase = L.nb_per_phase;
     p.ntaps = L.ntaps;
     p.off_min = L.off_min;
     p.halo = L.off_max - L.off_min;
-    p.nin = nin;
-    p.slope = slope;
     p.tap_step = L.ntaps > 1 ? L.tap_off[0][1] - L.tap_off[0][0] : 0;
     for (int r = 0; r < kMaxPhase; ++r) p.tap_off0[r] = r < L.n_phase ? L.tap_off[r][0] : 0;
-}
-
-template <int MI, int NJ, int WM, int WN>
-static hipError_t launch_conv_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<MI, NJ, WM, WN>), grid, dim3(256), lds, stream, mp);
-    return hipGetLastError();
 }
 
 // Launch nbr (1..3) same-shape conv layers ("branches") as one grid; branch = blockIdx.z.
@@ -798,7 +711,7 @@ static hipError_t launch_conv_b(const MultiConvParams& mp, dim3 grid, size_t lds
     return hipGetLastError();
 }
 
-// bf16x3 conv on split rows.  Per branch: xs (split input) -> y (fp32, nullable) and/or ys (split copy of
+// One conv launch on activated rows (either arithmetic).  Per branch: xs (activated input) -> y (fp32, nullable) and/or ys (split copy of
 // LeakyReLU(out, slope_out), nullable), + optional fp32 residual.
 struct ConvIOB {
     const char* xs;
@@ -854,8 +767,7 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
         const ConvLayer& Lb = *layers[b];
         if (Lb.n_blocks32 != L0.n_blocks32 || Lb.chunk16 != L0.chunk16 || Lb.cin_pad != L0.cin_pad)
             return fail(HIFICAR_E_INVALID, "internal: branch shape mismatch");
-        const float* none[3] = {nullptr, nullptr, nullptr};
-        fill_params(mp.p[b], Lb, rows, TM, none, 0, io[b].res, io[b].y, 1.0f);
+        fill_params(mp.p[b], Lb, rows, TM, io[b].res, io[b].y);
         mp.p[b].xs = io[b].xs;
         mp.p[b].ys = io[b].ys;
         mp.p[b].zeros = h->d_zeros;
@@ -929,9 +841,8 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
     for (int b = 0; b < nbr; ++b) {
         const ConvLayer& A = *l1[b];
         const ConvLayer& B = *l2[b];
-        const float* none[3] = {nullptr, nullptr, nullptr};
-        fill_params(pp.p1[b], A, rows, TMc, none, 0, nullptr, nullptr, 1.0f);
-        fill_params(pp.p2[b], B, rows, TMc, none, 0, io[b].res, io[b].y, 1.0f);
+        fill_params(pp.p1[b], A, rows, TMc, nullptr, nullptr);
+        fill_params(pp.p2[b], B, rows, TMc, io[b].res, io[b].y);
         pp.p1[b].w16 = reinterpret_cast<const bf16x8*>(A.d_w16c);
         pp.p2[b].w16 = reinterpret_cast<const bf16x8*>(B.d_w16c);
         pp.p1[b].xs = io[b].xs;
@@ -983,54 +894,6 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
     return HIFICAR_OK;
 }
 
-static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows,
-                       const float* (*xin)[3], int nin, const float* const* res, float* const* y, float slope,
-                       hipStream_t stream) {
-    const ConvLayer& L0 = *layers[0];
-    const TileCfg tc = pick_tile(L0, rows);
-    const int TM = tc.WM * tc.MI * 32;
-    MultiConvParams mp;
-    memset(&mp, 0, sizeof(mp));
-    int max_halo = 0;
-    for (int b = 0; b < nbr; ++b) {
-        fill_params(mp.p[b], *layers[b], rows, TM, xin[b], nin, res ? res[b] : nullptr, y[b], slope);
-        max_halo = std::max(max_halo, mp.p[b].halo);
-        if (layers[b]->NJ != L0.NJ || layers[b]->n_blocks != L0.n_blocks || layers[b]->chunk != L0.chunk)
-            return fail(HIFICAR_E_INVALID, "internal: branch shape mismatch");
-    }
-    const size_t lds = (size_t)(TM + max_halo) * (L0.chunk + 4) * sizeof(float);
-    if (lds > 160 * 1024) return fail(HIFICAR_E_INVALID, "internal: LDS tile too large (%zu)", lds);
-    dim3 grid((unsigned)(nseq * ((rows + TM - 1) / TM)), (unsigned)((L0.n_blocks + tc.WN - 1) / tc.WN), (unsigned)nbr);
-    hipError_t e = hipErrorInvalidValue;
-    double flops = 0.0, bytes = 0.0;
-    for (int b = 0; b < nbr; ++b) {
-        const ConvLayer& Lb = *layers[b];
-        const double pos = (double)nseq * rows;
-        flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K;
-        bytes += 4.0 * (pos * Lb.cin_pad * nin + pos * Lb.cout_total * (res ? 2 : 1) + (double)Lb.cin * Lb.cout * Lb.K);
-    }
-    char kname[96];
-    snprintf(kname, sizeof(kname), "conv_mfma_f32_kernel<%d,%d,%d,%d>", tc.MI, L0.NJ, tc.WM, tc.WN);
-    ProfScope prof(h, stream, kname, flops, bytes);
-#define HIFICAR_DISPATCH(mi, nj, wm, wn)                                              \
-    if (tc.MI == mi && L0.NJ == nj && tc.WM == wm && tc.WN == wn) e = launch_conv_t<mi, nj, wm, wn>(mp, grid, lds, stream);
-    HIFICAR_DISPATCH(1, 4, 4, 1)
-    HIFICAR_DISPATCH(1, 4, 2, 2)
-    HIFICAR_DISPATCH(1, 4, 1, 4)
-    HIFICAR_DISPATCH(2, 4, 4, 1)
-    HIFICAR_DISPATCH(1, 2, 4, 1)
-    HIFICAR_DISPATCH(1, 2, 2, 2)
-    HIFICAR_DISPATCH(1, 2, 1, 4)
-    HIFICAR_DISPATCH(2, 2, 4, 1)
-    HIFICAR_DISPATCH(1, 1, 4, 1)
-    HIFICAR_DISPATCH(1, 1, 2, 2)
-    HIFICAR_DISPATCH(1, 1, 1, 4)
-    HIFICAR_DISPATCH(2, 1, 4, 1)
-#undef HIFICAR_DISPATCH
-    if (e != hipSuccess) return fail(HIFICAR_E_HIP, "conv launch (%s) failed: %s", L0.name.c_str(), hipGetErrorString(e));
-    return HIFICAR_OK;
-}
-
 // One generator forward on B sequences of T frames.
 //   c: element (b, ch, t) at c[b*c_bstride + ch*c_cstride + t];  prev: (b, i) at prev[b*prev_bstride + i] or null
 //   out: sample (b, n) at out[b*out_bstride + n]
@@ -1047,9 +910,6 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     fp.prev = prev;
     fp.prev_bstride = prev_bstride;
     const bool f32 = h->precision == HIFICAR_PREC_F32;
-    // "split" flow: activations travel between layers already activated (split rows for bf16x3, plain fp32 rows for the
-    // exact-fp32 arithmetic) and are staged by LDS-DMA
-    const bool split = !(f32 && h->f32_old);
     fp.xin = f32 ? ws.xin : nullptr;
     fp.xin_s = f32 ? nullptr : reinterpret_cast<char*>(ws.xin);
     fp.T = T;
@@ -1080,8 +940,9 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     int max_d = 0;
     for (int j = 0; j < nbk; ++j) max_d = std::max(max_d, cfg.n_dilations[j]);
 
-    if (split) {
-        // ---- bf16x3 path: activations travel as split rows; fp32 only where a residual / the MRF mean needs it ----
+    {
+        // Activations travel between layers already activated — split rows (bf16x3) or plain fp32 rows (exact fp32), the
+        // "_s" buffers — and are staged by LDS-DMA; the layer's own fp32 value only where a residual / the MRF mean needs it
         char* xin_s = reinterpret_cast<char*>(ws.xin);
         char* h0_s = reinterpret_cast<char*>(ws.h0);
         char* xt_s[3] = {reinterpret_cast<char*>(ws.xt[0]), reinterpret_cast<char*>(ws.xt[1]), reinterpret_cast<char*>(ws.xt[2])};
@@ -1149,51 +1010,6 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     if ((rc = launch_conv_bf16x3(h, l1, n, B, rows, io1, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
                     if ((rc = launch_conv_bf16x3(h, l2, n, B, rows, io2, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
                 }
-            }
-        }
-    } else {
-        // ---- f32 path: fp32 rows everywhere, activation / MRF mean applied while staging ----
-        {   // 2. input conv (no activation in front of it: hifigan.py:221)
-            const ConvLayer* lay[1] = {&h->input_conv};
-            const float* xin[1][3] = {{ws.xin, nullptr, nullptr}};
-            float* y[1] = {ws.h0};
-            if ((rc = launch_conv(h, lay, 1, B, T, xin, 1, nullptr, y, 1.0f, stream)) != HIFICAR_OK) return rc;
-        }
-        for (int i = 0; i < cfg.n_stages; ++i) {
-            {   // LeakyReLU + ConvTranspose1d (hifigan.py:224); input = previous stage's MRF mean
-                const ConvLayer* lay[1] = {&h->ups[i]};
-                const float* xin[1][3] = {{i == 0 ? ws.h0 : ws.x[0], i == 0 ? nullptr : (nbk > 1 ? ws.x[1] : nullptr),
-                                           i == 0 ? nullptr : (nbk > 2 ? ws.x[2] : nullptr)}};
-                float* y[1] = {ws.u};
-                if ((rc = launch_conv(h, lay, 1, B, rows, xin, i == 0 ? 1 : nbk, nullptr, y, cfg.lrelu_slope, stream)) != HIFICAR_OK)
-                    return rc;
-            }
-            rows *= cfg.upsample_scales[i];
-            for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
-                const ConvLayer* l1[3];
-                const ConvLayer* l2[3];
-                const float* in1[3][3];
-                const float* in2[3][3];
-                const float* res[3];
-                float* y1[3];
-                float* y2[3];
-                int n = 0;
-                for (int oj = 0; oj < nbk; ++oj) {
-                    const int j = order[oj];
-                    if (d >= cfg.n_dilations[j]) continue;
-                    const int ci = conv_index(h, i, j, d);
-                    l1[n] = &h->convs1[ci];
-                    l2[n] = &h->convs2[ci];
-                    const float* xcur = d == 0 ? ws.u : ws.x[j];
-                    in1[n][0] = xcur; in1[n][1] = nullptr; in1[n][2] = nullptr;
-                    y1[n] = ws.xt[j];
-                    in2[n][0] = ws.xt[j]; in2[n][1] = nullptr; in2[n][2] = nullptr;
-                    res[n] = xcur;
-                    y2[n] = ws.x[j];
-                    ++n;
-                }
-                if ((rc = launch_conv(h, l1, n, B, rows, in1, 1, nullptr, y1, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
-                if ((rc = launch_conv(h, l2, n, B, rows, in2, 1, res, y2, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
             }
         }
     }

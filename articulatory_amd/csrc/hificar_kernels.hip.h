@@ -12,10 +12,10 @@
 // A ConvTranspose1d with K = 2*stride is that contraction with N = stride*Cout "virtual" channels (phase-major) and
 // per-phase tap lists, because out[(q*s + r), co] in channels-last memory IS row q, column r*Cout + co.
 //
-// Two arithmetics:
-//   conv_mfma_f32_kernel       exact fp32 products (v_mfma_f32_32x32x2_f32); fp32 rows; activation applied while staging
-//   conv_bf16x3_kernel         fp32 operands split hi+lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per K slab; "split rows";
-//   conv_pair_bf16x3_kernel    persistent, wave-specialised, LDS-DMA staged; the pair kernel fuses conv1 -> conv2 at C <= 64
+// Two arithmetics on one persistent, wave-specialised, LDS-DMA-staged kernel body:
+//   conv_bf16x3_kernel         fp32 operands split hi+lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per K slab; "split rows"
+//   conv_f32_kernel            exact fp32 products (v_mfma_f32_32x32x2_f32); plain fp32 rows
+//   conv_pair_bf16x3_kernel    fuses conv1 -> conv2 of a ResBlock layer pair at C <= 64 (bf16x3)
 // plus front_kernel (PastFCEncoder + input assembly), mrf_split_kernel (MRF mean + split), output_conv_kernel.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -33,39 +33,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kMaxPhase = 8;
 constexpr int kMaxTaps = 16;
 
-// f32 path: the activation operand is produced while staging into LDS from `nin` inputs:
-//   nin = 1: x0;  nin = 2: (x0 + x1) / 2;  nin = 3: ((x0 + x1) + x2) / 3
-// (the MRF mean `cs / num_blocks` of reference hifigan.py:226-230, summed in the reference's order).
-
+// One conv layer ("branch") of a launch.  Activations travel between layers already activated, 4*C bytes per row:
+//   bf16x3 arithmetic: "split rows" [hi: C bf16 | lo: C bf16] of LeakyReLU(x);  exact-fp32 arithmetic: C floats of LeakyReLU(x).
 struct ConvParams {
-    const float* x0;
-    const float* x1;
-    const float* x2;
-    const float* w;     // f32 path: packed [n_block][tap][ci][NB]
-    const bf16x8* w16;  // bf16x3 path: packed MFMA weight fragments [n_block32][chunk][tap][c16][hi|lo][lane], 16 B each
+    const bf16x8* w16;  // MFMA weight fragments [n_block32][chunk][tap][c16][hi|lo or half][lane], 16 B each (bf16 pairs or fp32)
     const float* bias;  // [cout_total] (never null; zeros when the layer has no bias)
-    const float* res;   // residual, same layout as y, or null
-    float* y;           // fp32 output (bf16x3 path: may be null when only the split copy is consumed)
-    // bf16x3 path ("split rows"): a row of C channels is stored as [hi: C bf16 | lo: C bf16] of act(x), 4*C bytes
-    const char* xs;     // input, already activated + split by its producer
-    char* ys;           // split copy of LeakyReLU(out, slope_out) for the consumer conv, or null
+    const float* res;   // fp32 residual, same layout as y, or null
+    float* y;           // fp32 output of the layer itself (pre-activation), or null when only the activated copy is consumed
+    const char* xs;     // input rows, already activated (and split) by their producer
+    char* ys;           // activated (and split) copy of the output for the consumer conv: LeakyReLU(out, slope_out), or null
     const char* zeros;  // >= 16 bytes of zeros (source of padding rows for the LDS DMA)
     float slope_out;
     int cout_real;      // channels per real output row (== cout_total except for the polyphase ConvTranspose1d)
     int L;              // rows (time steps) per sequence, input rows == output rows
     int tiles_per_seq;  // ceil(L / TM)
-    int cin;            // padded input channels == row pitch of x*
+    int cin;            // padded input channels == row pitch of xs in elements
     int cout_total;     // row pitch of y / res / bias length
-    int chunk;          // input-channel chunk staged per pass (multiple of 8, divides cin)
-    int n_blocks;       // number of NB-wide output blocks (cout_total / NB)
-    int nb_per_phase;   // n_blocks / n_phase
-    int n_blocks32;     // bf16x3 path: number of 32-wide output blocks (cout_total / 32)
+    int n_blocks32;     // number of 32-wide output blocks (cout_total / 32)
     int nb32_per_phase;
     int ntaps;          // taps per phase (same for all phases; missing taps have zero weights)
     int off_min;        // min over all tap offsets (<= 0)
     int halo;           // off_max - off_min
-    int nin;            // number of inputs averaged while staging (1..3)
-    float slope;        // LeakyReLU slope applied to the staged input; 1.0f = identity
     // tap t of phase r reads input row  t_out + tap_off0[r] + t * tap_step  (an arithmetic progression for both
     // Conv1d: -padding + t*dilation, and the polyphase ConvTranspose1d: floor((r+p)/s) - t); no per-tap table
     // lookups in the K loop (a memory lookup there would drain the weight prefetch queue with vmcnt(0)).
@@ -100,160 +88,6 @@ struct MultiConvParams {
 #endif
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
-
-// ------------------------------------------------------------------------------------------------
-// Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
-//
-//   workgroup = 4 waves arranged WM (time) x WN (channel blocks); a wave owns MI x NJ MFMA tiles
-//   of 32x32, i.e. MI*32 time rows x NB = NJ*32 output channels.  TM = WM*MI*32 rows per workgroup.
-//   grid = (sequences * tiles_per_seq, ceil(n_blocks / WN), branches)
-//
-//   LDS holds act(X)[t0 + off_min .. t0 + TM + off_max) x chunk channels, row pitch chunk+4 floats
-//   (pitch/4 odd => the ds_read_b128 of 16 lanes x distinct rows hit 16 distinct 16-byte slots).
-//   Weights are NOT staged: each lane's B operand is a contiguous float<NJ> of the packed weight
-//   row, 512 B per half-wave, L1/L2-served (the whole 54 MB model sits in the 256 MB Infinity Cache).
-//
-//   MFMA operand maps (32x32x2 f32): A lane l -> A[i = l&31][k = l>>5], B lane l -> B[k = l>>5][n = l&31],
-//   D reg r -> D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].  K is consumed 8 channels at a time:
-//   the half-wave g = l>>5 takes channels c8 + 4g .. c8 + 4g + 3 (one b128 LDS read = 4 MFMA steps).
-//   Output column n of tile j is channel NJ*n + j, so a lane's NJ accumulators of one row are NJ
-//   adjacent floats in memory (vector store).
-// ------------------------------------------------------------------------------------------------
-template <int MI, int NJ, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const MultiConvParams mp) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int NB = NJ * 32;
-    constexpr int TM = WM * MI * 32;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const ConvParams& p = mp.p[blockIdx.z];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN;
-    const int wn = wave % WN;
-    const int li = lane & 31;
-    const int g = lane >> 5;
-
-    const int seq = blockIdx.x / p.tiles_per_seq;
-    const int t0 = (blockIdx.x % p.tiles_per_seq) * TM;
-    const int nb = blockIdx.y * WN + wn;
-    const bool active = nb < p.n_blocks;
-    const int phase = active ? nb / p.nb_per_phase : 0;
-
-    const int P = p.chunk + 4;            // LDS row pitch (floats)
-    const int R = TM + p.halo;            // staged rows
-    const int c4n = p.chunk >> 2;         // float4 per staged row
-    const size_t seq_base = (size_t)seq * p.L;
-
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.f;
-
-    const float* wblk = p.w + (size_t)(active ? nb : 0) * p.ntaps * p.cin * NB;
-    const int wave_row0 = wm * (MI * 32);
-    const float slope = p.slope;
-    const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
-
-    for (int c0 = 0; c0 < p.cin; c0 += p.chunk) {
-        __syncthreads();
-        // ---- stage act(X)[rows, c0 : c0+chunk] into LDS (zero rows outside the sequence) ----
-        for (int idx = tid; idx < R * c4n; idx += 256) {
-            const int r = idx / c4n;
-            const int c4 = idx - r * c4n;
-            const int t = t0 + p.off_min + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < p.L) {
-                const size_t off = (seq_base + t) * p.cin + c0 + c4 * 4;
-                v = *reinterpret_cast<const f32x4*>(p.x0 + off);
-                if (p.nin == 3) {
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.x1 + off);
-                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(p.x2 + off);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ((v[e] + v1[e]) + v2[e]) / 3.0f;
-                } else if (p.nin == 2) {
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.x1 + off);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (v[e] + v1[e]) / 2.0f;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], slope);
-            }
-            *reinterpret_cast<f32x4*>(&smem[r * P + c4 * 4]) = v;
-        }
-        __syncthreads();
-        if (!active) continue;
-        // ---- MFMA over taps x channels of this chunk ----
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int roff = roff0 + t * p.tap_step;  // >= 0
-            const float* arow = &smem[(wave_row0 + li + roff) * P + 4 * g];
-            const float* wrow = wblk + ((size_t)t * p.cin + c0 + 4 * g) * NB + NJ * li;
-            for (int c8 = 0; c8 < p.chunk; c8 += 8) {
-                f32x4 a[MI];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(arow + mi * 32 * P + c8);
-                float b[4][NJ];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float* wp = wrow + (size_t)(c8 + s) * NB;
-                    if constexpr (NJ == 4) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(wp);
-                        b[s][0] = v[0]; b[s][1] = v[1]; b[s][2] = v[2]; b[s][3] = v[3];
-                    } else if constexpr (NJ == 2) {
-                        const f32x2 v = *reinterpret_cast<const f32x2*>(wp);
-                        b[s][0] = v[0]; b[s][1] = v[1];
-                    } else {
-                        b[s][0] = *wp;
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[s][j], acc[mi][j], 0, 0, 0);
-            }
-        }
-    }
-    if (!active) return;
-
-    // ---- epilogue: + bias (+ residual), vector store of NJ adjacent channels per row ----
-    const int co = nb * NB + NJ * li;
-    float bj[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) bj[j] = p.bias[co + j];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave_row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            const int t = t0 + row;
-            if (t < p.L) {
-                const size_t off = (seq_base + t) * p.cout_total + co;
-                float v[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) v[j] = acc[mi][j][r] + bj[j];
-                if (p.res) {
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) v[j] += p.res[off + j];
-                }
-                if constexpr (NJ == 4) {
-                    *reinterpret_cast<f32x4*>(p.y + off) = f32x4{v[0], v[1], v[2], v[3]};
-                } else if constexpr (NJ == 2) {
-                    *reinterpret_cast<f32x2*>(p.y + off) = f32x2{v[0], v[1]};
-                } else {
-                    p.y[off] = v[0];
-                }
-            }
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution with fp32 operands split into bf16 hi + lo ("bf16x3"):
