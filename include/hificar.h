@@ -127,7 +127,7 @@ double hificar_macs(const hificar_handle* h, int B, int T);
  * by two hipEvents.  hificar_profile_end synchronises the stream used, then fills up to `max_stats`
  * entries (one per distinct kernel) and writes the number of distinct kernels to *n_stats. */
 typedef struct hificar_kernel_stat {
-    char name[96];     /* e.g. "conv_mfma_f32_kernel<1,4,4,1>" (template args as in the rocprof kernel name) */
+    char name[96];     /* e.g. "conv_bf16x3_kernel<4,1,4,4>" (template args as in the rocprof kernel name) */
     int64_t launches;
     double total_ms;   /* sum of hipEventElapsedTime over the launches */
     double flops;      /* algorithmic FLOPs (2 x MACs) of those launches */

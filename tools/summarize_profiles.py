@@ -3,12 +3,24 @@
    python tools/summarize_profiles.py <tag> <stats_csv> <pmc_fetch_dir> <pmc_write_dir> <bench_json> [precision]"""
 import collections
 import csv
+import glob
 import json
+import os
 import sys
+
+
+def find(path, pattern):
+    """path itself if it is a file, else the single rocprofv3 output matching pattern below it"""
+    if os.path.isfile(path):
+        return path
+    hits = sorted(glob.glob(os.path.join(path, "**", pattern), recursive=True))
+    assert hits, (path, pattern)
+    return hits[0]
+
 
 tag, stats_csv, fdir, wdir, bench_json = sys.argv[1:6]
 prec = sys.argv[6] if len(sys.argv) > 6 else "bf16x3"
-rows = list(csv.DictReader(open(stats_csv)))
+rows = list(csv.DictReader(open(find(stats_csv, '*kernel_stats.csv'))))
 with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -f csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline  ({tag}); durations in ns\n")
     w = csv.writer(f)
@@ -19,7 +31,7 @@ with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
 res = {}
 for c, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for row in csv.DictReader(open(f"{d}/pmc_counter_collection.csv")):
+    for row in csv.DictReader(open(find(d, "*counter_collection.csv"))):
         if row["Counter_Name"] == c:
             agg[row["Kernel_Name"]][0] += 1
             agg[row["Kernel_Name"]][1] += float(row["Counter_Value"])
