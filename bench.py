@@ -213,6 +213,7 @@ def main():
             "frac": round(achieved / peak, 4), "traffic": traffic,
             # bf16x3 issues 3 bf16 MFMAs per algorithmic MAC: the matrix pipe itself runs at 3x `achieved`
             "mfma_issue_tflops": round(achieved * (3 if args.precision == "bf16x3" else 1), 2),
+            "mfma_issue_frac": round(achieved * (3 if args.precision == "bf16x3" else 1) / peak, 4),
             "launches": dom["launches"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
             "flops_per_launch": round(dom["flops"] / dom["launches"], 1),
             "kernel_time_share": round(dom["total_ms"] / total_ms, 4),
