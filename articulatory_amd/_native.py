@@ -29,6 +29,8 @@ SYMBOLS = (
     "hificar_workspace_bytes",
     "hificar_forward",
     "hificar_ar_loop",
+    "hificar_forward_ragged",
+    "hificar_ar_loop_ragged",
     "hificar_macs",
     "hificar_pcm16",
     "hificar_profile_begin",
@@ -104,6 +106,10 @@ def load_library():
     lib.hificar_forward.restype = ctypes.c_int
     lib.hificar_ar_loop.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
     lib.hificar_ar_loop.restype = ctypes.c_int
+    lib.hificar_forward_ragged.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.hificar_forward_ragged.restype = ctypes.c_int
+    lib.hificar_ar_loop_ragged.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.hificar_ar_loop_ragged.restype = ctypes.c_int
     lib.hificar_macs.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.hificar_macs.restype = ctypes.c_double
     lib.hificar_pcm16.argtypes = [vp, vp, ctypes.c_size_t, vp]

@@ -5,7 +5,8 @@
   batch-1 Python with one generator forward and one host round trip of ``prev_samples`` per chunk; here
   the whole non-WSOLA loop (all chunks, PastFCEncoder included, feedback taken straight from the output
   buffer) is enqueued on the device by ONE C-ABI call.  ``ar_loop_batch`` runs B equal-length utterances
-  side by side, which the reference cannot.  The WSOLA variant (``do_wsola``: half-overlapping chunks,
+  side by side and ``ar_loop_ragged`` B utterances of different lengths (each exactly as if it were alone),
+  which the reference cannot.  The WSOLA variant (``do_wsola``: half-overlapping chunks,
   decode.py:84-100) is a per-chunk loop over ``model.forward`` as in the reference, since each chunk's
   context comes from the *middle* of the previous chunk.
 * ``main`` (reference decode.py:103-358, console script ``articulatory-decode``): same flags, config
@@ -66,6 +67,42 @@ def ar_loop_batch(model, xs, config):
     return model.ar_synthesis(xs.permute(0, 2, 1), in_chunk_len)
 
 
+def pad_utterances(xs):
+    """list of (T_i, C) tensors -> ((B, T_max, C) zero-padded tensor, [T_i])."""
+    lens = [int(x.shape[0]) for x in xs]
+    out = torch.zeros((len(xs), max(lens), xs[0].shape[1]), dtype=xs[0].dtype, device=xs[0].device)
+    for i, x in enumerate(xs):
+        out[i, :lens[i]] = x
+    return out, lens
+
+
+def ar_loop_ragged(model, xs, config):
+    """xs: list of (T_i, num_feats) tensors of any lengths -> list of (hop * T_i,) waveforms; every utterance gets the
+    result of ``ar_loop`` on it alone (its own short tail chunk included), all of them in one device call."""
+    in_chunk_len, _ = _chunk_frames(config)
+    padded, lens = pad_utterances(xs)
+    y = model.ar_synthesis(padded.permute(0, 2, 1), in_chunk_len, lengths=lens)
+    hop = y.shape[1] // padded.shape[1]
+    return [y[i, :hop * n] for i, n in enumerate(lens)]
+
+
+def length_batches(items, batch_size, window=8):
+    """Group (key, tensor) items into batches of <= batch_size with similar lengths: sort a window of
+    ``window * batch_size`` items by length (bounded memory, little padding), cut it into batches."""
+    buf = []
+    for it in items:
+        buf.append(it)
+        if len(buf) >= window * batch_size:
+            buf.sort(key=lambda kv: kv[1].shape[0])
+            while buf:
+                yield buf[:batch_size]
+                buf = buf[batch_size:]
+    buf.sort(key=lambda kv: kv[1].shape[0])
+    while buf:
+        yield buf[:batch_size]
+        buf = buf[batch_size:]
+
+
 # ----------------------------------------------------------------------------------------------
 # articulatory-decode counterpart
 # ----------------------------------------------------------------------------------------------
@@ -107,17 +144,42 @@ def get_parser():
     parser.add_argument("--normalize-before", default=False, action="store_true",
                         help="whether to perform feature normalization before input to the model.")
     parser.add_argument("--verbose", type=int, default=1, help="logging level. higher is more logging. (default=1)")
+    parser.add_argument("--batch-size", type=int, default=1,
+                        help="utterances synthesised per device call (any lengths; not in the reference, which is batch-1)")
     return parser
 
 
-def decode_dataset(model, items, config, device, outdir, normalize_before=False, writer=None):
-    """The generation loop of decode.py:292-351 for the a2w modes.  Returns (n_utterances, average RTF)."""
+def decode_dataset(model, items, config, device, outdir, normalize_before=False, writer=None, batch_size=1):
+    """The generation loop of decode.py:292-351 for the a2w modes.  Returns (n_utterances, average RTF).
+    ``batch_size`` > 1: ragged batches of utterances per device call (RTF = batch time / batch audio)."""
     from articulatory_amd.bin.predict_wav import write_wav
 
     writer = writer or write_wav
     use_ar = bool(config["generator_params"].get("use_ar", False))
     do_wsola = bool(config.get("wsola", False))
     total_rtf, n = 0.0, 0
+    if batch_size > 1 and not do_wsola:
+        with torch.no_grad():
+            feats = ((u, torch.tensor(c, dtype=torch.float).to(device)) for u, c in items)
+            for batch in length_batches(feats, batch_size):
+                start = time.time()
+                xs = [c for _, c in batch]
+                if use_ar:
+                    ys = ar_loop_ragged(model, xs, config)
+                else:
+                    if normalize_before:
+                        xs = [(c - model.mean) / model.scale for c in xs]
+                    padded, lens = pad_utterances(xs)
+                    yb = model(padded.permute(0, 2, 1), lengths=lens)
+                    hop = yb.shape[2] // padded.shape[1]
+                    ys = [yb[i, 0, :hop * m] for i, m in enumerate(lens)]
+                ys = [y.cpu().numpy() for y in ys]  # device -> host: the synchronisation point the RTF needs
+                rtf = (time.time() - start) / (sum(len(y) for y in ys) / config["sampling_rate"])
+                for (utt_id, _), y in zip(batch, ys):
+                    writer(os.path.join(outdir, f"{utt_id}_gen.wav"), y, config["sampling_rate"])
+                    total_rtf += rtf
+                    n += 1
+        return n, (total_rtf / n if n else float("nan"))
     with torch.no_grad():
         for utt_id, c in items:
             c = torch.tensor(c, dtype=torch.float).to(device)
@@ -180,7 +242,8 @@ def main(argv=None):
     model.remove_weight_norm()
     model = model.eval().to(device)
     print(sum(p.numel() for p in model.parameters() if p.requires_grad))
-    n, rtf = decode_dataset(model, items, config, device, config["outdir"], normalize_before=args.normalize_before)
+    n, rtf = decode_dataset(model, items, config, device, config["outdir"], normalize_before=args.normalize_before,
+                            batch_size=args.batch_size)
     logging.info(f"Finished generation of {n} utterances (RTF = {rtf:.03f}).")
 
 

@@ -3,8 +3,9 @@
 egs/ema/voc1/local/predict_wav.py:24-137 (same flags, same scp / config / checkpoint conventions).
 
 Differences, all on the device side: the autoregressive loop of every utterance runs as ONE enqueued
-C-ABI call (no per-chunk host round trip), and utterances of equal length can be batched
-(``--batch-size``; the reference is strictly one utterance at a time).  ``soundfile`` is not in this
+C-ABI call (no per-chunk host round trip), and utterances of any lengths can be batched
+(``--batch-size``; the reference is strictly one utterance at a time) — each utterance's waveform is the one it
+gets alone.  ``soundfile`` is not in this
 image, so 16-bit PCM WAV files are written with the standard library.
 """
 
@@ -17,7 +18,7 @@ import numpy as np
 import torch
 import yaml
 
-from articulatory_amd.bin.decode import ar_loop, ar_loop_batch
+from articulatory_amd.bin.decode import ar_loop, ar_loop_ragged, length_batches
 from articulatory_amd.utils import load_model
 
 
@@ -58,49 +59,39 @@ def get_parser():
                              "it will be searched in the checkpoint directory. (default=None)")
     parser.add_argument("--verbose", type=int, default=1, help="logging level. higher is more logging. (default=1)")
     parser.add_argument("--batch-size", type=int, default=1,
-                        help="synthesise up to this many equal-length utterances per device call (extension; default=1)")
+                        help="synthesise up to this many utterances (any lengths) per device call (extension; default=1)")
     return parser
 
 
 def synthesize_file_list(model, fids, featps, config, device, outdir, batch_size=1, writer=write_wav):
-    """The generation loop of predict_wav.py:124-137."""
+    """The generation loop of predict_wav.py:124-137.  ``batch_size`` > 1 (not in the reference): AR utterances are
+    synthesised ``batch_size`` at a time, whatever their lengths — each exactly as if it were alone."""
     use_ar = bool(config["generator_params"].get("use_ar", False))
     written = []
-    pending = {}  # length -> [(fid, tensor)]
 
-    def flush(items):
-        if not items:
-            return
-        if len(items) == 1:
-            ys = [ar_loop(model, items[0][1], config)]
-        else:
-            ys = list(ar_loop_batch(model, torch.stack([c for _, c in items]), config))
-        for (fid, _), y in zip(items, ys):
-            writer(os.path.join(outdir, fid + ".wav"), y.cpu().numpy(), config["sampling_rate"])
-            written.append(fid)
+    def kept():
+        for fid, featp in zip(fids, featps):
+            c = torch.tensor(np.load(featp), dtype=torch.float).to(device)
+            if c.shape[0] > 250:  # the reference skips short utterances (predict_wav.py:130)
+                yield fid, c
 
     with torch.no_grad():
-        for fid, featp in zip(fids, featps):
-            c = np.load(featp)
-            c = torch.tensor(c, dtype=torch.float).to(device)
-            if c.shape[0] > 250:  # the reference skips short utterances (predict_wav.py:130)
-                if use_ar:
-                    if batch_size <= 1:
-                        flush([(fid, c)])
-                    else:
-                        bucket = pending.setdefault(c.shape[0], [])
-                        bucket.append((fid, c))
-                        if len(bucket) >= batch_size:
-                            flush(bucket)
-                            pending[c.shape[0]] = []
-                else:
-                    if len(c.shape) == 1:
-                        c = c.long()
-                    y = model.inference(c)
+        if use_ar and batch_size > 1:
+            for batch in length_batches(kept(), batch_size):
+                ys = [ar_loop(model, batch[0][1], config)] if len(batch) == 1 else ar_loop_ragged(model, [c for _, c in batch], config)
+                for (fid, _), y in zip(batch, ys):
                     writer(os.path.join(outdir, fid + ".wav"), y.cpu().numpy(), config["sampling_rate"])
                     written.append(fid)
-        for bucket in pending.values():
-            flush(bucket)
+            return written
+        for fid, c in kept():
+            if use_ar:
+                y = ar_loop(model, c, config)
+            else:
+                if len(c.shape) == 1:
+                    c = c.long()
+                y = model.inference(c)
+            writer(os.path.join(outdir, fid + ".wav"), y.cpu().numpy(), config["sampling_rate"])
+            written.append(fid)
     return written
 
 

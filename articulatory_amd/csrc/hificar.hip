@@ -620,7 +620,19 @@ extern "C" double hificar_macs(const hificar_handle* h, int B, int T) {
 // ------------------------------------------------------------------------------------------------
 // launches
 // ------------------------------------------------------------------------------------------------
-static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, const float* res, float* y) {
+// Ragged batch context of one forward: utterance b has seq_len[b] frames (device array, null = all equal); the forward
+// covers frames [f0, f0 + frames) of every utterance.
+struct Ragged {
+    const int32_t* seq_len = nullptr;
+    int f0 = 0;
+    int frames = 0;
+};
+
+static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, const float* res, float* y, const Ragged& rg) {
+    p.seq_len = rg.seq_len;
+    p.len_f0 = rg.f0;
+    p.len_max = rg.frames;
+    p.len_mul = rg.frames > 0 ? rows / rg.frames : 1;
     p.w16 = reinterpret_cast<const bf16x8*>(L.d_w16);
     p.n_blocks32 = L.n_blocks32;
     p.nb32_per_phase = L.nb32_per_phase;
@@ -721,7 +733,7 @@ struct ConvIOB {
 };
 
 static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows, const ConvIOB* io,
-                              float slope_out, hipStream_t stream) {
+                              float slope_out, const Ragged& rg, hipStream_t stream) {
     const ConvLayer& L0 = *layers[0];
     const bool f32 = h->precision == HIFICAR_PREC_F32;  // rows are plain fp32 LeakyReLU(x) instead of split rows
     int halo_all = 0;
@@ -767,7 +779,7 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
         const ConvLayer& Lb = *layers[b];
         if (Lb.n_blocks32 != L0.n_blocks32 || Lb.chunk16 != L0.chunk16 || Lb.cin_pad != L0.cin_pad)
             return fail(HIFICAR_E_INVALID, "internal: branch shape mismatch");
-        fill_params(mp.p[b], Lb, rows, TM, io[b].res, io[b].y);
+        fill_params(mp.p[b], Lb, rows, TM, io[b].res, io[b].y, rg);
         mp.p[b].xs = io[b].xs;
         mp.p[b].ys = io[b].ys;
         mp.p[b].zeros = h->d_zeros;
@@ -829,7 +841,7 @@ static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const Con
 }
 
 static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, const ConvLayer* const* l2, int nbr, int nseq, int rows,
-                              const PairIOB* io, float slope, hipStream_t stream) {
+                              const PairIOB* io, float slope, const Ragged& rg, hipStream_t stream) {
     const int C = l1[0]->cin;
     const int MI = 4, WM = C == 64 ? 2 : 4;
     const int TMc = WM * MI * 32, RB = C * 4;
@@ -841,8 +853,8 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
     for (int b = 0; b < nbr; ++b) {
         const ConvLayer& A = *l1[b];
         const ConvLayer& B = *l2[b];
-        fill_params(pp.p1[b], A, rows, TMc, nullptr, nullptr);
-        fill_params(pp.p2[b], B, rows, TMc, io[b].res, io[b].y);
+        fill_params(pp.p1[b], A, rows, TMc, nullptr, nullptr, rg);
+        fill_params(pp.p2[b], B, rows, TMc, io[b].res, io[b].y, rg);
         pp.p1[b].w16 = reinterpret_cast<const bf16x8*>(A.d_w16c);
         pp.p2[b].w16 = reinterpret_cast<const bf16x8*>(B.d_w16c);
         pp.p1[b].xs = io[b].xs;
@@ -899,8 +911,12 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
 //   out: sample (b, n) at out[b*out_bstride + n]
 static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, int64_t c_cstride, const float* prev,
                         int64_t prev_bstride, float* out, int64_t out_bstride, int B, int T, const Workspace& ws,
-                        hipStream_t stream) {
+                        hipStream_t stream, const int32_t* seq_len = nullptr, int f0 = 0) {
     const hificar_config& cfg = h->cfg;
+    Ragged rg;
+    rg.seq_len = seq_len;
+    rg.f0 = f0;
+    rg.frames = T;
     // 1. front end
     FrontParams fp;
     memset(&fp, 0, sizeof(fp));
@@ -949,7 +965,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
         {   // 2. input conv (no activation in front of it: hifigan.py:221); its consumer applies LeakyReLU(slope)
             const ConvLayer* lay[1] = {&h->input_conv};
             const ConvIOB io[1] = {{xin_s, nullptr, nullptr, h0_s}};
-            if ((rc = launch_conv_bf16x3(h, lay, 1, B, T, io, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+            if ((rc = launch_conv_bf16x3(h, lay, 1, B, T, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
         }
         for (int i = 0; i < cfg.n_stages; ++i) {
             const char* up_in = h0_s;
@@ -977,7 +993,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             {   // LeakyReLU + ConvTranspose1d (hifigan.py:224): fp32 u (first residual) + split copy (first conv input)
                 const ConvLayer* lay[1] = {&h->ups[i]};
                 const ConvIOB io[1] = {{up_in, nullptr, ws.u, ws.u_s}};
-                if ((rc = launch_conv_bf16x3(h, lay, 1, B, rows, io, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+                if ((rc = launch_conv_bf16x3(h, lay, 1, B, rows, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
             }
             rows *= cfg.upsample_scales[i];
             for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
@@ -1005,10 +1021,10 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     ++n;
                 }
                 if (fuse) {
-                    if ((rc = launch_pair_bf16x3(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+                    if ((rc = launch_pair_bf16x3(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                 } else {
-                    if ((rc = launch_conv_bf16x3(h, l1, n, B, rows, io1, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
-                    if ((rc = launch_conv_bf16x3(h, l2, n, B, rows, io2, cfg.lrelu_slope, stream)) != HIFICAR_OK) return rc;
+                    if ((rc = launch_conv_bf16x3(h, l1, n, B, rows, io1, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    if ((rc = launch_conv_bf16x3(h, l2, n, B, rows, io2, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                 }
             }
         }
@@ -1029,6 +1045,10 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     op.K = cfg.kernel_size;
     op.slope = 0.01f;
     op.use_tanh = cfg.use_tanh;
+    op.seq_len = seq_len;
+    op.len_f0 = f0;
+    op.len_max = T;
+    op.len_mul = rows / T;
     const size_t lds = ((size_t)(256 + op.K - 1) * (op.C + 1) + (size_t)op.K * op.C) * sizeof(float);
     {
         const double pos = (double)B * rows;
@@ -1049,19 +1069,24 @@ static int check_ready(hificar_handle* h, int B, int T, void* ws, size_t ws_byte
     return HIFICAR_OK;
 }
 
-extern "C" int hificar_forward(hificar_handle* h, const float* c, const float* ar, float* out, int B, int T, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+extern "C" int hificar_forward_ragged(hificar_handle* h, const float* c, const float* ar, const int32_t* lengths, float* out, int B,
+                                      int T, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_ready(h, B, T, workspace, workspace_bytes);
     if (rc != HIFICAR_OK) return rc;
     if (!c || !out) return fail(HIFICAR_E_INVALID, "hificar_forward: null tensor");
     if (h->cfg.use_ar && !ar) return fail(HIFICAR_E_INVALID, "use_ar model needs the ar context (got NULL)");
     const Workspace ws = plan_workspace(h, B, T, workspace);
     return forward_impl(h, c, (int64_t)h->cf * T, T, h->cfg.use_ar ? ar : nullptr, h->cfg.ar_input, out,
-                        (int64_t)h->hop * T, B, T, ws, static_cast<hipStream_t>(stream));
+                        (int64_t)h->hop * T, B, T, ws, static_cast<hipStream_t>(stream), lengths, 0);
 }
 
-extern "C" int hificar_ar_loop(hificar_handle* h, const float* c, float* out, int B, int T_total, int chunk_frames,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int hificar_forward(hificar_handle* h, const float* c, const float* ar, float* out, int B, int T, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    return hificar_forward_ragged(h, c, ar, nullptr, out, B, T, workspace, workspace_bytes, stream);
+}
+
+extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const int32_t* lengths, float* out, int B, int T_total,
+                                      int chunk_frames, void* workspace, size_t workspace_bytes, void* stream) {
     if (h && !h->cfg.use_ar) return fail(HIFICAR_E_INVALID, "hificar_ar_loop on a model built with use_ar=false");
     if (chunk_frames < 1) return fail(HIFICAR_E_INVALID, "chunk_frames=%d must be positive", chunk_frames);
     int rc = check_ready(h, B, std::min(chunk_frames, std::max(T_total, 1)), workspace, workspace_bytes);
@@ -1080,10 +1105,15 @@ extern "C" int hificar_ar_loop(hificar_handle* h, const float* c, float* out, in
         // prev = last ar_input samples already written for this utterance (zeros for the first chunk)
         const float* prev = f0 == 0 ? nullptr : out + pos - h->cfg.ar_input;
         rc = forward_impl(h, c + f0, (int64_t)h->cf * T_total, T_total, prev, out_bstride, out + pos, out_bstride, B, Tn, ws,
-                          static_cast<hipStream_t>(stream));
+                          static_cast<hipStream_t>(stream), lengths, f0);
         if (rc != HIFICAR_OK) return rc;
     }
     return HIFICAR_OK;
+}
+
+extern "C" int hificar_ar_loop(hificar_handle* h, const float* c, float* out, int B, int T_total, int chunk_frames,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    return hificar_ar_loop_ragged(h, c, nullptr, out, B, T_total, chunk_frames, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

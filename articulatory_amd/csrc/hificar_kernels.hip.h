@@ -59,7 +59,19 @@ struct ConvParams {
     // lookups in the K loop (a memory lookup there would drain the weight prefetch queue with vmcnt(0)).
     int tap_step;
     int tap_off0[kMaxPhase];
+    // ragged batches: utterance b is seq_len[b] frames long; this launch covers frames [len_f0, len_f0 + len_max) at
+    // len_mul rows per frame, so sequence b has clamp(seq_len[b] - len_f0, 0, len_max) * len_mul valid rows (<= L): rows
+    // beyond them read as zero padding and are never written.  seq_len == null: every sequence has L rows.
+    const int* seq_len;
+    int len_f0, len_max, len_mul;
 };
+
+// valid rows of sequence `seq` (wave-uniform: one scalar load)
+__device__ __forceinline__ int seq_rows(const ConvParams& p, int seq) {
+    if (!p.seq_len) return p.L;
+    const int n = p.seq_len[__builtin_amdgcn_readfirstlane(seq)] - p.len_f0;
+    return min(max(n, 0), p.len_max) * p.len_mul;
+}
 
 struct MultiConvParams {
     ConvParams p[3];
@@ -197,7 +209,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         const bool lane_on = rr < rpp;                            // w8 = 12 leaves a few threads idle
         const size_t seq_base = (size_t)T.seq * p.L;
         const float slope_out = p.slope_out;
-        const int rows = min(TM, p.L - T.t0);
+        const int rows = min(TM, seq_rows(p, T.seq) - T.t0);
         const int vc = vc_base + c8;
         const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + vc);
         const f32x4 bv1 = *reinterpret_cast<const f32x4*>(p.bias + vc + 4);
@@ -272,6 +284,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             const int R = TM + p.halo;
             const int ninstr = (R * SPR + 63) >> 6;  // 1 KiB of LDS per wave-instruction
             const size_t seq_base = (size_t)T.seq * p.L;
+            const int Ls = seq_rows(p, T.seq);
             const int row_bytes = p.cin * 4;
             char* dst = smem_b + (jj & 1) * buf_bytes;
             const int c0b = c * CH * 2;  // byte offset of this chunk inside the hi (and lo) half of a row
@@ -281,7 +294,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                 const int sl = (n & (SPR - 1)) ^ ((r >> LOG_RPB) & (SPR - 1));  // logical slot stored at this position
                 const int t = T.t0 + p.off_min + r;
                 const char* src = p.zeros;
-                if (r < R && t >= 0 && t < p.L) {
+                if (r < R && t >= 0 && t < Ls) {
                     if constexpr (F32) src = p.xs + (seq_base + t) * row_bytes + 2 * c0b + sl * 16;
                     else src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
                 }
@@ -608,7 +621,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         const int c8 = (ltid - rr * w8) * 8;
         const size_t seq_base = (size_t)T.seq * p.L;
         const float slope_out = p.slope_out;
-        const int rows = min(T.tmo, p.L - T.t0);
+        const int rows = min(T.tmo, seq_rows(p, T.seq) - T.t0);
         const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + c8);
         const f32x4 bv1 = *reinterpret_cast<const f32x4*>(p.bias + c8 + 4);
         constexpr int UB = 4;
@@ -665,6 +678,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
             const int R = TMc + p.halo;
             const int ninstr = (R * SPR + 63) >> 6;
             const size_t seq_base = (size_t)T.seq * p.L;
+            const int Ls = seq_rows(p, T.seq);
             const int row_bytes = p.cin * 4;
             const int tfirst = T.t0 - pad2 + p.off_min;  // time of LDS row 0
             for (int i = lw; i < ninstr; i += 4) {
@@ -673,7 +687,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
                 const int sl = (n & (SPR - 1)) ^ ((r >> LOG_RPB) & (SPR - 1));
                 const int t = tfirst + r;
                 const char* src = p.zeros;
-                if (r < R && t >= 0 && t < p.L)
+                if (r < R && t >= 0 && t < Ls)
                     src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? sl * 16 : p.cin * 2 + (sl - SPR / 2) * 16);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(smem_b + i * 1024), 16, 0, 2);
@@ -804,6 +818,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         const int k2 = p2.ntaps;
         const int pad2 = (k2 - 1) >> 1;
         const Tile Tn = decode(tile_of(it + 1 < my_rounds ? it + 1 : it));
+        const int Ls = seq_rows(p1, T.seq);
         HIFICAR_STAMP(6 * it);
         __syncthreads();  // A: input landed
         HIFICAR_STAMP(6 * it + 1);
@@ -820,7 +835,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
             for (int mi = 0; mi < MI; ++mi) {
                 const int r1 = wave_row0 + mi * 32 + li;
                 const int t = T.t0 - pad2 + r1;
-                const bool in_seq = t >= 0 && t < p1.L;
+                const bool in_seq = t >= 0 && t < Ls;
                 const int swz = (r1 >> LOG_RPB) & (SPR - 1);
                 char* trow = smem_b + ts_off + r1 * RB + 8 * g;
 #pragma unroll
@@ -1040,6 +1055,8 @@ struct OutConvParams {
     int K;
     float slope;
     int use_tanh;
+    const int* seq_len;  // ragged batches, as in ConvParams (rows = samples)
+    int len_f0, len_max, len_mul;
 };
 
 __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p) {
@@ -1053,13 +1070,15 @@ __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p)
     float* ws = smem + R * P;  // weights [k][C]
     for (int i = tid; i < p.K * p.C; i += 256) ws[i] = p.w[i];
     const size_t base = (size_t)seq * p.L;
+    const int Ls = p.seq_len ? min(max(p.seq_len[seq] - p.len_f0, 0), p.len_max) * p.len_mul : p.L;
+    if (t0 >= Ls) return;  // nothing of this sequence in the block (uniform)
     const int c4n = p.C >> 2;  // C is a multiple of 32: 16-byte loads
     for (int idx = tid; idx < R * c4n; idx += 256) {
         const int r = idx / c4n;
         const int ch = (idx - r * c4n) * 4;
         const int t = t0 - pad + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t >= 0 && t < p.L) {
+        if (t >= 0 && t < Ls) {
             const size_t off = (base + t) * p.C + ch;
             v = *reinterpret_cast<const f32x4*>(p.x0 + off);
             if (p.nin >= 2) {
@@ -1081,7 +1100,7 @@ __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p)
     }
     __syncthreads();
     const int t = t0 + tid;
-    if (t < p.L) {
+    if (t < Ls) {
         float s = p.bias;
         for (int k = 0; k < p.K; ++k) {
             const float* xr = &smem[(tid + k) * P];

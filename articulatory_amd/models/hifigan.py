@@ -372,8 +372,20 @@ class HiFiGANGenerator(torch.nn.Module):
         if c.dim() != 3 or c.shape[1] != cf:
             raise RuntimeError(f"Expected input of shape (B, {cf}, T), got {tuple(c.shape)}")
 
-    def forward(self, c, spk_id=None, ar=None, ph=None):
-        """c: (B, in_channels[-ar_output], T) -> (B, out_channels, T * prod(upsample_scales))  (hifigan.py:198-239)."""
+    def _lengths_arg(self, lengths, B, T, device):
+        """lengths (sequence / tensor of B frame counts) -> int32 device tensor for the ragged entry points."""
+        lengths = torch.as_tensor(lengths, dtype=torch.int32).reshape(-1)
+        if lengths.numel() != B:
+            raise RuntimeError(f"lengths has {lengths.numel()} entries for a batch of {B}")
+        if int(lengths.min()) < 0 or int(lengths.max()) > T:
+            raise RuntimeError(f"lengths must lie in [0, {T}]")
+        return lengths.to(device).contiguous()
+
+    def forward(self, c, spk_id=None, ar=None, ph=None, lengths=None):
+        """c: (B, in_channels[-ar_output], T) -> (B, out_channels, T * prod(upsample_scales))  (hifigan.py:198-239).
+
+        ``lengths`` (not in the reference, which is batch-1 at inference): frame counts of a padded batch of utterances of
+        different lengths; utterance b is computed exactly as if it were alone and out[b, :, hop*lengths[b]:] is zero."""
         self._check_input(c)
         if self.use_ar:
             if ar is None:
@@ -384,21 +396,28 @@ class HiFiGANGenerator(torch.nn.Module):
         c = c.to(torch.float32).contiguous()
         B, _, T = c.shape
         handle = self._native_handle()
-        out = torch.empty((B, 1, T * self.hop), dtype=torch.float32, device=c.device)
+        if lengths is None:
+            out = torch.empty((B, 1, T * self.hop), dtype=torch.float32, device=c.device)
+        else:
+            lengths = self._lengths_arg(lengths, B, T, c.device)
+            out = torch.zeros((B, 1, T * self.hop), dtype=torch.float32, device=c.device)
         with torch.cuda.device(c.device):
             ws_ptr, ws_bytes = self._workspace(B, T)
             stream = torch.cuda.current_stream().cuda_stream
-            rc = self._lib.hificar_forward(handle, c.data_ptr(), ar.data_ptr() if self.use_ar else None, out.data_ptr(),
-                                           B, T, ws_ptr, ws_bytes, ctypes.c_void_p(stream))
+            rc = self._lib.hificar_forward_ragged(handle, c.data_ptr(), ar.data_ptr() if self.use_ar else None,
+                                                  lengths.data_ptr() if lengths is not None else None, out.data_ptr(),
+                                                  B, T, ws_ptr, ws_bytes, ctypes.c_void_p(stream))
         _native.check(rc, "hificar_forward")
         return out
 
-    def ar_synthesis(self, c, chunk_frames):
-        """Batched autoregressive synthesis of equal-length utterances on device.
+    def ar_synthesis(self, c, chunk_frames, lengths=None):
+        """Batched autoregressive synthesis on device.
 
         c: (B, C, T_total) features; returns (B, hop*T_total).  Per utterance this equals the
         reference's ``ar_loop`` (articulatory/bin/decode.py:54-83) with
         ``chunk_frames = batch_max_steps // hop_size``; the reference driver is batch-1 only.
+        ``lengths``: frame counts of a padded batch of utterances of different lengths (see ``forward``); each utterance's
+        last chunk is then its own shorter tail chunk, as in the reference loop.
         """
         if not self.use_ar:
             raise RuntimeError("ar_synthesis needs a use_ar=True generator")
@@ -406,12 +425,16 @@ class HiFiGANGenerator(torch.nn.Module):
         c = c.to(torch.float32).contiguous()
         B, _, T = c.shape
         handle = self._native_handle()
-        out = torch.empty((B, T * self.hop), dtype=torch.float32, device=c.device)
+        if lengths is None:
+            out = torch.empty((B, T * self.hop), dtype=torch.float32, device=c.device)
+        else:
+            lengths = self._lengths_arg(lengths, B, T, c.device)
+            out = torch.zeros((B, T * self.hop), dtype=torch.float32, device=c.device)
         with torch.cuda.device(c.device):
             ws_ptr, ws_bytes = self._workspace(B, min(int(chunk_frames), T))
             stream = torch.cuda.current_stream().cuda_stream
-            rc = self._lib.hificar_ar_loop(handle, c.data_ptr(), out.data_ptr(), B, T, int(chunk_frames), ws_ptr, ws_bytes,
-                                           ctypes.c_void_p(stream))
+            rc = self._lib.hificar_ar_loop_ragged(handle, c.data_ptr(), lengths.data_ptr() if lengths is not None else None,
+                                                  out.data_ptr(), B, T, int(chunk_frames), ws_ptr, ws_bytes, ctypes.c_void_p(stream))
         _native.check(rc, "hificar_ar_loop")
         return out
 

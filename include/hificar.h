@@ -12,6 +12,10 @@
  *   hificar_finalize        model.eval().to(device)              egs/ema/voc1/local/predict_wav.py:114-115
  *   hificar_forward         HiFiGANGenerator.forward             articulatory/models/hifigan.py:198-239
  *   hificar_ar_loop         ar_loop (non-WSOLA branch), batched  articulatory/bin/decode.py:31-83
+ *   hificar_forward_ragged  the per-utterance loop over a dataset calling .inference()  egs/ema/voc1/local/predict_wav.py:124-137,
+ *   hificar_ar_loop_ragged  ... or ar_loop(), one utterance at a time                    articulatory/bin/decode.py:292-351
+ *                           (a batch of utterances of DIFFERENT lengths in one call; results per utterance are those of
+ *                           the one-at-a-time loop, bit for bit)
  *   hificar_pcm16           sf.write(..., "PCM_16") sample conversion articulatory/bin/decode.py:319-324
  *   hificar_workspace_bytes (torch's caching allocator does this implicitly in the reference)
  *   hificar_last_error      Python exceptions / assert           articulatory/models/hifigan.py:78-80
@@ -110,6 +114,17 @@ int hificar_forward(hificar_handle* h, const float* c, const float* ar, float* o
  * Requires ar_input <= hop*chunk_frames (the only case in which the reference's loop is well formed). */
 int hificar_ar_loop(hificar_handle* h, const float* c, float* out, int B, int T_total, int chunk_frames,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Ragged batches: B utterances of different lengths, padded to a common T (T_total) in `c`.
+ * lengths: DEVICE pointer to B int32 frame counts (0 <= lengths[b] <= T), or NULL (all T).  Utterance b is
+ * synthesised exactly as if it were alone: frames >= lengths[b] do not exist for it (its convs see zero padding
+ * there — also in the shorter last AR chunk, decode.py:56-58 — and nothing is written to out[b, hop*lengths[b]:],
+ * which keeps whatever the caller put there).  This is the dataset loop of predict_wav.py:124-137 /
+ * decode.py:292-351 run B utterances at a time. */
+int hificar_forward_ragged(hificar_handle* h, const float* c, const float* ar, const int32_t* lengths, float* out, int B,
+                           int T, void* workspace, size_t workspace_bytes, void* stream);
+int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const int32_t* lengths, float* out, int B, int T_total,
+                           int chunk_frames, void* workspace, size_t workspace_bytes, void* stream);
 
 /* float waveform in [-1, 1] -> 16-bit PCM on the device: y = clip(round_half_even(x * 32767), -32768, 32767).
  * What the reference's sf.write(..., "PCM_16") does on the host after the device->host copy

@@ -367,3 +367,67 @@ def test_pcm16_on_device_matches_host_writer(tmp_path):
     with wave.open(str(tmp_path / "a.wav")) as f:
         assert f.getnframes() == y.numel() and f.getsampwidth() == 2
         assert np.array_equal(np.frombuffer(f.readframes(y.numel()), dtype="<i2"), got)
+
+
+def test_ragged_batch_equals_one_at_a_time(car):
+    """hificar_ar_loop_ragged: a padded batch of utterances of different lengths gives, per utterance, the waveform of
+    that utterance synthesised alone (bit for bit — same kernels, same accumulation order, zero padding at its own end),
+    which in turn matches the oracle's batch-1 ``ar_loop`` (decode.py:54-83) incl. each utterance's own short tail chunk."""
+    g, w = car
+    lens = [260, 25, 131, 7, 200, 0, 99]
+    Tm = max(lens)
+    x = synth_features(len(lens), Tm, 13, seed=4242)
+    for b, n in enumerate(lens):
+        x[b, n:] = 7.5  # padding frames must not matter, whatever they hold
+    feats = torch.from_numpy(x).permute(0, 2, 1).contiguous().cuda()
+    with torch.no_grad():
+        y = g.ar_synthesis(feats, 25, lengths=lens)
+    assert y.shape == (len(lens), 80 * Tm)
+    for b, n in enumerate(lens):
+        assert float(y[b, 80 * n:].abs().max()) == 0.0 if n < Tm else True
+        if n == 0:
+            continue
+        with torch.no_grad():
+            alone = g.ar_synthesis(feats[b:b + 1, :, :n].contiguous(), 25)
+            ref = O.ar_loop(w, E2W_PARAMS, torch.from_numpy(x[b, :n]), 2000, 80)
+        assert torch.equal(y[b, :80 * n], alone[0]), (b, n)
+        assert rel_err(y[b, :80 * n].cpu().numpy(), ref.numpy()) < g.tol, (b, n)
+
+
+def test_ragged_forward_non_ar(prec):
+    """hificar_forward_ragged on the non-AR generator: per utterance identical to a forward of that utterance alone."""
+    params = dict(E2W_PARAMS, in_channels=12, use_ar=False)
+    g, w = make(params, prec)
+    lens = [300, 41, 128, 1]
+    Tm = max(lens)
+    x = synth_features(len(lens), Tm, 12, seed=777)
+    feats = torch.from_numpy(x).permute(0, 2, 1).contiguous().cuda()
+    with torch.no_grad():
+        y = g(feats, lengths=torch.tensor(lens))
+        for b, n in enumerate(lens):
+            alone = g(feats[b:b + 1, :, :n].contiguous())
+            assert torch.equal(y[b, :, :80 * n], alone[0]), (b, n)
+            assert float(y[b, :, 80 * n:].abs().sum()) == 0.0
+        ref = O.generator_forward(w, params, torch.from_numpy(x[1:2, :41]).permute(0, 2, 1))
+    assert rel_err(y[1, :, :80 * 41].cpu().numpy(), ref[0].numpy()) < TOLS[prec]
+    with pytest.raises(RuntimeError):
+        g(feats, lengths=[1, 2, 3])
+    with pytest.raises(RuntimeError):
+        g(feats, lengths=[1, 2, 3, Tm + 1])
+
+
+def test_decode_dataset_ragged_batches_on_device(car, tmp_path):
+    """articulatory-decode counterpart over a small dataset of mixed lengths: --batch-size 4 writes the very waveforms
+    that one-utterance-at-a-time decoding writes."""
+    from articulatory_amd.bin import decode as D
+    g, _ = car
+    config = dict(generator_params=dict(E2W_PARAMS, extra_art=False), sampling_rate=16000, hop_size=80, batch_max_steps=2000,
+                  dataset_mode="a2w")
+    items = [(f"u{i}", synth_features(1, T, 13, seed=60 + i)[0]) for i, T in enumerate([310, 64, 255, 129, 26])]
+    one, four = {}, {}
+    n1, _ = D.decode_dataset(g, iter(items), config, "cuda:0", str(tmp_path), writer=lambda p, y, sr: one.__setitem__(os.path.basename(p), y))
+    n4, rtf = D.decode_dataset(g, iter(items), config, "cuda:0", str(tmp_path), batch_size=4,
+                               writer=lambda p, y, sr: four.__setitem__(os.path.basename(p), y))
+    assert n1 == n4 == 5 and rtf > 0 and sorted(one) == sorted(four)
+    for k in one:
+        assert one[k].shape == four[k].shape and np.array_equal(one[k], four[k]), k

@@ -130,9 +130,14 @@ class _OracleBackedModel:
         self.params, self.w = params, O.fold_weight_norm(sd)
         self.calls = []
 
-    def ar_synthesis(self, c, chunk_frames):
-        self.calls.append((tuple(c.shape), chunk_frames))
-        return O.ar_loop_batched(self.w, self.params, c.permute(0, 2, 1), chunk_frames * 80, 80)
+    def ar_synthesis(self, c, chunk_frames, lengths=None):
+        self.calls.append((tuple(c.shape), chunk_frames) if lengths is None else (tuple(c.shape), chunk_frames, list(lengths)))
+        if lengths is None:
+            return O.ar_loop_batched(self.w, self.params, c.permute(0, 2, 1), chunk_frames * 80, 80)
+        out = torch.zeros(c.shape[0], 80 * c.shape[2])  # ragged: each utterance alone, as the HIP path guarantees
+        for b, n in enumerate(lengths):
+            out[b, :80 * n] = O.ar_loop(self.w, self.params, c[b, :, :n].permute(1, 0), chunk_frames * 80, 80)
+        return out
 
     def __call__(self, c, ar=None):
         return O.generator_forward(self.w, self.params, c, ar)
@@ -169,7 +174,7 @@ def test_predict_wav_plumbing_matches_reference_pin(tmp_path):
         assert (f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()) == (16000, 1, 2, 56000)
 
 
-def test_predict_wav_batches_equal_lengths(tmp_path):
+def test_predict_wav_ragged_batches(tmp_path):
     params = dict(E2W_PARAMS)
     model = _OracleBackedModel(params, synth_state_dict(params, seed=1234))
     paths = []
@@ -181,7 +186,15 @@ def test_predict_wav_batches_equal_lengths(tmp_path):
     outs = {}
     PW.synthesize_file_list(model, ["u0", "u1", "u2"], paths, config, "cpu", str(tmp_path), batch_size=2,
                             writer=lambda p, y, sr: outs.__setitem__(os.path.basename(p), y))
-    assert sorted(model.calls) == [((1, 13, 300), 100), ((2, 13, 260), 100)]
+    assert model.calls == [((2, 13, 260), 100, [260, 260]), ((1, 13, 300), 100)]  # sorted by length, cut into batches of 2
+    outs3 = {}
+    model3 = _OracleBackedModel(params, synth_state_dict(params, seed=1234))
+    PW.synthesize_file_list(model3, ["u0", "u1", "u2"], paths, config, "cpu", str(tmp_path), batch_size=3,
+                            writer=lambda p, y, sr: outs3.__setitem__(os.path.basename(p), y))
+    assert model3.calls == [((3, 13, 300), 100, [260, 260, 300])]  # one ragged batch, padded to the longest
+    assert {k: len(v) for k, v in outs3.items()} == {"u0.wav": 20800, "u1.wav": 24000, "u2.wav": 20800}
+    for k in outs:
+        assert rel_err(outs3[k], outs[k]) < 1e-6
     single = _OracleBackedModel(params, synth_state_dict(params, seed=1234))
     y0 = D.ar_loop(single, torch.from_numpy(np.load(paths[0])).float(), config)
     assert rel_err(outs["u0.wav"], y0.numpy()) < 2e-5
@@ -221,6 +234,16 @@ def test_decode_cli_plumbing(tmp_path):
     assert rel_err(got["uttA_gen.wav"], gold["out_bms2000"]) < 2e-5
     with wave.open(str(out / "uttA_gen.wav")) as f:
         assert f.getnframes() == 20800 and f.getsampwidth() == 2
+    # ragged batches over a dataset: same waveforms as one at a time
+    extra = synth_features(1, 77, 13, seed=3)[0]
+    np.save(dump / "uttB-feats.npy", extra)
+    got_b = {}
+    model_b = _OracleBackedModel(E2W_PARAMS, sd)
+    n, rtf = D.decode_dataset(model_b, D.iter_features(dumpdir=str(dump)), config, "cpu", str(out), batch_size=4,
+                              writer=lambda p, y, sr: got_b.__setitem__(os.path.basename(p), y))
+    assert n == 2 and rtf > 0 and model_b.calls == [((2, 13, 260), 25, [77, 260])]
+    assert rel_err(got_b["uttA_gen.wav"], gold["out_bms2000"]) < 2e-5 and len(got_b["uttB_gen.wav"]) == 77 * 80
+    (dump / "uttB-feats.npy").unlink()
     # WSOLA variant: half-overlapping 100-frame chunks, one wav + one input .npy per chunk
     gw = np.load(os.path.join(GOLDEN, "gold_arloop_wsola.npz"))
     config_w = dict(config, batch_max_steps=8000, wsola=True)
