@@ -108,7 +108,7 @@ def load_library():
     lib.hificar_ar_loop.restype = ctypes.c_int
     lib.hificar_forward_ragged.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
     lib.hificar_forward_ragged.restype = ctypes.c_int
-    lib.hificar_ar_loop_ragged.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.hificar_ar_loop_ragged.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
     lib.hificar_ar_loop_ragged.restype = ctypes.c_int
     lib.hificar_macs.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.hificar_macs.restype = ctypes.c_double

@@ -80,10 +80,14 @@ def ar_loop_ragged(model, xs, config):
     """xs: list of (T_i, num_feats) tensors of any lengths -> list of (hop * T_i,) waveforms; every utterance gets the
     result of ``ar_loop`` on it alone (its own short tail chunk included), all of them in one device call."""
     in_chunk_len, _ = _chunk_frames(config)
-    padded, lens = pad_utterances(xs)
+    order = sorted(range(len(xs)), key=lambda i: -int(xs[i].shape[0]))  # longest first: later AR steps run on a shrinking prefix
+    padded, lens = pad_utterances([xs[i] for i in order])
     y = model.ar_synthesis(padded.permute(0, 2, 1), in_chunk_len, lengths=lens)
     hop = y.shape[1] // padded.shape[1]
-    return [y[i, :hop * n] for i, n in enumerate(lens)]
+    out = [None] * len(xs)
+    for k, i in enumerate(order):
+        out[i] = y[k, :hop * lens[k]]
+    return out
 
 
 def length_batches(items, batch_size, window=8):

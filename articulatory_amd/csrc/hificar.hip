@@ -1085,8 +1085,9 @@ extern "C" int hificar_forward(hificar_handle* h, const float* c, const float* a
     return hificar_forward_ragged(h, c, ar, nullptr, out, B, T, workspace, workspace_bytes, stream);
 }
 
-extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const int32_t* lengths, float* out, int B, int T_total,
-                                      int chunk_frames, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const int32_t* lengths, const int32_t* lengths_host,
+                                      float* out, int B, int T_total, int chunk_frames, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
     if (h && !h->cfg.use_ar) return fail(HIFICAR_E_INVALID, "hificar_ar_loop on a model built with use_ar=false");
     if (chunk_frames < 1) return fail(HIFICAR_E_INVALID, "chunk_frames=%d must be positive", chunk_frames);
     int rc = check_ready(h, B, std::min(chunk_frames, std::max(T_total, 1)), workspace, workspace_bytes);
@@ -1096,16 +1097,33 @@ extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const i
     if (h->cfg.ar_input > h->hop * chunk_frames && T_total > chunk_frames)
         return fail(HIFICAR_E_INVALID, "ar_input (%d) > chunk audio length (%d): the reference loop (decode.py:79-81) is ill-formed there",
                     h->cfg.ar_input, h->hop * chunk_frames);
-    const int Tc = std::min(chunk_frames, T_total);
-    const Workspace ws = plan_workspace(h, B, Tc, workspace);
     const int64_t out_bstride = (int64_t)h->hop * T_total;
+    if (lengths_host && !lengths) return fail(HIFICAR_E_INVALID, "hificar_ar_loop_ragged: lengths_host without the device copy");
+    if (lengths_host)
+        for (int b = 0; b < B; ++b)
+            if (lengths_host[b] < 0 || lengths_host[b] > T_total)
+                return fail(HIFICAR_E_INVALID, "lengths[%d]=%d outside [0, %d]", b, lengths_host[b], T_total);
     for (int f0 = 0; f0 < T_total; f0 += chunk_frames) {
-        const int Tn = std::min(chunk_frames, T_total - f0);
+        int Tn = std::min(chunk_frames, T_total - f0);
+        // With the host copy of the lengths the step only covers the utterances still running: the batch prefix up to the
+        // last one longer than f0 (all of them when the batch is sorted longest first) and their longest remainder.
+        int Bn = B;
+        if (lengths_host) {
+            Bn = 0;
+            int longest = 0;
+            for (int b = 0; b < B; ++b)
+                if (lengths_host[b] > f0) {
+                    Bn = b + 1;
+                    longest = std::max(longest, lengths_host[b] - f0);
+                }
+            if (Bn == 0) break;
+            Tn = std::min(Tn, longest);
+        }
         const int64_t pos = (int64_t)h->hop * f0;
         // prev = last ar_input samples already written for this utterance (zeros for the first chunk)
         const float* prev = f0 == 0 ? nullptr : out + pos - h->cfg.ar_input;
-        rc = forward_impl(h, c + f0, (int64_t)h->cf * T_total, T_total, prev, out_bstride, out + pos, out_bstride, B, Tn, ws,
-                          static_cast<hipStream_t>(stream), lengths, f0);
+        rc = forward_impl(h, c + f0, (int64_t)h->cf * T_total, T_total, prev, out_bstride, out + pos, out_bstride, Bn, Tn,
+                          plan_workspace(h, Bn, Tn, workspace), static_cast<hipStream_t>(stream), lengths, f0);
         if (rc != HIFICAR_OK) return rc;
     }
     return HIFICAR_OK;
@@ -1113,7 +1131,7 @@ extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const i
 
 extern "C" int hificar_ar_loop(hificar_handle* h, const float* c, float* out, int B, int T_total, int chunk_frames,
                                void* workspace, size_t workspace_bytes, void* stream) {
-    return hificar_ar_loop_ragged(h, c, nullptr, out, B, T_total, chunk_frames, workspace, workspace_bytes, stream);
+    return hificar_ar_loop_ragged(h, c, nullptr, nullptr, out, B, T_total, chunk_frames, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -192,6 +192,17 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         if (mp.sched_start) return mp.sched_tiles[sched_lo + i];
         return (int)blockIdx.x + (my_rounds - 1 - i) * (int)gridDim.x;
     };
+    // ragged batches: tiles past the end of their sequence are skipped by both roles (same predicate, so the barrier
+    // counts stay in step); nxt(i) = first non-empty position of this workgroup's list at or after i
+    auto nxt = [&](int i) {
+        if (mp.p[0].seq_len)
+            while (i < my_rounds) {
+                const Tile T = decode(tile_of(i));
+                if (T.t0 < seq_rows(mp.p[T.b], T.seq)) break;
+                ++i;
+            }
+        return i;
+    };
     const float* O = reinterpret_cast<const float*>(smem_b + 2 * buf_bytes);
     // Output pass of a finished tile: the MFMA waves left the raw accumulators in the LDS out-buffer as
     // O[time row][channel]; the participating threads (the 256 loader threads, or all 512 for the last tile) walk it row-major (a wave-instruction covers whole 512-byte
@@ -308,7 +319,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         HIFICAR_STAMP(0);
         bool have_prev = false;
         Tile Tprev;
-        for (int it = 0; it < my_rounds; ++it) {
+        for (int it = nxt(0); it < my_rounds; it = nxt(it + 1)) {
             const Tile T = decode(tile_of(it));
             for (int c = 0; c < nchunks; ++c, ++j) {
                 dma_item(T, c, j);
@@ -401,8 +412,11 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     };
 
     int j = 0;
+    int last = -1;  // position of the last tile computed
     HIFICAR_STAMP(0);
-    for (int it = 0; it < my_rounds; ++it) {
+    for (int it = nxt(0), itn; it < my_rounds; it = itn) {
+        itn = nxt(it + 1);
+        last = it;
         const Tile T = decode(tile_of(it));
         const ConvParams& p = mp.p[T.b];
         const int nb = T.ng * WN + wn;
@@ -413,7 +427,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         const int ntaps = p.ntaps;
         // after this tile's stream is exhausted the loads continue with the NEXT tile's first tap-groups, so its ring is
         // primed when it starts (the last tile re-reads its own head: harmless)
-        const Tile Tn = decode(tile_of(it + 1 < my_rounds ? it + 1 : it));
+        const Tile Tn = decode(tile_of(itn < my_rounds ? itn : it));
         const frag_t* wp_next = wstream(Tn);
         const int groups_next = nchunks * mp.p[Tn.b].ntaps;
         if (active && !primed) prime(T);  // first tile, or this wave sat out the previous tile (partial channel group)
@@ -512,7 +526,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         }
     }
     __syncthreads();  // matches the loader waves' final barrier
-    if (my_rounds > 0) write_out(decode(tile_of(my_rounds - 1)), tid, 512);
+    if (last >= 0) write_out(decode(tile_of(last)), tid, 512);
 }
 
 template <int MI, int WM, int WN, int NC16>
@@ -612,6 +626,16 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         if (mp.sched_start) return mp.sched_tiles[sched_lo + i];
         return (int)blockIdx.x + (my_rounds - 1 - i) * (int)gridDim.x;
     };
+    auto nxt = [&](int i) {  // first non-empty position at or after i (ragged batches; see conv_ws_body)
+        if (mp.p1[0].seq_len)
+            while (i < my_rounds) {
+                const Tile T = decode(tile_of(i));
+                if (T.t0 < seq_rows(mp.p1[T.b], T.seq)) break;
+                ++i;
+            }
+        return i;
+    };
+    const int first = nxt(0);
     const float* O = reinterpret_cast<const float*>(smem_b + o_off);
     auto write_out = [&](const Tile& T, int ltid, int nthr) {
         const ConvParams& p = mp.p2[T.b];
@@ -694,23 +718,24 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
             }
         };
         Tile Tprev;
-        if (my_rounds > 0) dma_in(decode(tile_of(0)));
-        for (int it = 0; it < my_rounds; ++it) {
+        if (first < my_rounds) dma_in(decode(tile_of(first)));
+        for (int it = first, itn; it < my_rounds; it = itn) {
+            itn = nxt(it + 1);
             const Tile T = decode(tile_of(it));
             HIFICAR_STAMP(4 * it);
             __syncthreads();                 // A: input of tile `it` landed (hipcc drains vmcnt first)
             HIFICAR_STAMP(4 * it + 1);
-            if (it > 0) write_out(Tprev, ltid, 256);  // hidden behind conv1 of this tile
+            if (it != first) write_out(Tprev, ltid, 256);  // hidden behind conv1 of this tile
             HIFICAR_STAMP(4 * it + 2);
             __syncthreads();                 // F: shared region free
             __syncthreads();                 // B: TS complete, input buffer free
             HIFICAR_STAMP(4 * it + 3);
-            if (it + 1 < my_rounds) dma_in(decode(tile_of(it + 1)));  // hidden behind conv2
+            if (itn < my_rounds) dma_in(decode(tile_of(itn)));  // hidden behind conv2
             __syncthreads();                 // C: conv2 done reading TS
             Tprev = T;
         }
         __syncthreads();                     // Z: the last tile's accumulators are in the out-buffer
-        if (my_rounds > 0) write_out(Tprev, tid, 512);  // all eight waves share the final output pass
+        if (first < my_rounds) write_out(Tprev, tid, 512);  // all eight waves share the final output pass
         return;
     }
 
@@ -722,8 +747,8 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
     int groups_left = 0;
     auto stream1 = [&](const Tile& T) { return mp.p1[T.b].w16 + (size_t)wn * mp.p1[T.b].ntaps * NC16 * 128 + lane; };
     auto stream2 = [&](const Tile& T) { return mp.p2[T.b].w16 + (size_t)wn * mp.p2[T.b].ntaps * NC16 * 128 + lane; };
-    if (my_rounds > 0) {
-        const Tile T0 = decode(tile_of(0));
+    if (first < my_rounds) {
+        const Tile T0 = decode(tile_of(first));
         wp = stream1(T0);
 #pragma unroll
         for (int u = 0; u < NC16; ++u) {
@@ -811,13 +836,16 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         }
     };
 
-    for (int it = 0; it < my_rounds; ++it) {
+    int last = -1;
+    for (int it = first, itn; it < my_rounds; it = itn) {
+        itn = nxt(it + 1);
+        last = it;
         const Tile T = decode(tile_of(it));
         const ConvParams& p1 = mp.p1[T.b];
         const ConvParams& p2 = mp.p2[T.b];
         const int k2 = p2.ntaps;
         const int pad2 = (k2 - 1) >> 1;
-        const Tile Tn = decode(tile_of(it + 1 < my_rounds ? it + 1 : it));
+        const Tile Tn = decode(tile_of(itn < my_rounds ? itn : it));
         const int Ls = seq_rows(p1, T.seq);
         HIFICAR_STAMP(6 * it);
         __syncthreads();  // A: input landed
@@ -875,7 +903,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         }
     }
     __syncthreads();  // Z
-    if (my_rounds > 0) write_out(decode(tile_of(my_rounds - 1)), tid, 512);
+    if (last >= 0) write_out(decode(tile_of(last)), tid, 512);
 }
 
 // MRF mean + LeakyReLU + split for the upsample convs' input: out = split(lrelu(((x0 + x1) + x2) / n, slope)).

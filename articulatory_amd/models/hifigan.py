@@ -379,7 +379,7 @@ class HiFiGANGenerator(torch.nn.Module):
             raise RuntimeError(f"lengths has {lengths.numel()} entries for a batch of {B}")
         if int(lengths.min()) < 0 or int(lengths.max()) > T:
             raise RuntimeError(f"lengths must lie in [0, {T}]")
-        return lengths.to(device).contiguous()
+        return lengths.contiguous(), lengths.to(device).contiguous()  # (host copy, device copy)
 
     def forward(self, c, spk_id=None, ar=None, ph=None, lengths=None):
         """c: (B, in_channels[-ar_output], T) -> (B, out_channels, T * prod(upsample_scales))  (hifigan.py:198-239).
@@ -399,7 +399,7 @@ class HiFiGANGenerator(torch.nn.Module):
         if lengths is None:
             out = torch.empty((B, 1, T * self.hop), dtype=torch.float32, device=c.device)
         else:
-            lengths = self._lengths_arg(lengths, B, T, c.device)
+            _, lengths = self._lengths_arg(lengths, B, T, c.device)
             out = torch.zeros((B, 1, T * self.hop), dtype=torch.float32, device=c.device)
         with torch.cuda.device(c.device):
             ws_ptr, ws_bytes = self._workspace(B, T)
@@ -428,12 +428,13 @@ class HiFiGANGenerator(torch.nn.Module):
         if lengths is None:
             out = torch.empty((B, T * self.hop), dtype=torch.float32, device=c.device)
         else:
-            lengths = self._lengths_arg(lengths, B, T, c.device)
+            lengths_host, lengths = self._lengths_arg(lengths, B, T, c.device)
             out = torch.zeros((B, T * self.hop), dtype=torch.float32, device=c.device)
         with torch.cuda.device(c.device):
             ws_ptr, ws_bytes = self._workspace(B, min(int(chunk_frames), T))
             stream = torch.cuda.current_stream().cuda_stream
             rc = self._lib.hificar_ar_loop_ragged(handle, c.data_ptr(), lengths.data_ptr() if lengths is not None else None,
+                                                  lengths_host.data_ptr() if lengths is not None else None,
                                                   out.data_ptr(), B, T, int(chunk_frames), ws_ptr, ws_bytes, ctypes.c_void_p(stream))
         _native.check(rc, "hificar_ar_loop")
         return out

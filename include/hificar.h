@@ -123,8 +123,11 @@ int hificar_ar_loop(hificar_handle* h, const float* c, float* out, int B, int T_
  * decode.py:292-351 run B utterances at a time. */
 int hificar_forward_ragged(hificar_handle* h, const float* c, const float* ar, const int32_t* lengths, float* out, int B,
                            int T, void* workspace, size_t workspace_bytes, void* stream);
-int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const int32_t* lengths, float* out, int B, int T_total,
-                           int chunk_frames, void* workspace, size_t workspace_bytes, void* stream);
+int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const int32_t* lengths, const int32_t* lengths_host, float* out,
+                           int B, int T_total, int chunk_frames, void* workspace, size_t workspace_bytes, void* stream);
+/* lengths_host: optional HOST copy of the same B values (NULL = unknown to the host).  With it, every AR step is launched
+ * only over the utterances still running — the batch prefix up to the last one longer than the step's first frame, i.e.
+ * all of them and nothing else when the batch is sorted longest first — instead of masking finished ones on the device. */
 
 /* float waveform in [-1, 1] -> 16-bit PCM on the device: y = clip(round_half_even(x * 32767), -32768, 32767).
  * What the reference's sf.write(..., "PCM_16") does on the host after the device->host copy
