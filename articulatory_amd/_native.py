@@ -31,6 +31,7 @@ SYMBOLS = (
     "hificar_ar_loop",
     "hificar_forward_ragged",
     "hificar_ar_loop_ragged",
+    "hificar_ar_loop_packed",
     "hificar_macs",
     "hificar_pcm16",
     "hificar_profile_begin",
@@ -110,6 +111,8 @@ def load_library():
     lib.hificar_forward_ragged.restype = ctypes.c_int
     lib.hificar_ar_loop_ragged.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
     lib.hificar_ar_loop_ragged.restype = ctypes.c_int
+    lib.hificar_ar_loop_packed.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.hificar_ar_loop_packed.restype = ctypes.c_int
     lib.hificar_macs.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.hificar_macs.restype = ctypes.c_double
     lib.hificar_pcm16.argtypes = [vp, vp, ctypes.c_size_t, vp]

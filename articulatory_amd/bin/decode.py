@@ -76,18 +76,31 @@ def pad_utterances(xs):
     return out, lens
 
 
-def ar_loop_ragged(model, xs, config):
+def ar_loop_ragged(model, xs, config, batch=64):
     """xs: list of (T_i, num_feats) tensors of any lengths -> list of (hop * T_i,) waveforms; every utterance gets the
-    result of ``ar_loop`` on it alone (its own short tail chunk included), all of them in one device call."""
+    result of ``ar_loop`` on it alone (its own short tail chunk included).  One device call for the whole list: at most
+    ``batch`` utterances are in flight and a finished one is replaced by the next (longest first, so the tail is short)."""
     in_chunk_len, _ = _chunk_frames(config)
-    order = sorted(range(len(xs)), key=lambda i: -int(xs[i].shape[0]))  # longest first: later AR steps run on a shrinking prefix
+    order = sorted(range(len(xs)), key=lambda i: -int(xs[i].shape[0]))
     padded, lens = pad_utterances([xs[i] for i in order])
-    y = model.ar_synthesis(padded.permute(0, 2, 1), in_chunk_len, lengths=lens)
+    y = model.ar_synthesis_packed(padded.permute(0, 2, 1), in_chunk_len, lens, batch=batch)
     hop = y.shape[1] // padded.shape[1]
     out = [None] * len(xs)
     for k, i in enumerate(order):
         out[i] = y[k, :hop * lens[k]]
     return out
+
+
+def windows(items, n):
+    """Consecutive groups of up to n items of an iterable (bounded memory for a whole-dataset decode)."""
+    buf = []
+    for it in items:
+        buf.append(it)
+        if len(buf) >= n:
+            yield buf
+            buf = []
+    if buf:
+        yield buf
 
 
 def length_batches(items, batch_size, window=8):
@@ -165,11 +178,12 @@ def decode_dataset(model, items, config, device, outdir, normalize_before=False,
     if batch_size > 1 and not do_wsola:
         with torch.no_grad():
             feats = ((u, torch.tensor(c, dtype=torch.float).to(device)) for u, c in items)
-            for batch in length_batches(feats, batch_size):
+            # AR: a window of 8 batches per device call, continuously batched; non-AR: rectangular-ish batches
+            for batch in (windows(feats, 8 * batch_size) if use_ar else length_batches(feats, batch_size)):
                 start = time.time()
                 xs = [c for _, c in batch]
                 if use_ar:
-                    ys = ar_loop_ragged(model, xs, config)
+                    ys = ar_loop_ragged(model, xs, config, batch=batch_size)
                 else:
                     if normalize_before:
                         xs = [(c - model.mean) / model.scale for c in xs]

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import yaml
 
-from articulatory_amd.bin.decode import ar_loop, ar_loop_ragged, length_batches
+from articulatory_amd.bin.decode import ar_loop, ar_loop_ragged, windows
 from articulatory_amd.utils import load_model
 
 
@@ -77,8 +77,8 @@ def synthesize_file_list(model, fids, featps, config, device, outdir, batch_size
 
     with torch.no_grad():
         if use_ar and batch_size > 1:
-            for batch in length_batches(kept(), batch_size):
-                ys = [ar_loop(model, batch[0][1], config)] if len(batch) == 1 else ar_loop_ragged(model, [c for _, c in batch], config)
+            for batch in windows(kept(), 8 * batch_size):  # one device call per window, batch_size utterances in flight
+                ys = [ar_loop(model, batch[0][1], config)] if len(batch) == 1 else ar_loop_ragged(model, [c for _, c in batch], config, batch=batch_size)
                 for (fid, _), y in zip(batch, ys):
                     writer(os.path.join(outdir, fid + ".wav"), y.cpu().numpy(), config["sampling_rate"])
                     written.append(fid)

@@ -90,6 +90,10 @@ struct hificar_handle {
     float* d_mlp_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs;
     char* d_zeros = nullptr;  // 256 bytes of zeros: source of padding rows for the LDS DMA
+    void* d_tab = nullptr;    // step table of hificar_ar_loop_packed (grown on demand) and its pinned host staging copy
+    void* h_tab = nullptr;
+    size_t tab_bytes = 0;
+    hipEvent_t tab_copied = nullptr;  // recorded behind the last upload: the staging copy may be rewritten once it has fired
     // tile schedules (LPT assignment of tiles to workgroups), cached per launch shape
     struct Sched {
         int* d_start = nullptr;
@@ -330,6 +334,9 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
 extern "C" void hificar_destroy(hificar_handle* h) {
     if (!h) return;
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->d_tab) (void)hipFree(h->d_tab);
+    if (h->h_tab) (void)hipHostFree(h->h_tab);
+    if (h->tab_copied) (void)hipEventDestroy(h->tab_copied);
     for (auto& kv : h->scheds) {
         (void)hipFree(kv.second.d_start);
         (void)hipFree(kv.second.d_tiles);
@@ -911,7 +918,7 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
 //   out: sample (b, n) at out[b*out_bstride + n]
 static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, int64_t c_cstride, const float* prev,
                         int64_t prev_bstride, float* out, int64_t out_bstride, int B, int T, const Workspace& ws,
-                        hipStream_t stream, const int32_t* seq_len = nullptr, int f0 = 0) {
+                        hipStream_t stream, const int32_t* seq_len = nullptr, int f0 = 0, const int2* slots = nullptr) {
     const hificar_config& cfg = h->cfg;
     Ragged rg;
     rg.seq_len = seq_len;
@@ -925,6 +932,9 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     fp.c_cstride = c_cstride;
     fp.prev = prev;
     fp.prev_bstride = prev_bstride;
+    fp.slots = slots;
+    fp.valid = seq_len;
+    fp.hop = h->hop;
     const bool f32 = h->precision == HIFICAR_PREC_F32;
     fp.xin = f32 ? ws.xin : nullptr;
     fp.xin_s = f32 ? nullptr : reinterpret_cast<char*>(ws.xin);
@@ -1049,6 +1059,8 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     op.len_f0 = f0;
     op.len_max = T;
     op.len_mul = rows / T;
+    op.slots = slots;
+    op.hop = h->hop;
     const size_t lds = ((size_t)(256 + op.K - 1) * (op.C + 1) + (size_t)op.K * op.C) * sizeof(float);
     {
         const double pos = (double)B * rows;
@@ -1125,6 +1137,91 @@ extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const i
         rc = forward_impl(h, c + f0, (int64_t)h->cf * T_total, T_total, prev, out_bstride, out + pos, out_bstride, Bn, Tn,
                           plan_workspace(h, Bn, Tn, workspace), static_cast<hipStream_t>(stream), lengths, f0);
         if (rc != HIFICAR_OK) return rc;
+    }
+    return HIFICAR_OK;
+}
+
+// Packed (continuously batched) AR synthesis: N utterances, at most `batch` of them in flight; as soon as one finishes the
+// next one takes its place, so every step but the last few runs a full batch whatever the lengths are.  The AR state of
+// an utterance is its own waveform so far, so a "slot" exists only in the host-side step table uploaded here.
+extern "C" int hificar_ar_loop_packed(hificar_handle* h, const float* c, const int32_t* lengths_host, float* out, int N, int T_max,
+                                      int chunk_frames, int batch, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (h && !h->cfg.use_ar) return fail(HIFICAR_E_INVALID, "hificar_ar_loop on a model built with use_ar=false");
+    if (chunk_frames < 1 || batch < 1 || N < 1 || T_max < 1)
+        return fail(HIFICAR_E_INVALID, "hificar_ar_loop_packed: N=%d, T_max=%d, chunk_frames=%d, batch=%d must be positive", N, T_max,
+                    chunk_frames, batch);
+    batch = std::min(batch, N);
+    int rc = check_ready(h, batch, std::min(chunk_frames, T_max), workspace, workspace_bytes);
+    if (rc != HIFICAR_OK) return rc;
+    if (!c || !out || !lengths_host) return fail(HIFICAR_E_INVALID, "hificar_ar_loop_packed: null argument");
+    if (h->cfg.ar_input > h->hop * chunk_frames && T_max > chunk_frames)
+        return fail(HIFICAR_E_INVALID, "ar_input (%d) > chunk audio length (%d): the reference loop (decode.py:79-81) is ill-formed there",
+                    h->cfg.ar_input, h->hop * chunk_frames);
+    for (int u = 0; u < N; ++u)
+        if (lengths_host[u] < 0 || lengths_host[u] > T_max)
+            return fail(HIFICAR_E_INVALID, "lengths[%d]=%d outside [0, %d]", u, lengths_host[u], T_max);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // step table: row s lists the utterances advanced by step s as (utterance, first frame) + their valid frames
+    struct Step {
+        int n, frames;
+    };
+    std::vector<Step> steps;
+    std::vector<int2> slots;
+    std::vector<int> valid;
+    {
+        std::vector<int> run, f0((size_t)N, 0);
+        int next = 0;
+        for (;;) {
+            while ((int)run.size() < batch && next < N) {
+                if (lengths_host[next] > 0) run.push_back(next);
+                ++next;
+            }
+            if (run.empty()) break;
+            Step st{(int)run.size(), 0};
+            for (int u : run) {
+                const int v = std::min(chunk_frames, lengths_host[u] - f0[u]);
+                slots.push_back(int2{u, f0[u]});
+                valid.push_back(v);
+                st.frames = std::max(st.frames, v);
+            }
+            slots.resize((slots.size() + 1) & ~(size_t)1);  // keep every row 16-byte aligned in both arrays
+            valid.resize(slots.size());
+            steps.push_back(st);
+            std::vector<int> keep;
+            for (int u : run) {
+                f0[u] += chunk_frames;
+                if (f0[u] < lengths_host[u]) keep.push_back(u);
+            }
+            run.swap(keep);
+        }
+    }
+    if (steps.empty()) return HIFICAR_OK;
+    const size_t tab_bytes = slots.size() * (sizeof(int2) + sizeof(int));
+    if (!h->tab_copied) HIP_TRY(hipEventCreateWithFlags(&h->tab_copied, hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(h->tab_copied));  // the previous upload has left the staging copy (long ago, normally)
+    if (tab_bytes > h->tab_bytes) {
+        if (h->d_tab) HIP_TRY(hipFree(h->d_tab));  // synchronises: no earlier call can still be reading it
+        if (h->h_tab) HIP_TRY(hipHostFree(h->h_tab));
+        h->d_tab = h->h_tab = nullptr;
+        h->tab_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_tab, tab_bytes * 2));
+        HIP_TRY(hipHostMalloc(&h->h_tab, tab_bytes * 2, hipHostMallocDefault));
+        h->tab_bytes = tab_bytes * 2;
+    }
+    int2* d_slots = static_cast<int2*>(h->d_tab);
+    int* d_valid = reinterpret_cast<int*>(d_slots + slots.size());
+    memcpy(h->h_tab, slots.data(), slots.size() * sizeof(int2));
+    memcpy(static_cast<char*>(h->h_tab) + slots.size() * sizeof(int2), valid.data(), valid.size() * sizeof(int));
+    // one asynchronous upload, ordered on the stream behind any earlier call that still reads the table
+    HIP_TRY(hipMemcpyAsync(h->d_tab, h->h_tab, tab_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(h->tab_copied, stream));
+    const int64_t out_bstride = (int64_t)h->hop * T_max;
+    size_t row = 0;
+    for (const Step& st : steps) {
+        rc = forward_impl(h, c, (int64_t)h->cf * T_max, T_max, out, out_bstride, out, out_bstride, st.n, st.frames,
+                          plan_workspace(h, st.n, st.frames, workspace), stream, d_valid + row, 0, d_slots + row);
+        if (rc != HIFICAR_OK) return rc;
+        row += ((size_t)st.n + 1) & ~(size_t)1;
     }
     return HIFICAR_OK;
 }

@@ -990,6 +990,12 @@ struct FrontParams {
     int ar_input, ar_hidden, ar_output;
     const float* wt[5];   // transposed Linear weights (in, out)
     const float* bs[5];
+    // packed mode (hificar_ar_loop_packed): sequence b of this step is utterance slots[b].x continuing at frame slots[b].y
+    // with valid[b] frames; c / prev are then the bases of the packed feature / waveform tensors (prev = waveform, row
+    // pitch prev_bstride, hop samples per frame): its AR context are the ar_input samples before hop * frame.
+    const int2* slots;
+    const int* valid;
+    int hop;
 };
 
 __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
@@ -1002,7 +1008,12 @@ __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
     const int ks = tid >> 6;  // wave index = K slice: each wave reduces an eighth of the input dimension
     int cur = 0;
     if (p.use_ar) {
-        for (int i = tid; i < p.ar_input; i += 512) act[0][i] = p.prev ? p.prev[(size_t)b * p.prev_bstride + i] : 0.f;
+        const float* prevp = p.prev ? p.prev + (size_t)b * p.prev_bstride : nullptr;
+        if (p.slots) {
+            const int2 sl = p.slots[b];
+            prevp = sl.y > 0 ? p.prev + (size_t)sl.x * p.prev_bstride + (size_t)p.hop * sl.y - p.ar_input : nullptr;
+        }
+        for (int i = tid; i < p.ar_input; i += 512) act[0][i] = prevp ? prevp[i] : 0.f;
         __syncthreads();
         int din = p.ar_input;
         for (int layer = 0; layer < 5; ++layer) {
@@ -1047,11 +1058,17 @@ __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
     // act[cur][0:ar_output] now holds the AR features
     const float* feats = act[cur];
     const int n = p.T * p.cin_pad;
+    size_t cbase = (size_t)b * p.c_bstride;
+    int tmax = p.T;
+    if (p.slots) {
+        cbase = (size_t)p.slots[b].x * p.c_bstride + p.slots[b].y;
+        tmax = p.valid[b];  // frames past the utterance's end may lie outside the packed tensor
+    }
     for (int idx = tid; idx < n; idx += 512) {
         const int t = idx / p.cin_pad;
         const int ch = idx - t * p.cin_pad;
         float v = 0.f;
-        if (ch < p.cf) v = p.c[(size_t)b * p.c_bstride + (size_t)ch * p.c_cstride + t];
+        if (ch < p.cf) v = t < tmax ? p.c[cbase + (size_t)ch * p.c_cstride + t] : 0.f;
         else if (p.use_ar && ch < p.cf + p.ar_output) v = feats[ch - p.cf];
         if (p.xin) p.xin[(size_t)b * n + idx] = v;
         if (p.xin_s) {
@@ -1085,6 +1102,8 @@ struct OutConvParams {
     int use_tanh;
     const int* seq_len;  // ragged batches, as in ConvParams (rows = samples)
     int len_f0, len_max, len_mul;
+    const int2* slots;   // packed mode, as in FrontParams: sequence -> (utterance, first frame); out is the packed waveform
+    int hop;
 };
 
 __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p) {
@@ -1135,7 +1154,8 @@ __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p)
             const float* wk = &ws[k * p.C];
             for (int ch = 0; ch < p.C; ++ch) s = fmaf(xr[ch], wk[ch], s);
         }
-        p.out[(size_t)seq * p.out_bstride + t] = p.use_tanh ? tanhf(s) : s;
+        const size_t obase = p.slots ? (size_t)p.slots[seq].x * p.out_bstride + (size_t)p.hop * p.slots[seq].y : (size_t)seq * p.out_bstride;
+        p.out[obase + t] = p.use_tanh ? tanhf(s) : s;
     }
 }
 

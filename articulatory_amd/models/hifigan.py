@@ -439,6 +439,29 @@ class HiFiGANGenerator(torch.nn.Module):
         _native.check(rc, "hificar_ar_loop")
         return out
 
+    def ar_synthesis_packed(self, c, chunk_frames, lengths, batch=64):
+        """Continuously batched autoregressive synthesis of a list of utterances (C ABI: hificar_ar_loop_packed).
+
+        c: (N, C, T_max) zero-padded features, ``lengths`` their N frame counts; at most ``batch`` utterances are in flight
+        and a finished one is replaced by the next of the list.  Returns (N, hop*T_max) with zeros past each utterance's
+        end; per utterance the reference's ``ar_loop`` result (articulatory/bin/decode.py:54-83)."""
+        if not self.use_ar:
+            raise RuntimeError("ar_synthesis needs a use_ar=True generator")
+        self._check_input(c)
+        c = c.to(torch.float32).contiguous()
+        N, _, T = c.shape
+        lengths_host, _ = self._lengths_arg(lengths, N, T, c.device)
+        handle = self._native_handle()
+        out = torch.zeros((N, T * self.hop), dtype=torch.float32, device=c.device)
+        batch = max(1, min(int(batch), N))
+        with torch.cuda.device(c.device):
+            ws_ptr, ws_bytes = self._workspace(batch, min(int(chunk_frames), T))
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = self._lib.hificar_ar_loop_packed(handle, c.data_ptr(), lengths_host.data_ptr(), out.data_ptr(), N, T,
+                                                  int(chunk_frames), batch, ws_ptr, ws_bytes, ctypes.c_void_p(stream))
+        _native.check(rc, "hificar_ar_loop_packed")
+        return out
+
     def inference(self, c, normalize_before=False):
         """(T, in_channels) -> (T * prod(upsample_scales), out_channels)  (hifigan.py:298-314)."""
         if not isinstance(c, torch.Tensor):

@@ -16,6 +16,7 @@
  *   hificar_ar_loop_ragged  ... or ar_loop(), one utterance at a time                    articulatory/bin/decode.py:292-351
  *                           (a batch of utterances of DIFFERENT lengths in one call; results per utterance are those of
  *                           the one-at-a-time loop, bit for bit)
+ *   hificar_ar_loop_packed  the same dataset loop, continuously batched (a finished utterance's place is taken by the next)
  *   hificar_pcm16           sf.write(..., "PCM_16") sample conversion articulatory/bin/decode.py:319-324
  *   hificar_workspace_bytes (torch's caching allocator does this implicitly in the reference)
  *   hificar_last_error      Python exceptions / assert           articulatory/models/hifigan.py:78-80
@@ -128,6 +129,16 @@ int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const int32_t* len
 /* lengths_host: optional HOST copy of the same B values (NULL = unknown to the host).  With it, every AR step is launched
  * only over the utterances still running — the batch prefix up to the last one longer than the step's first frame, i.e.
  * all of them and nothing else when the batch is sorted longest first — instead of masking finished ones on the device. */
+
+/* Packed ("continuously batched") AR synthesis of a whole list of utterances: c (N, C, T_max) and out (N, hop*T_max) on the
+ * device, lengths_host N frame counts on the HOST.  At most `batch` utterances are in flight; when one finishes, the next
+ * one of the list takes its place in the following step, so all steps but the last few run a full batch whatever the
+ * length distribution (list the utterances longest first for the shortest tail).  Per utterance the result is that of
+ * hificar_ar_loop on it alone, bit for bit; out[u, hop*lengths[u]:] is left untouched.
+ * workspace: hificar_workspace_bytes(h, batch, chunk_frames).  Stands in for the dataset loop of
+ * articulatory/bin/decode.py:292-351 / egs/ema/voc1/local/predict_wav.py:124-137. */
+int hificar_ar_loop_packed(hificar_handle* h, const float* c, const int32_t* lengths_host, float* out, int N, int T_max,
+                           int chunk_frames, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
 /* float waveform in [-1, 1] -> 16-bit PCM on the device: y = clip(round_half_even(x * 32767), -32768, 32767).
  * What the reference's sf.write(..., "PCM_16") does on the host after the device->host copy

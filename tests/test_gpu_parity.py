@@ -431,3 +431,29 @@ def test_decode_dataset_ragged_batches_on_device(car, tmp_path):
     assert n1 == n4 == 5 and rtf > 0 and sorted(one) == sorted(four)
     for k in one:
         assert one[k].shape == four[k].shape and np.array_equal(one[k], four[k]), k
+
+
+def test_packed_ar_loop_equals_one_at_a_time(car):
+    """hificar_ar_loop_packed (continuous batching: 3 utterances in flight out of 9, a finished one replaced by the next):
+    every utterance's waveform is bit-identical to synthesising it alone; zero-length and single-chunk utterances included."""
+    g, w = car
+    lens = [260, 131, 130, 99, 64, 26, 25, 7, 0]
+    Tm = max(lens)
+    x = synth_features(len(lens), Tm, 13, seed=515)
+    for b, n in enumerate(lens):
+        x[b, n:] = -3.0  # padding frames must not matter
+    feats = torch.from_numpy(x).permute(0, 2, 1).contiguous().cuda()
+    with torch.no_grad():
+        y = g.ar_synthesis_packed(feats, 25, lens, batch=3)
+        y_all = g.ar_synthesis_packed(feats, 25, lens, batch=64)
+    assert y.shape == (len(lens), 80 * Tm) and torch.equal(y, y_all)
+    for b, n in enumerate(lens):
+        assert float(y[b, 80 * n:].abs().sum()) == 0.0
+        if n:
+            with torch.no_grad():
+                alone = g.ar_synthesis(feats[b:b + 1, :, :n].contiguous(), 25)
+            assert torch.equal(y[b, :80 * n], alone[0]), (b, n)
+    ref = O.ar_loop(w, E2W_PARAMS, torch.from_numpy(x[1, :131]), 2000, 80)
+    assert rel_err(y[1, :80 * 131].cpu().numpy(), ref.numpy()) < g.tol
+    with pytest.raises(RuntimeError):
+        g.ar_synthesis_packed(feats, 25, lens[:-1])

@@ -139,6 +139,13 @@ class _OracleBackedModel:
             out[b, :80 * n] = O.ar_loop(self.w, self.params, c[b, :, :n].permute(1, 0), chunk_frames * 80, 80)
         return out
 
+    def ar_synthesis_packed(self, c, chunk_frames, lengths, batch=64):
+        self.calls.append((tuple(c.shape), chunk_frames, list(lengths), batch))
+        out = torch.zeros(c.shape[0], 80 * c.shape[2])  # each utterance alone, as the HIP path guarantees
+        for b, n in enumerate(lengths):
+            out[b, :80 * n] = O.ar_loop(self.w, self.params, c[b, :, :n].permute(1, 0), chunk_frames * 80, 80)
+        return out
+
     def __call__(self, c, ar=None):
         return O.generator_forward(self.w, self.params, c, ar)
 
@@ -186,12 +193,12 @@ def test_predict_wav_ragged_batches(tmp_path):
     outs = {}
     PW.synthesize_file_list(model, ["u0", "u1", "u2"], paths, config, "cpu", str(tmp_path), batch_size=2,
                             writer=lambda p, y, sr: outs.__setitem__(os.path.basename(p), y))
-    assert model.calls == [((2, 13, 260), 100, [260, 260]), ((1, 13, 300), 100)]  # sorted by length, cut into batches of 2
+    assert model.calls == [((3, 13, 300), 100, [300, 260, 260], 2)]  # one call: longest first, 2 utterances in flight
     outs3 = {}
     model3 = _OracleBackedModel(params, synth_state_dict(params, seed=1234))
     PW.synthesize_file_list(model3, ["u0", "u1", "u2"], paths, config, "cpu", str(tmp_path), batch_size=3,
                             writer=lambda p, y, sr: outs3.__setitem__(os.path.basename(p), y))
-    assert model3.calls == [((3, 13, 300), 100, [300, 260, 260])]  # one ragged batch, longest first, padded to it
+    assert model3.calls == [((3, 13, 300), 100, [300, 260, 260], 3)]
     assert {k: len(v) for k, v in outs3.items()} == {"u0.wav": 20800, "u1.wav": 24000, "u2.wav": 20800}
     for k in outs:
         assert rel_err(outs3[k], outs[k]) < 1e-6
@@ -241,7 +248,7 @@ def test_decode_cli_plumbing(tmp_path):
     model_b = _OracleBackedModel(E2W_PARAMS, sd)
     n, rtf = D.decode_dataset(model_b, D.iter_features(dumpdir=str(dump)), config, "cpu", str(out), batch_size=4,
                               writer=lambda p, y, sr: got_b.__setitem__(os.path.basename(p), y))
-    assert n == 2 and rtf > 0 and model_b.calls == [((2, 13, 260), 25, [260, 77])]
+    assert n == 2 and rtf > 0 and model_b.calls == [((2, 13, 260), 25, [260, 77], 4)]
     assert rel_err(got_b["uttA_gen.wav"], gold["out_bms2000"]) < 2e-5 and len(got_b["uttB_gen.wav"]) == 77 * 80
     (dump / "uttB-feats.npy").unlink()
     # WSOLA variant: half-overlapping 100-frame chunks, one wav + one input .npy per chunk
