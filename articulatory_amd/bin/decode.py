@@ -251,6 +251,10 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise RuntimeError("decode: no GPU visible; this package has no CPU synthesis path")
+    # under torchrun (one process per GPU) every rank decodes its own share of the list and writes its own files
+    from articulatory_amd.bin.shard import shard_items
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    items = shard_items(items, length_of=lambda kv: kv[1].shape[0])
     device = torch.device("cuda")
     model = load_model(args.checkpoint, config)
     logging.info(f"Loaded model parameters from {args.checkpoint}.")

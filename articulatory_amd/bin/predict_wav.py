@@ -112,6 +112,11 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise RuntimeError("predict_wav: no GPU visible; this package has no CPU synthesis path")
+    # under torchrun (one process per GPU) every rank synthesises its own share of the list and writes its own files
+    from articulatory_amd.bin.shard import shard_items
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    pairs = shard_items(list(zip(fids, featps)))
+    fids, featps = [p[0] for p in pairs], [p[1] for p in pairs]
     device = torch.device("cuda")
     model = load_model(args.checkpoint, config)
     logging.info(f"Loaded model parameters from {args.checkpoint}.")

@@ -21,6 +21,30 @@ def shard_range(n_items, world_size, rank):
     return rank * per, (rank + 1) * per
 
 
+def shard_items(items, world_size=None, rank=None, length_of=None):
+    """This rank's share of a list of utterances for file-to-file decoding (each rank writes its own wav files: no
+    collective at all).  With ``length_of`` utterances go longest first to the least-loaded rank, so that every rank gets
+    the same amount of audio (deterministic: all ranks compute the same deal).  world_size / rank default to the
+    torchrun environment."""
+    import os
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    if world_size <= 1:
+        return list(items)
+    items = list(items)
+    if length_of is None:
+        return items[rank::world_size]
+    load = [0] * world_size
+    mine = []
+    for i in sorted(range(len(items)), key=lambda i: (-length_of(items[i]), i)):
+        r = min(range(world_size), key=lambda q: (load[q], q))
+        load[r] += length_of(items[i])
+        if r == rank:
+            mine.append(i)
+    return [items[i] for i in sorted(mine)]
+
+
 def synthesize_sharded(synth_fn, feats, group=None):
     """Each rank synthesises its slice of ``feats`` (B, ...) with ``synth_fn`` and every rank receives all
     waveforms (B, n_samples) in the original utterance order.

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import E2W_PARAMS
-from articulatory_amd.bin.shard import shard_range, synthesize_sharded
+from articulatory_amd.bin.shard import shard_items, shard_range, synthesize_sharded
 
 
 def _free_port():
@@ -82,6 +82,15 @@ def test_sharded_synthesis_world2_gloo():
     assert status == "ok", err
     assert shape == (4, 2400)
     assert err < 1e-6  # each rank's slice equals the unsharded result (utterances are independent)
+
+
+def test_shard_items_deals_by_length():
+    items = [("a", 5), ("b", 50), ("c", 7), ("d", 40), ("e", 6), ("f", 45)]
+    shares = [shard_items(items, 2, r, length_of=lambda kv: kv[1]) for r in range(2)]
+    assert sorted(shares[0] + shares[1]) == sorted(items) and not set(shares[0]) & set(shares[1])
+    assert abs(sum(v for _, v in shares[0]) - sum(v for _, v in shares[1])) <= 20  # longest first to the least-loaded rank: 50+7+6+5 vs 45+40
+    assert shard_items(items, 1, 0) == items
+    assert shard_items(items, 3, 1) == [items[1], items[4]]
 
 
 def test_unsharded_passthrough():
