@@ -457,3 +457,46 @@ def test_packed_ar_loop_equals_one_at_a_time(car):
     assert rel_err(y[1, :80 * 131].cpu().numpy(), ref.numpy()) < g.tol
     with pytest.raises(RuntimeError):
         g.ar_synthesis_packed(feats, 25, lens[:-1])
+
+
+def test_cli_mains_end_to_end_on_device(tmp_path, monkeypatch):
+    """The two console-script counterparts, argv to wav files, on the device: reference-layout checkpoint + config.yml +
+    scp of .npy features; --batch-size 4 writes the same samples as the default one-at-a-time run; under a torchrun
+    environment (WORLD_SIZE=2) the two ranks' shares are disjoint and together complete."""
+    import wave
+    import yaml
+    from articulatory_amd.bin import decode as D, predict_wav as PW
+    params = dict(E2W_PARAMS)
+    sd = synth_state_dict(params, seed=1234)
+    ckpt = tmp_path / "checkpoint-1steps.pkl"
+    torch.save({"model": {"generator": {k: torch.from_numpy(v) for k, v in sd.items()}}}, ckpt)
+    with open(tmp_path / "config.yml", "w") as f:
+        yaml.dump(dict(generator_type="HiFiGANGenerator", generator_params=params, format="npy", sampling_rate=16000,
+                       hop_size=80, batch_max_steps=2000, dataset_mode="a2w"), f)
+    lens = [300, 260, 411, 275, 333]
+    with open(tmp_path / "feats.scp", "w") as f:
+        for i, T in enumerate(lens):
+            np.save(tmp_path / f"u{i}.npy", synth_features(1, T, 13, seed=90 + i)[0].astype(np.float64))
+            f.write(f"u{i} {tmp_path / f'u{i}.npy'}\n")
+
+    def read(path):
+        with wave.open(str(path)) as f:
+            return np.frombuffer(f.readframes(f.getnframes()), dtype="<i2")
+
+    def run(mod, outdir, *extra):
+        mod.main(["--feats-scp", str(tmp_path / "feats.scp"), "--outdir", str(outdir), "--checkpoint", str(ckpt), "--verbose", "0", *extra])
+
+    run(D, tmp_path / "d1")
+    run(D, tmp_path / "d4", "--batch-size", "4")
+    run(PW, tmp_path / "p4", "--batch-size", "4")
+    for i, T in enumerate(lens):
+        a = read(tmp_path / "d1" / f"u{i}_gen.wav")
+        assert len(a) == 80 * T
+        assert np.array_equal(a, read(tmp_path / "d4" / f"u{i}_gen.wav"))
+        assert np.array_equal(a, read(tmp_path / "p4" / f"u{i}.wav"))
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    for r in (0, 1):
+        monkeypatch.setenv("RANK", str(r))
+        run(D, tmp_path / f"r{r}", "--batch-size", "4")
+    got = [sorted(os.listdir(tmp_path / f"r{r}")) for r in (0, 1)]
+    assert not set(got[0]) & set(got[1]) and sorted(got[0] + got[1]) == sorted(os.listdir(tmp_path / "d1"))
