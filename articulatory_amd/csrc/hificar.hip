@@ -1184,7 +1184,7 @@ extern "C" int hificar_ar_loop_packed(hificar_handle* h, const float* c, const i
                 valid.push_back(v);
                 st.frames = std::max(st.frames, v);
             }
-            slots.resize((slots.size() + 1) & ~(size_t)1);  // keep every row 16-byte aligned in both arrays
+            slots.resize((slots.size() + 1) & ~(size_t)1);  // rows start on an even index in both arrays (int2 rows 16-byte aligned)
             valid.resize(slots.size());
             steps.push_back(st);
             std::vector<int> keep;
