@@ -751,9 +751,14 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
     // lock step: 3*MI MFMAs of 32 cycles per 16-channel K slab) plus a fixed per-tile and per-item overhead.
     TileCfgB tc = kTileCfgsB[8];
     double best = 1e300;
+    // dev override: HIFICAR_TILE="cin,MI,WM,WN" forces the shape for layers with that many input channels
+    static const char* force = getenv("HIFICAR_TILE");
+    int fc = 0, fmi = 0, fwm = 0, fwn = 0;
+    if (force) sscanf(force, "%d,%d,%d,%d", &fc, &fmi, &fwm, &fwn);
     for (const TileCfgB& t : kTileCfgsB) {
         const int TM = t.WM * t.MI * 32;
         if (2 * round_up_sz((size_t)(TM + halo_all) * RB, 1024) + out_buf_bytes(t) > 160 * 1024) continue;
+        if (fc == L0.cin_pad && nbr == 3 && !(t.MI == fmi && t.WM == fwm && t.WN == fwn)) continue;
         const long long tiles_per_branch = (long long)nseq * ((rows + TM - 1) / TM) * ((L0.n_blocks32 + t.WN - 1) / t.WN);
         const long long total = tiles_per_branch * nbr;
         const int G = (int)std::min<long long>(total, h->num_cus);

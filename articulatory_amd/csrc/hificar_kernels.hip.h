@@ -486,25 +486,37 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                     }
                 }
             } else {
-                for (int t = 0; t < ntaps; ++t) {
+                // one K slab per tap (NC16 == 1): the fragments of tap t+1 are read while tap t's MFMAs issue
+                static_assert(NC16 % 2 == 0 || NC16 == 1, "odd chunk sizes other than 16 channels are not instantiated");
+                frag_t x0h[MI], x0l[MI], x1h[MI], x1l[MI];
+                load_x(x0h, x0l, ad[0]);
+                auto tap = [&](const frag_t (&xh)[MI], const frag_t (&xl)[MI]) {
                     if (groups_left == 0) {
                         wp = wp_next;
                         groups_left = groups_next;
                     }
                     --groups_left;
-                    addr_set(buf_off, roff0 + t * tap_step, ad);
-#pragma unroll
-                    for (int u = 0; u < NC16; ++u) {
-                        frag_t xh[MI], xl[MI];
-                        load_x(xh, xl, ad[u]);
-                        const frag_t wh = bq[u][0], wl = bq[u][1];
-                        bq[u][0] = bn[u][0];
-                        bq[u][1] = bn[u][1];
-                        bn[u][0] = wp[u * 128];
-                        bn[u][1] = wp[u * 128 + 64];
-                        mfma_step(xh, xl, wh, wl);
-                    }
+                    const frag_t wh = bq[0][0], wl = bq[0][1];
+                    bq[0][0] = bn[0][0];
+                    bq[0][1] = bn[0][1];
+                    bn[0][0] = wp[0];
+                    bn[0][1] = wp[64];
                     wp += NC16 * 128;
+                    mfma_step(xh, xl, wh, wl);
+                };
+                for (int t = 0; t < ntaps; t += 2) {
+                    if (t + 1 < ntaps) {
+                        addr_set(buf_off, roff0 + (t + 1) * tap_step, ad);
+                        load_x(x1h, x1l, ad[0]);
+                    }
+                    tap(x0h, x0l);
+                    if (t + 1 < ntaps) {
+                        if (t + 2 < ntaps) {
+                            addr_set(buf_off, roff0 + (t + 2) * tap_step, ad);
+                            load_x(x0h, x0l, ad[0]);
+                        }
+                        tap(x1h, x1l);
+                    }
                 }
             }
         }
