@@ -27,4 +27,16 @@ for prec in ("bf16x3", "f32"):
                 bad += int(not torch.equal(g.ar_synthesis(x, chunk), ref))
         print(f"{prec} B={B} chunk={chunk}: {a.reps} repeats, {bad} differing", flush=True)
         assert bad == 0
+    # continuous batching over a mixed-length list (tile skipping, step table): repeated calls must agree bit for bit
+    import numpy as np
+    lens = [int(v) for v in np.random.default_rng(3).integers(20, 400, size=96)]
+    lens.sort(reverse=True)
+    x = torch.from_numpy(synth_features(len(lens), max(lens), 13, seed=9)).permute(0, 2, 1).contiguous().cuda()
+    with torch.no_grad():
+        ref = g.ar_synthesis_packed(x, 25, lens, batch=32).clone()
+        bad = sum(int(not torch.equal(g.ar_synthesis_packed(x, 25, lens, batch=32), ref)) for _ in range(a.reps // 2))
+        one = g.ar_synthesis(x[5:6, :, :lens[5]].contiguous(), 25)
+    print(f"{prec} packed 96 utterances, 32 in flight: {a.reps // 2} repeats, {bad} differing; utterance 5 == alone: "
+          f"{bool(torch.equal(ref[5, :80 * lens[5]], one[0]))}", flush=True)
+    assert bad == 0 and torch.equal(ref[5, :80 * lens[5]], one[0])
 print("soak ok")
