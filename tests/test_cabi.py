@@ -98,3 +98,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "libhificar.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _native.load_library()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/hificar.h is a C ABI: it must compile as C99 on its own (no C++ / HIP / torch types)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "t.c"
+    src.write_text('#include "hificar.h"\nint main(void) { return hificar_version() == 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
