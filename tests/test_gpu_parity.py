@@ -392,6 +392,16 @@ def test_ragged_batch_equals_one_at_a_time(car):
             ref = O.ar_loop(w, E2W_PARAMS, torch.from_numpy(x[b, :n]), 2000, 80)
         assert torch.equal(y[b, :80 * n], alone[0]), (b, n)
         assert rel_err(y[b, :80 * n].cpu().numpy(), ref.numpy()) < g.tol, (b, n)
+    # one chunk through hificar_forward_ragged with an AR context per utterance
+    ar = torch.from_numpy(synth_features(len(lens), 512, 1, seed=8)[:, :, 0] * 0.3).reshape(len(lens), 1, 512).cuda()
+    flens = [min(n, 25) for n in lens]
+    with torch.no_grad():
+        yf = g(feats[:, :, :25].contiguous(), ar=ar, lengths=flens)
+        for b, n in enumerate(flens):
+            if n:
+                alone = g(feats[b:b + 1, :, :n].contiguous(), ar=ar[b:b + 1])
+                assert torch.equal(yf[b, :, :80 * n], alone[0]), (b, n)
+            assert float(yf[b, :, 80 * n:].abs().sum()) == 0.0
 
 
 def test_ragged_forward_non_ar(prec):
