@@ -1066,11 +1066,15 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     op.len_mul = rows / T;
     op.slots = slots;
     op.hop = h->hop;
-    const size_t lds = ((size_t)(256 + op.K - 1) * (op.C + 1) + (size_t)op.K * op.C) * sizeof(float);
+    // samples per workgroup: 256, or what a 64-KB LDS tile of (TR + K - 1) rows x (C + 1) floats + the weights allows
+    const long long fit = ((long long)64 * 1024 / 4 - (long long)op.K * op.C) / (op.C + 1) - (op.K - 1);
+    if (fit < 1) return fail(HIFICAR_E_INVALID, "output conv: %d channels x kernel %d does not fit the LDS tile", op.C, op.K);
+    op.TR = (int)std::min<long long>(256, fit);
+    const size_t lds = ((size_t)(op.TR + op.K - 1) * (op.C + 1) + (size_t)op.K * op.C) * sizeof(float);
     {
         const double pos = (double)B * rows;
         ProfScope prof(h, stream, "output_conv_kernel", 2.0 * pos * op.C * op.K, 4.0 * pos * (op.C * nbk + 1));
-        hipLaunchKernelGGL(output_conv_kernel, dim3((rows + 255) / 256, B), dim3(256), lds, stream, op);
+        hipLaunchKernelGGL(output_conv_kernel, dim3((rows + op.TR - 1) / op.TR, B), dim3(256), lds, stream, op);
     }
     HIP_TRY(hipGetLastError());
     return HIFICAR_OK;

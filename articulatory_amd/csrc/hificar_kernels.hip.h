@@ -1116,15 +1116,16 @@ struct OutConvParams {
     int len_f0, len_max, len_mul;
     const int2* slots;   // packed mode, as in FrontParams: sequence -> (utterance, first frame); out is the packed waveform
     int hop;
+    int TR;              // output samples per workgroup (<= 256; fewer when C is wide, so that the LDS tile fits)
 };
 
 __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int seq = blockIdx.y;
-    const int t0 = blockIdx.x * 256;
+    const int t0 = blockIdx.x * p.TR;
     const int pad = (p.K - 1) / 2;
-    const int R = 256 + p.K - 1;
+    const int R = p.TR + p.K - 1;
     const int P = p.C + 1;
     float* ws = smem + R * P;  // weights [k][C]
     for (int i = tid; i < p.K * p.C; i += 256) ws[i] = p.w[i];
@@ -1159,7 +1160,7 @@ __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p)
     }
     __syncthreads();
     const int t = t0 + tid;
-    if (t < Ls) {
+    if (tid < p.TR && t < Ls) {
         float s = p.bias;
         for (int k = 0; k < p.K; ++k) {
             const float* xr = &smem[(tid + k) * P];

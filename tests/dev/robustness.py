@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Parity of both arithmetics under unfriendly weight / input scales (vs the CPU oracle on the same box)."""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 import numpy as np, torch
 from articulatory_amd.models import HiFiGANGenerator

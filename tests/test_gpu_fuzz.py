@@ -1,0 +1,73 @@
+"""Seeded random-configuration parity fuzz of the HIP path against the CPU oracle (``pytest -m gpu``).
+Hyper-parameters, batch, length, ragged lengths and arithmetic are drawn at random from what hificar_create
+accepts; HIFICAR_FUZZ_CASES raises the number of cases (default 16, a few seconds each on the GPU box)."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import E2W_PARAMS, rel_err
+from articulatory_amd.models import HiFiGANGenerator
+from articulatory_amd.utils.synth import synth_features, synth_state_dict
+from oracle import hificar_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOLS = {"f32": 2e-5, "bf16x3": 2e-4}
+N_CASES = int(os.environ.get("HIFICAR_FUZZ_CASES", "16"))
+
+
+def draw(rng):
+    n_stages = int(rng.integers(1, 5))
+    channels = int(rng.choice([c for c in (64, 128, 256, 512) if c >> n_stages >= 32] or [512]))
+    while channels >> n_stages < 32:
+        n_stages -= 1
+    scales = [int(rng.choice([2, 3, 4, 5, 8])) for _ in range(n_stages)]
+    n_blocks = int(rng.integers(1, 4))
+    ks = [int(rng.choice([3, 5, 7, 9, 11])) for _ in range(n_blocks)]
+    dils = [[int(rng.integers(1, 7)) for _ in range(int(rng.integers(1, 4)))] for _ in range(n_blocks)]
+    use_ar = bool(rng.integers(0, 2))
+    cf = int(rng.integers(1, 90))
+    params = dict(E2W_PARAMS, channels=channels, kernel_size=int(rng.choice([3, 5, 7, 9])), upsample_scales=scales,
+                  upsample_kernel_sizes=[2 * s for s in scales], resblock_kernel_sizes=ks, resblock_dilations=dils,
+                  use_ar=use_ar, in_channels=cf + (128 if use_ar else 0), bias=bool(rng.integers(0, 4)),
+                  use_tanh=bool(rng.integers(0, 4)),
+                  nonlinear_activation_params={"negative_slope": float(rng.choice([0.1, 0.2, 0.01, 0.5]))})
+    return params, cf
+
+
+@pytest.mark.parametrize("case", range(N_CASES))
+def test_random_configuration(case):
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(1000 + case)
+    params, cf = draw(rng)
+    prec = "f32" if case % 2 else "bf16x3"
+    hop = int(np.prod(params["upsample_scales"]))
+    sd = synth_state_dict(params, seed=500 + case)
+    g = HiFiGANGenerator(**params, precision=prec)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    g.remove_weight_norm()
+    g = g.eval().cuda()
+    w = O.fold_weight_norm(sd)
+    B = int(rng.integers(1, 6))
+    T = int(rng.integers(1, 70))
+    lens = [int(v) for v in rng.integers(0, T + 1, size=B)]
+    lens[int(rng.integers(0, B))] = T
+    x = synth_features(B, T, cf, seed=case)
+    c = torch.from_numpy(x).permute(0, 2, 1).contiguous()
+    ar = torch.from_numpy(synth_features(B, 512, 1, seed=case + 1)[:, :, 0] * 0.3).reshape(B, 1, 512) if params["use_ar"] else None
+    with torch.no_grad():
+        y = g(c.cuda(), ar=ar.cuda() if ar is not None else None).cpu()
+        yr = g(c.cuda(), ar=ar.cuda() if ar is not None else None, lengths=lens).cpu()
+        ref = O.generator_forward(w, params, c, ar)
+    tag = (case, prec, {k: params[k] for k in ("channels", "kernel_size", "upsample_scales", "resblock_kernel_sizes",
+                                                "resblock_dilations", "use_ar", "in_channels", "bias")}, B, T, lens)
+    assert y.shape == ref.shape == (B, 1, hop * T), tag
+    assert rel_err(y.numpy(), ref.numpy()) < TOLS[prec], tag
+    for b, n in enumerate(lens):  # ragged: each utterance as if alone (zero padding at its own end), nothing beyond it
+        assert float(yr[b, :, hop * n:].abs().sum()) == 0.0, tag
+        if n:
+            with torch.no_grad():
+                alone = O.generator_forward(w, params, c[b:b + 1, :, :n], ar[b:b + 1] if ar is not None else None)
+            assert rel_err(yr[b:b + 1, :, :hop * n].numpy(), alone.numpy()) < TOLS[prec] * max(1.0, float(ref.abs().max() / alone.abs().max())), tag
