@@ -71,3 +71,42 @@ def test_random_configuration(case):
             with torch.no_grad():
                 alone = O.generator_forward(w, params, c[b:b + 1, :, :n], ar[b:b + 1] if ar is not None else None)
             assert rel_err(yr[b:b + 1, :, :hop * n].numpy(), alone.numpy()) < TOLS[prec] * max(1.0, float(ref.abs().max() / alone.abs().max())), tag
+
+
+@pytest.mark.parametrize("case", range(max(1, N_CASES // 2)))
+def test_random_ar_dataset(case):
+    """Random HiFi-CAR configuration, random chunk length, a random list of utterance lengths through the continuously
+    batched loop (random number in flight) and through the padded-batch loop: each utterance equals the oracle's batch-1
+    ``ar_loop`` (decode.py:54-83) and the two device paths agree bit for bit."""
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(7000 + case)
+    params, cf = draw(rng)
+    params.update(use_ar=True, in_channels=cf + 128)
+    prec = "bf16x3" if case % 2 else "f32"
+    hop = int(np.prod(params["upsample_scales"]))
+    chunk = int(rng.integers(-(-512 // hop), -(-512 // hop) + 20))  # ar_input <= hop * chunk (the reference's well-formed case)
+    sd = synth_state_dict(params, seed=900 + case)
+    g = HiFiGANGenerator(**params, precision=prec)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    g.remove_weight_norm()
+    g = g.eval().cuda()
+    w = O.fold_weight_norm(sd)
+    N = int(rng.integers(1, 7))
+    lens = sorted((int(v) for v in rng.integers(0, 3 * chunk + 2, size=N)), reverse=True)
+    if lens[0] == 0:
+        lens[0] = chunk + 1
+    Tm = lens[0]
+    x = synth_features(N, Tm, cf, seed=case)
+    feats = torch.from_numpy(x).permute(0, 2, 1).contiguous().cuda()
+    with torch.no_grad():
+        yp = g.ar_synthesis_packed(feats, chunk, lens, batch=int(rng.integers(1, N + 1)))
+        yr = g.ar_synthesis(feats, chunk, lengths=lens)
+    tag = (case, prec, chunk, lens, {k: params[k] for k in ("channels", "kernel_size", "upsample_scales", "resblock_kernel_sizes",
+                                                             "resblock_dilations", "in_channels")})
+    assert torch.equal(yp, yr), tag
+    for b, n in enumerate(lens):
+        assert float(yp[b, hop * n:].abs().sum()) == 0.0, tag
+        if n:
+            with torch.no_grad():
+                ref = O.ar_loop(w, params, torch.from_numpy(x[b, :n]), hop * chunk, hop)
+            assert rel_err(yp[b, :hop * n].cpu().numpy(), ref.numpy()) < TOLS[prec], tag
