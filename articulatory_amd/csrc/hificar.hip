@@ -849,7 +849,14 @@ struct PairIOB {
 };
 
 static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const ConvLayer& b) {
-    return h->use_pair && h->precision == HIFICAR_PREC_BF16X3 && a.d_w16c && b.d_w16c && a.cin == b.cin && a.ntaps >= 2 && b.ntaps >= 2 && b.dilation == 1 && a.K == b.K;
+    if (!(h->use_pair && h->precision == HIFICAR_PREC_BF16X3 && a.d_w16c && b.d_w16c && a.cin == b.cin && a.ntaps >= 2 &&
+          b.ntaps >= 2 && b.dilation == 1 && a.K == b.K))
+        return false;
+    // the LDS budget of launch_pair_bf16x3 (wide dilations x long kernels do not fit: those pairs run layer by layer)
+    const int C = a.cin, TMc = (C == 64 ? 2 : 4) * 4 * 32;
+    const size_t in_bytes = round_up_sz((size_t)(TMc + a.off_max - a.off_min) * C * 4, 1024);
+    const size_t ts_bytes = std::max<size_t>((size_t)(TMc + 16) * C * 4, (size_t)TMc * (C + 4) * sizeof(float));
+    return in_bytes + ts_bytes <= 160 * 1024;
 }
 
 static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, const ConvLayer* const* l2, int nbr, int nseq, int rows,
@@ -1011,11 +1018,17 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 if ((rc = launch_conv_bf16x3(h, lay, 1, B, rows, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
             }
             rows *= cfg.upsample_scales[i];
+            // activated stream of each branch: where the next conv1 reads its input.  It alternates between x_s[j] and
+            // xt_s[j]: a launch never writes the buffer it (or a neighbouring tile, through the halo) reads.
+            const char* cur_s[3] = {ws.u_s, ws.u_s, ws.u_s};
             for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
                 const ConvLayer* l1[3];
                 const ConvLayer* l2[3];
                 ConvIOB io1[3], io2[3];
                 PairIOB iop[3];
+                int jn[3];
+                char* pair_out[3];
+                char* lbl_out[3];
                 int n = 0;
                 bool fuse = true;
                 for (int oj = 0; oj < nbk; ++oj) {
@@ -1026,13 +1039,14 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     l2[n] = &h->convs2[ci];
                     fuse = fuse && pair_eligible(h, *l1[n], *l2[n]);
                     const bool last = d + 1 == cfg.n_dilations[j];
-                    // layer-by-layer: x_s[j] -> xt_s[j] -> x_s[j].  Fused pair: the split stream ping-pongs between x_s[j]
-                    // and xt_s[j] (a tile's output pass must not overwrite rows a neighbouring tile still reads as halo)
-                    const char* in_s = d == 0 ? ws.u_s : ((d & 1) ? ws.x_s[j] : xt_s[j]);
-                    char* out_s = (d & 1) ? xt_s[j] : ws.x_s[j];
-                    io1[n] = {d == 0 ? ws.u_s : ws.x_s[j], nullptr, nullptr, xt_s[j]};
-                    io2[n] = {xt_s[j], d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : ws.x_s[j]};
-                    iop[n] = {in_s, d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : out_s};
+                    // fused pair: cur -> the other buffer.  Layer by layer: cur -> mid -> the buffer that is not mid.
+                    pair_out[n] = cur_s[j] == ws.x_s[j] ? xt_s[j] : ws.x_s[j];
+                    char* mid = cur_s[j] == xt_s[j] ? ws.x_s[j] : xt_s[j];
+                    lbl_out[n] = mid == xt_s[j] ? ws.x_s[j] : xt_s[j];
+                    io1[n] = {cur_s[j], nullptr, nullptr, mid};
+                    io2[n] = {mid, d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : lbl_out[n]};
+                    iop[n] = {cur_s[j], d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : pair_out[n]};
+                    jn[n] = j;
                     ++n;
                 }
                 if (fuse) {
@@ -1041,6 +1055,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     if ((rc = launch_conv_bf16x3(h, l1, n, B, rows, io1, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                     if ((rc = launch_conv_bf16x3(h, l2, n, B, rows, io2, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                 }
+                for (int q = 0; q < n; ++q) cur_s[jn[q]] = fuse ? pair_out[q] : lbl_out[q];
             }
         }
     }

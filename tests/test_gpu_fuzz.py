@@ -25,10 +25,10 @@ def draw(rng):
         n_stages -= 1
     scales = [int(rng.choice([2, 3, 4, 5, 8])) for _ in range(n_stages)]
     n_blocks = int(rng.integers(1, 4))
-    ks = [int(rng.choice([3, 5, 7, 9, 11])) for _ in range(n_blocks)]
-    dils = [[int(rng.integers(1, 7)) for _ in range(int(rng.integers(1, 4)))] for _ in range(n_blocks)]
+    ks = [int(rng.choice([3, 5, 7, 9, 11, 13, 15])) for _ in range(n_blocks)]
+    dils = [[int(rng.integers(1, 10)) for _ in range(int(rng.integers(1, 4)))] for _ in range(n_blocks)]
     use_ar = bool(rng.integers(0, 2))
-    cf = int(rng.integers(1, 90))
+    cf = int(rng.integers(1, 90)) if rng.integers(0, 5) else int(rng.integers(90, 400))
     params = dict(E2W_PARAMS, channels=channels, kernel_size=int(rng.choice([3, 5, 7, 9])), upsample_scales=scales,
                   upsample_kernel_sizes=[2 * s for s in scales], resblock_kernel_sizes=ks, resblock_dilations=dils,
                   use_ar=use_ar, in_channels=cf + (128 if use_ar else 0), bias=bool(rng.integers(0, 4)),
