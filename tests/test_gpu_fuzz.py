@@ -33,7 +33,7 @@ def draw(rng):
                   upsample_kernel_sizes=[2 * s for s in scales], resblock_kernel_sizes=ks, resblock_dilations=dils,
                   use_ar=use_ar, in_channels=cf + (128 if use_ar else 0), bias=bool(rng.integers(0, 4)),
                   use_tanh=bool(rng.integers(0, 4)),
-                  nonlinear_activation_params={"negative_slope": float(rng.choice([0.1, 0.2, 0.01, 0.5]))})
+                  nonlinear_activation_params={"negative_slope": float(rng.choice([0.1, 0.1, 0.2, 0.01, 0.5, 0.0, 1.0]))})
     return params, cf
 
 
@@ -50,7 +50,7 @@ def test_random_configuration(case):
     g.remove_weight_norm()
     g = g.eval().cuda()
     w = O.fold_weight_norm(sd)
-    B = int(rng.integers(1, 6))
+    B = int(rng.integers(1, 6)) if rng.integers(0, 6) else int(rng.integers(6, 80))
     T = int(rng.integers(1, 70)) if rng.integers(0, 4) else int(rng.integers(70, 500))  # mostly short, sometimes many tiles per sequence
     lens = [int(v) for v in rng.integers(0, T + 1, size=B)]
     lens[int(rng.integers(0, B))] = T
@@ -61,16 +61,20 @@ def test_random_configuration(case):
         y = g(c.cuda(), ar=ar.cuda() if ar is not None else None).cpu()
         yr = g(c.cuda(), ar=ar.cuda() if ar is not None else None, lengths=lens).cpu()
         ref = O.generator_forward(w, params, c, ar)
+        pre = O.generator_forward(w, dict(params, use_tanh=False), c, ar) if params["use_tanh"] else ref
+    # the arithmetic's error is a fixed fraction of the PRE-tanh scale (conditioning): a configuration
+    # that drives tanh into saturation is held to that, not to the squashed output's scale
+    tol = TOLS[prec] * max(1.0, float(pre.abs().max() / ref.abs().max()))
     tag = (case, prec, {k: params[k] for k in ("channels", "kernel_size", "upsample_scales", "resblock_kernel_sizes",
                                                 "resblock_dilations", "use_ar", "in_channels", "bias")}, B, T, lens)
     assert y.shape == ref.shape == (B, 1, hop * T), tag
-    assert rel_err(y.numpy(), ref.numpy()) < TOLS[prec], tag
+    assert rel_err(y.numpy(), ref.numpy()) < tol, tag
     for b, n in enumerate(lens):  # ragged: each utterance as if alone (zero padding at its own end), nothing beyond it
         assert float(yr[b, :, hop * n:].abs().sum()) == 0.0, tag
         if n:
             with torch.no_grad():
                 alone = O.generator_forward(w, params, c[b:b + 1, :, :n], ar[b:b + 1] if ar is not None else None)
-            assert rel_err(yr[b:b + 1, :, :hop * n].numpy(), alone.numpy()) < TOLS[prec] * max(1.0, float(ref.abs().max() / alone.abs().max())), tag
+            assert rel_err(yr[b:b + 1, :, :hop * n].numpy(), alone.numpy()) < tol * max(1.0, float(ref.abs().max() / alone.abs().max())), tag
 
 
 @pytest.mark.parametrize("case", range(max(1, N_CASES // 2)))
@@ -109,4 +113,7 @@ def test_random_ar_dataset(case):
         if n:
             with torch.no_grad():
                 ref = O.ar_loop(w, params, torch.from_numpy(x[b, :n]), hop * chunk, hop)
-            assert rel_err(yp[b, :hop * n].cpu().numpy(), ref.numpy()) < TOLS[prec], tag
+            # a configuration that drives tanh towards saturation feeds rounding differences back through the AR context
+            # (conditioning): those are held to the north-star bar, the others to the tight one
+            tol = TOLS[prec] if float(ref.abs().max()) < 0.5 else 1e-3
+            assert rel_err(yp[b, :hop * n].cpu().numpy(), ref.numpy()) < tol, tag
