@@ -28,7 +28,9 @@
  *   - every function returns 0 on success or a negative HIFICAR_E_* code; hificar_last_error() then
  *     returns a thread-local, human-readable message.  Nothing ever calls exit().
  *   - all device work is enqueued on the caller-supplied hipStream_t (passed as void*); no call
- *     synchronises the device except hificar_finalize() (one-time weight upload).
+ *     synchronises the device except hificar_finalize() (one-time weight upload) and the FIRST call for a new
+ *     (batch, frames) shape, which builds and uploads that shape's tile schedules (small device allocations + blocking
+ *     copies; cached in the handle afterwards, so a warm-up call per shape keeps the steady state fully asynchronous).
  *   - a handle is not thread-safe; use one handle per (process, device).
  */
 #ifndef HIFICAR_H
