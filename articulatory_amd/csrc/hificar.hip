@@ -664,7 +664,7 @@ static int get_schedule(hificar_handle* h, const std::string& key, const std::ve
                         const int** d_start, const int** d_tiles) {
     auto it = h->scheds.find(key);
     if (it == h->scheds.end()) {
-        if (h->scheds.size() >= 1024) {
+        if (h->scheds.size() >= 4096) {
             // many distinct launch shapes (e.g. non-AR inference over utterances of every length): drop the cache.
             // Kernels still in flight may be reading old schedules, so drain the device first (rare, off the hot path).
             HIP_TRY(hipDeviceSynchronize());
@@ -1140,20 +1140,15 @@ extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const i
             if (lengths_host[b] < 0 || lengths_host[b] > T_total)
                 return fail(HIFICAR_E_INVALID, "lengths[%d]=%d outside [0, %d]", b, lengths_host[b], T_total);
     for (int f0 = 0; f0 < T_total; f0 += chunk_frames) {
-        int Tn = std::min(chunk_frames, T_total - f0);
+        const int Tn = std::min(chunk_frames, T_total - f0);
         // With the host copy of the lengths the step only covers the utterances still running: the batch prefix up to the
-        // last one longer than f0 (all of them when the batch is sorted longest first) and their longest remainder.
+        // last one longer than f0 (all of them when the batch is sorted longest first).
         int Bn = B;
         if (lengths_host) {
             Bn = 0;
-            int longest = 0;
             for (int b = 0; b < B; ++b)
-                if (lengths_host[b] > f0) {
-                    Bn = b + 1;
-                    longest = std::max(longest, lengths_host[b] - f0);
-                }
+                if (lengths_host[b] > f0) Bn = b + 1;
             if (Bn == 0) break;
-            Tn = std::min(Tn, longest);
         }
         const int64_t pos = (int64_t)h->hop * f0;
         // prev = last ar_input samples already written for this utterance (zeros for the first chunk)
@@ -1201,12 +1196,12 @@ extern "C" int hificar_ar_loop_packed(hificar_handle* h, const float* c, const i
                 ++next;
             }
             if (run.empty()) break;
-            Step st{(int)run.size(), 0};
+            // every step is launched over a full chunk (shorter last chunks are masked per sequence and their empty tiles
+            // skipped): launch shapes then differ by the number of running utterances only, and their schedules stay cached
+            Step st{(int)run.size(), std::min(chunk_frames, T_max)};
             for (int u : run) {
-                const int v = std::min(chunk_frames, lengths_host[u] - f0[u]);
                 slots.push_back(int2{u, f0[u]});
-                valid.push_back(v);
-                st.frames = std::max(st.frames, v);
+                valid.push_back(std::min(chunk_frames, lengths_host[u] - f0[u]));
             }
             slots.resize((slots.size() + 1) & ~(size_t)1);  // rows start on an even index in both arrays (int2 rows 16-byte aligned)
             valid.resize(slots.size());
