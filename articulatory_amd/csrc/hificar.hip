@@ -489,10 +489,10 @@ static hipError_t set_lds_attr_f() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-// every (MI, WM, WN) x NC16 instantiation of the bf16x3 kernel
-#define HIFICAR_FOR_BF16_TILES(X, nc) \
+// every (MI, WM, WN) x NC16 instantiation of the conv kernels (both arithmetics)
+#define HIFICAR_FOR_TILES(X, nc) \
     X(4, 1, 4, nc) X(4, 2, 2, nc) X(4, 4, 1, nc) X(2, 1, 4, nc) X(2, 2, 2, nc) X(2, 4, 1, nc) X(1, 1, 4, nc) X(1, 2, 2, nc) X(1, 4, 1, nc)
-#define HIFICAR_FOR_BF16_ALL(X) HIFICAR_FOR_BF16_TILES(X, 1) HIFICAR_FOR_BF16_TILES(X, 2) HIFICAR_FOR_BF16_TILES(X, 4)
+#define HIFICAR_FOR_ALL_TILES(X) HIFICAR_FOR_TILES(X, 1) HIFICAR_FOR_TILES(X, 2) HIFICAR_FOR_TILES(X, 4)
 
 extern "C" int hificar_finalize(hificar_handle* h) {
     if (!h) return fail(HIFICAR_E_INVALID, "hificar_finalize: null handle");
@@ -541,7 +541,7 @@ extern "C" int hificar_finalize(hificar_handle* h) {
 #define HIFICAR_SET_ATTR(mi, wm, wn, nc)         \
     HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>())); \
     HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>()));
-    HIFICAR_FOR_BF16_ALL(HIFICAR_SET_ATTR)
+    HIFICAR_FOR_ALL_TILES(HIFICAR_SET_ATTR)
 #undef HIFICAR_SET_ATTR
     HIP_TRY(hipDeviceSynchronize());
     h->tensors.clear();  // host copies no longer needed
@@ -716,15 +716,15 @@ static int get_schedule(hificar_handle* h, const std::string& key, const std::ve
     return HIFICAR_OK;
 }
 
-struct TileCfgB {
+struct TileCfg {
     int MI, WM, WN;
 };
-static size_t out_buf_bytes(const TileCfgB& t) { return (size_t)(t.WM * t.MI * 32) * (t.WN * 32 + 4) * sizeof(float); }
+static size_t out_buf_bytes(const TileCfg& t) { return (size_t)(t.WM * t.MI * 32) * (t.WN * 32 + 4) * sizeof(float); }
 // preference order: ties keep the earlier entry (taller wave tiles re-read fewer weights per MFMA)
-static const TileCfgB kTileCfgsB[9] = {{4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {2, 1, 4}, {2, 2, 2}, {2, 4, 1}, {1, 1, 4}, {1, 2, 2}, {1, 4, 1}};
+static const TileCfg kTileCfgs[9] = {{4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {2, 1, 4}, {2, 2, 2}, {2, 4, 1}, {1, 1, 4}, {1, 2, 2}, {1, 4, 1}};
 
 template <int MI, int WM, int WN, int NC16>
-static hipError_t launch_conv_b(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
+static hipError_t launch_conv_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
     if (f32) hipLaunchKernelGGL((conv_f32_kernel<MI, WM, WN, NC16>), grid, dim3(512), lds, stream, mp);
     else hipLaunchKernelGGL((conv_bf16x3_kernel<MI, WM, WN, NC16>), grid, dim3(512), lds, stream, mp);
     return hipGetLastError();
@@ -732,14 +732,14 @@ static hipError_t launch_conv_b(const MultiConvParams& mp, dim3 grid, size_t lds
 
 // One conv launch on activated rows (either arithmetic).  Per branch: xs (activated input) -> y (fp32, nullable) and/or ys (split copy of
 // LeakyReLU(out, slope_out), nullable), + optional fp32 residual.
-struct ConvIOB {
+struct ConvIO {
     const char* xs;
     const float* res;
     float* y;
     char* ys;
 };
 
-static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows, const ConvIOB* io,
+static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows, const ConvIO* io,
                               float slope_out, const Ragged& rg, hipStream_t stream) {
     const ConvLayer& L0 = *layers[0];
     const bool f32 = h->precision == HIFICAR_PREC_F32;  // rows are plain fp32 LeakyReLU(x) instead of split rows
@@ -749,13 +749,13 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
     // Tile shape: simulate the kernel's static tile walk (workgroup w takes tiles w, w+G, ...; branch-major order) and
     // take the shape with the smallest makespan.  A tile costs its MFMA issue cycles (all four MFMA waves run in
     // lock step: 3*MI MFMAs of 32 cycles per 16-channel K slab) plus a fixed per-tile and per-item overhead.
-    TileCfgB tc = kTileCfgsB[8];
+    TileCfg tc = kTileCfgs[8];
     double best = 1e300;
     // dev override: HIFICAR_TILE="cin,MI,WM,WN" forces the shape for layers with that many input channels
     static const char* force = getenv("HIFICAR_TILE");
     int fc = 0, fmi = 0, fwm = 0, fwn = 0;
     if (force) sscanf(force, "%d,%d,%d,%d", &fc, &fmi, &fwm, &fwn);
-    for (const TileCfgB& t : kTileCfgsB) {
+    for (const TileCfg& t : kTileCfgs) {
         const int TM = t.WM * t.MI * 32;
         if (2 * round_up_sz((size_t)(TM + halo_all) * RB, 1024) + out_buf_bytes(t) > 160 * 1024) continue;
         if (fc == L0.cin_pad && nbr == 3 && !(t.MI == fmi && t.WM == fwm && t.WN == fwn)) continue;
@@ -832,10 +832,10 @@ static int launch_conv_bf16x3(hificar_handle* h, const ConvLayer* const* layers,
     }
     ProfScope prof(h, stream, kname, flops, bytes);
     hipError_t e = hipErrorInvalidValue;
-#define HIFICAR_DISPATCH_B(mi, wm, wn, nc) \
-    if (tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_b<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
-    HIFICAR_FOR_BF16_ALL(HIFICAR_DISPATCH_B)
-#undef HIFICAR_DISPATCH_B
+#define HIFICAR_DISPATCH(mi, wm, wn, nc) \
+    if (tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_t<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
+    HIFICAR_FOR_ALL_TILES(HIFICAR_DISPATCH)
+#undef HIFICAR_DISPATCH
     if (e != hipSuccess) return fail(HIFICAR_E_HIP, "conv launch (%s, %s) failed: %s", L0.name.c_str(), kname, hipGetErrorString(e));
     return HIFICAR_OK;
 }
@@ -986,8 +986,8 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
         char* xt_s[3] = {reinterpret_cast<char*>(ws.xt[0]), reinterpret_cast<char*>(ws.xt[1]), reinterpret_cast<char*>(ws.xt[2])};
         {   // 2. input conv (no activation in front of it: hifigan.py:221); its consumer applies LeakyReLU(slope)
             const ConvLayer* lay[1] = {&h->input_conv};
-            const ConvIOB io[1] = {{xin_s, nullptr, nullptr, h0_s}};
-            if ((rc = launch_conv_bf16x3(h, lay, 1, B, T, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+            const ConvIO io[1] = {{xin_s, nullptr, nullptr, h0_s}};
+            if ((rc = launch_conv(h, lay, 1, B, T, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
         }
         for (int i = 0; i < cfg.n_stages; ++i) {
             const char* up_in = h0_s;
@@ -1014,8 +1014,8 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             }
             {   // LeakyReLU + ConvTranspose1d (hifigan.py:224): fp32 u (first residual) + split copy (first conv input)
                 const ConvLayer* lay[1] = {&h->ups[i]};
-                const ConvIOB io[1] = {{up_in, nullptr, ws.u, ws.u_s}};
-                if ((rc = launch_conv_bf16x3(h, lay, 1, B, rows, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                const ConvIO io[1] = {{up_in, nullptr, ws.u, ws.u_s}};
+                if ((rc = launch_conv(h, lay, 1, B, rows, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
             }
             rows *= cfg.upsample_scales[i];
             // activated stream of each branch: where the next conv1 reads its input.  It alternates between x_s[j] and
@@ -1024,7 +1024,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
                 const ConvLayer* l1[3];
                 const ConvLayer* l2[3];
-                ConvIOB io1[3], io2[3];
+                ConvIO io1[3], io2[3];
                 PairIOB iop[3];
                 int jn[3];
                 char* pair_out[3];
@@ -1052,8 +1052,8 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 if (fuse) {
                     if ((rc = launch_pair_bf16x3(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                 } else {
-                    if ((rc = launch_conv_bf16x3(h, l1, n, B, rows, io1, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
-                    if ((rc = launch_conv_bf16x3(h, l2, n, B, rows, io2, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    if ((rc = launch_conv(h, l1, n, B, rows, io1, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    if ((rc = launch_conv(h, l2, n, B, rows, io2, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                 }
                 for (int q = 0; q < n; ++q) cur_s[jn[q]] = fuse ? pair_out[q] : lbl_out[q];
             }
