@@ -842,6 +842,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
 
 // Fused conv1 -> LeakyReLU -> conv2 (+ residual) for C = 32 / 64 (conv_pair_bf16x3_kernel).
 struct PairIOB {
+    const float* xf;  // fp32 pre-activation input of conv1 (activated + split while staging), or null when xs is given
     const char* xs;   // split input of conv1
     const float* res; // fp32 residual
     float* y;         // fp32 output (may alias res)
@@ -877,6 +878,8 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
         pp.p1[b].w16 = reinterpret_cast<const bf16x8*>(A.d_w16c);
         pp.p2[b].w16 = reinterpret_cast<const bf16x8*>(B.d_w16c);
         pp.p1[b].xs = io[b].xs;
+        pp.p1[b].xf = io[b].xf;
+        pp.p1[b].slope_in = slope;
         pp.p1[b].zeros = h->d_zeros;
         pp.p2[b].ys = io[b].ys;
         pp.p2[b].slope_out = slope;
@@ -978,6 +981,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     int max_d = 0;
     for (int j = 0; j < nbk; ++j) max_d = std::max(max_d, cfg.n_dilations[j]);
 
+    const float* fin[3] = {ws.x[0], ws.x[1], ws.x[2]};  // where each branch's ResBlock output of the current stage lives
     {
         // Activations travel between layers already activated — split rows (bf16x3) or plain fp32 rows (exact fp32), the
         // "_s" buffers — and are staged by LDS-DMA; the layer's own fp32 value only where a residual / the MRF mean needs it
@@ -994,10 +998,10 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             if (i > 0) {  // MRF mean of the previous stage (hifigan.py:226-230) + LeakyReLU + split, elementwise
                 MrfSplitParams mq;
                 memset(&mq, 0, sizeof(mq));
-                mq.x0 = ws.x[0];
-                mq.x1 = nbk > 1 ? ws.x[1] : nullptr;
-                mq.x2 = nbk > 2 ? ws.x[2] : nullptr;
-                mq.out = xt_s[0];
+                mq.x0 = fin[0];
+                mq.x1 = nbk > 1 ? fin[1] : nullptr;
+                mq.x2 = nbk > 2 ? fin[2] : nullptr;
+                mq.out = fin[0] == ws.xt[0] ? ws.x_s[0] : xt_s[0];  // a buffer none of the inputs lives in
                 mq.nin = nbk;
                 mq.C = stage_channels(cfg, i);
                 mq.rows = (long long)B * rows;
@@ -1010,14 +1014,49 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     hipLaunchKernelGGL(mrf_split_kernel, dim3(blocks), dim3(256), 0, stream, mq);
                 }
                 HIP_TRY(hipGetLastError());
-                up_in = xt_s[0];
+                up_in = mq.out;
             }
-            {   // LeakyReLU + ConvTranspose1d (hifigan.py:224): fp32 u (first residual) + split copy (first conv input)
+            // Narrow stage whose every layer pair runs in the fused kernel: the residual stream stays fp32-only (the pair
+            // kernel activates + splits its input while staging), ping-ponging between x[j] and xt[j]; no activated copies
+            // are written at all.  Otherwise: activated copies ("_s") travel next to the fp32 stream.
+            static const bool f32in = !getenv("HIFICAR_PAIR_F32IN") || atoi(getenv("HIFICAR_PAIR_F32IN")) != 0;  // A/B runs
+            bool all_pairs = f32in;
+            for (int j = 0; j < nbk; ++j)
+                for (int d = 0; d < cfg.n_dilations[j]; ++d) {
+                    const int ci = conv_index(h, i, j, d);
+                    all_pairs = all_pairs && pair_eligible(h, h->convs1[ci], h->convs2[ci]);
+                }
+            {   // LeakyReLU + ConvTranspose1d (hifigan.py:224): fp32 u (first residual) (+ activated copy: first conv input)
                 const ConvLayer* lay[1] = {&h->ups[i]};
-                const ConvIO io[1] = {{up_in, nullptr, ws.u, ws.u_s}};
+                const ConvIO io[1] = {{up_in, nullptr, ws.u, all_pairs ? nullptr : ws.u_s}};
                 if ((rc = launch_conv(h, lay, 1, B, rows, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
             }
             rows *= cfg.upsample_scales[i];
+            if (all_pairs) {
+                const float* cur_f[3] = {ws.u, ws.u, ws.u};
+                for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
+                    const ConvLayer* l1[3];
+                    const ConvLayer* l2[3];
+                    PairIOB iop[3];
+                    int n = 0;
+                    for (int oj = 0; oj < nbk; ++oj) {
+                        const int j = order[oj];
+                        if (d >= cfg.n_dilations[j]) continue;
+                        const int ci = conv_index(h, i, j, d);
+                        l1[n] = &h->convs1[ci];
+                        l2[n] = &h->convs2[ci];
+                        // a tile's output pass must not overwrite rows a neighbouring tile still reads as halo: out != in
+                        float* out_f = cur_f[j] == ws.x[j] ? ws.xt[j] : ws.x[j];
+                        iop[n] = {cur_f[j], nullptr, cur_f[j], out_f, nullptr};
+                        cur_f[j] = out_f;
+                        ++n;
+                    }
+                    if ((rc = launch_pair_bf16x3(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                }
+                for (int j = 0; j < nbk; ++j) fin[j] = cur_f[j];
+                continue;
+            }
+            for (int j = 0; j < nbk; ++j) fin[j] = ws.x[j];
             // activated stream of each branch: where the next conv1 reads its input.  It alternates between x_s[j] and
             // xt_s[j]: a launch never writes the buffer it (or a neighbouring tile, through the halo) reads.
             const char* cur_s[3] = {ws.u_s, ws.u_s, ws.u_s};
@@ -1045,7 +1084,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     lbl_out[n] = mid == xt_s[j] ? ws.x_s[j] : xt_s[j];
                     io1[n] = {cur_s[j], nullptr, nullptr, mid};
                     io2[n] = {mid, d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : lbl_out[n]};
-                    iop[n] = {cur_s[j], d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : pair_out[n]};
+                    iop[n] = {nullptr, cur_s[j], d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : pair_out[n]};
                     jn[n] = j;
                     ++n;
                 }
@@ -1062,9 +1101,9 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     // 4. output conv: LeakyReLU(0.01) + Conv1d + tanh (hifigan.py:146-159)
     OutConvParams op;
     memset(&op, 0, sizeof(op));
-    op.x0 = ws.x[0];
-    op.x1 = nbk > 1 ? ws.x[1] : nullptr;
-    op.x2 = nbk > 2 ? ws.x[2] : nullptr;
+    op.x0 = fin[0];
+    op.x1 = nbk > 1 ? fin[1] : nullptr;
+    op.x2 = nbk > 2 ? fin[2] : nullptr;
     op.nin = nbk;
     op.w = h->d_out_w;
     op.bias = h->out_bias;

@@ -40,6 +40,9 @@ struct ConvParams {
     const float* bias;  // [cout_total] (never null; zeros when the layer has no bias)
     const float* res;   // fp32 residual, same layout as y, or null
     float* y;           // fp32 output of the layer itself (pre-activation), or null when only the activated copy is consumed
+    const float* xf;    // pair kernel only: fp32 PRE-activation input rows (C floats per row); LeakyReLU(slope_in) + split are
+                        // then applied while staging and xs is null (narrow stages: the producer writes no activated copy)
+    float slope_in;
     const char* xs;     // input rows, already activated (and split) by their producer
     char* ys;           // activated (and split) copy of the output for the consumer conv: LeakyReLU(out, slope_out), or null
     const char* zeros;  // >= 16 bytes of zeros (source of padding rows for the LDS DMA)
@@ -729,8 +732,61 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
                                                  (__attribute__((address_space(3))) void*)(smem_b + i * 1024), 16, 0, 2);
             }
         };
+        // fp32 input mode: rows are read as fp32, activated and split in registers and written to the same swizzled slots the
+        // DMA would fill (logical slot s of row r lives at position s ^ swizzle(r)); out-of-sequence rows become zeros
+        auto stage_f32 = [&](const Tile& T) {
+            const ConvParams& p = mp.p1[T.b];
+            const int pad2 = (mp.p2[T.b].ntaps - 1) >> 1;
+            const int R = TMc + p.halo;
+            const size_t seq_base = (size_t)T.seq * p.L;
+            const int Ls = seq_rows(p, T.seq);
+            const int tfirst = T.t0 - pad2 + p.off_min;
+            const float slope = p.slope_in;
+            constexpr int UPR = CH / 8;  // 8-channel units per row
+            constexpr int LOG_UPR = NC16 == 4 ? 3 : 2;
+            const int nunits = R * UPR;
+            constexpr int UB = 4;        // units in flight per thread: all loads are issued before the first is used
+            for (int u0 = ltid; u0 < nunits; u0 += 256 * UB) {
+                f32x4 a[UB], b[UB];
+#pragma unroll
+                for (int q = 0; q < UB; ++q) {
+                    const int u = u0 + q * 256;
+                    const int r = u >> LOG_UPR;
+                    const int t = tfirst + r;
+                    a[q] = b[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (u < nunits && t >= 0 && t < Ls) {
+                        const float* src = p.xf + (seq_base + t) * CH + (u & (UPR - 1)) * 8;
+                        a[q] = *reinterpret_cast<const f32x4*>(src);
+                        b[q] = *reinterpret_cast<const f32x4*>(src + 4);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < UB; ++q) {
+                    const int u = u0 + q * 256;
+                    if (u < nunits) {
+                        const int r = u >> LOG_UPR;
+                        const int cu = u & (UPR - 1);
+                        const int swz = (r >> LOG_RPB) & (SPR - 1);
+                        bf16x8 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = e < 4 ? a[q][e] : b[q][e - 4];
+                            const float act = fmaxf(v, v * slope);
+                            hi[e] = (__bf16)act;
+                            lo[e] = (__bf16)(act - (float)hi[e]);
+                        }
+                        *reinterpret_cast<bf16x8*>(smem_b + r * RB + ((cu ^ swz) << 4)) = hi;
+                        *reinterpret_cast<bf16x8*>(smem_b + r * RB + (((SPR / 2 + cu) ^ swz) << 4)) = lo;
+                    }
+                }
+            }
+        };
+        auto stage_in = [&](const Tile& T) {
+            if (mp.p1[T.b].xf) stage_f32(T);
+            else dma_in(T);
+        };
         Tile Tprev;
-        if (first < my_rounds) dma_in(decode(tile_of(first)));
+        if (first < my_rounds) stage_in(decode(tile_of(first)));
         for (int it = first, itn; it < my_rounds; it = itn) {
             itn = nxt(it + 1);
             const Tile T = decode(tile_of(it));
@@ -742,7 +798,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
             __syncthreads();                 // F: shared region free
             __syncthreads();                 // B: TS complete, input buffer free
             HIFICAR_STAMP(4 * it + 3);
-            if (itn < my_rounds) dma_in(decode(tile_of(itn)));  // hidden behind conv2
+            if (itn < my_rounds) stage_in(decode(tile_of(itn)));  // hidden behind conv2
             __syncthreads();                 // C: conv2 done reading TS
             Tprev = T;
         }
