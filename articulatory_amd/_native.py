@@ -36,6 +36,7 @@ SYMBOLS = (
     "hificar_pcm16",
     "hificar_profile_begin",
     "hificar_profile_end",
+    "hificar_debug_tap",
     "hificar_destroy",
     "hificar_last_error",
     "hificar_version",
@@ -121,6 +122,8 @@ def load_library():
     lib.hificar_profile_begin.restype = ctypes.c_int
     lib.hificar_profile_end.argtypes = [vp, ctypes.POINTER(HificarKernelStat), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     lib.hificar_profile_end.restype = ctypes.c_int
+    lib.hificar_debug_tap.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t]
+    lib.hificar_debug_tap.restype = ctypes.c_int
     lib.hificar_destroy.argtypes = [vp]
     lib.hificar_destroy.restype = None
     lib.hificar_last_error.argtypes = []

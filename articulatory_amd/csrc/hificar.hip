@@ -51,6 +51,8 @@ struct ConvLayer {
     int cin = 0;          // real input channels
     int cin_pad = 0;      // row pitch of the input buffer (multiple of 16)
     int cout = 0;         // real output channels (per phase for transposed)
+    int cout_pad = 0;     // output channels per phase as laid out in memory: cout rounded up to a multiple of 32 (extra channels have
+                          // zero weights and bias, so they hold exact zeros through every layer and cost nothing in accuracy)
     int K = 0, dilation = 1, stride = 1, padding = 0;
     bool has_bias = true;
     // derived
@@ -100,6 +102,14 @@ struct hificar_handle {
         int* d_tiles = nullptr;
     };
     std::map<std::string, Sched> scheds;
+    // debug taps (hificar_debug_tap): name -> (destination, capacity in floats); scratch for pre-activation copies
+    struct Tap {
+        float* dst;
+        size_t cap;
+    };
+    std::map<std::string, Tap> taps;
+    float* tap_scratch = nullptr;
+    size_t tap_scratch_elems = 0;
     // profiling (hificar_profile_begin/end)
     bool profiling = false;
     struct ProfRec {
@@ -132,10 +142,11 @@ struct ProfScope {
     }
 };
 
-static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static int stage_channels(const hificar_config& c, int i) { return c.channels >> i; }  // channels // 2**i
+static int stage_pad(const hificar_config& c, int i) { return round_up(stage_channels(c, i), 32); }  // row pitch of that stage's buffers
 
 static int conv_index(const hificar_handle* h, int stage, int block, int dil) {
     int idx = 0;
@@ -145,11 +156,9 @@ static int conv_index(const hificar_handle* h, int stage, int block, int dil) {
 
 // Derive tap tables and blocking for one layer.
 static int plan_layer(ConvLayer& L) {
-    if (L.cin_pad < 32)
-        return fail(HIFICAR_E_INVALID, "%s: needs at least 32 (padded) input channels", L.name.c_str());
-    if (L.cout % 32 != 0)
-        return fail(HIFICAR_E_INVALID, "%s: output channels (%d) must be a multiple of 32 for the MFMA kernels",
-                    L.name.c_str(), L.cout);
+    if (L.cin_pad < 32 || L.cin_pad % 16 != 0 || L.cin < 1 || L.cout < 1)
+        return fail(HIFICAR_E_INVALID, "internal: %s: bad channel counts (cin %d, padded %d, cout %d)", L.name.c_str(), L.cin, L.cin_pad, L.cout);
+    L.cout_pad = round_up(L.cout, 32);  // any width runs (hifigan.py:108-145 accepts any): the MFMA tiles are 32 channels wide
     if (!L.transposed) {
         if (L.K > kMaxTaps) return fail(HIFICAR_E_INVALID, "%s: kernel size %d > %d", L.name.c_str(), L.K, kMaxTaps);
         L.n_phase = 1;
@@ -190,11 +199,11 @@ static int plan_layer(ConvLayer& L) {
             L.off_min = std::min(L.off_min, L.tap_off[r][t]);
             L.off_max = std::max(L.off_max, L.tap_off[r][t]);
         }
-    L.cout_total = L.cout * L.n_phase;
+    L.cout_total = L.cout_pad * L.n_phase;
     // 16/32/64 channels per LDS item (XOR-swizzled rows), and at least two items per tile (out-buffer hand-off)
     L.chunk16 = (L.cin_pad % 64 == 0 && L.cin_pad >= 128) ? 64 : (L.cin_pad % 32 == 0 && L.cin_pad >= 64) ? 32 : 16;
     L.n_blocks32 = L.cout_total / 32;
-    L.nb32_per_phase = L.cout / 32;
+    L.nb32_per_phase = L.cout_pad / 32;
     return HIFICAR_OK;
 }
 
@@ -219,7 +228,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (!(c.lrelu_slope >= 0.f && c.lrelu_slope <= 1.f)) return fail(HIFICAR_E_INVALID, "negative_slope=%g outside [0, 1]", c.lrelu_slope);
     if (c.precision != HIFICAR_PREC_F32 && c.precision != HIFICAR_PREC_BF16X3)
         return fail(HIFICAR_E_INVALID, "unknown precision %d", c.precision);
-    if (c.channels % (1 << c.n_stages) != 0) return fail(HIFICAR_E_INVALID, "channels=%d not divisible by 2^n_stages", c.channels);
+    if ((c.channels >> c.n_stages) < 1) return fail(HIFICAR_E_INVALID, "channels=%d leaves no channels after %d halvings", c.channels, c.n_stages);
 
     hificar_handle* h = new hificar_handle();
     h->cfg = c;
@@ -266,15 +275,12 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
         ConvLayer u;
         u.name = "upsamples." + std::to_string(i) + ".1";
         u.transposed = true;
-        u.cin = u.cin_pad = stage_channels(c, i);
+        u.cin = stage_channels(c, i);
+        u.cin_pad = stage_pad(c, i);
         u.cout = stage_channels(c, i + 1);
         u.K = K;
         u.stride = s;
         u.padding = pad;
-        if (u.cin_pad % 16 != 0) {
-            rc = fail(HIFICAR_E_INVALID, "stage %d input channels %d must be a multiple of 16", i, u.cin_pad);
-            break;
-        }
         rc = plan_layer(u);
         expect(u.name + ".weight", {u.cin, u.cout, K});
         expect(u.name + ".bias", {u.cout});
@@ -293,7 +299,8 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
                 const std::string base = "blocks." + std::to_string(i * c.n_blocks + j);
                 ConvLayer c1;
                 c1.name = base + ".convs1." + std::to_string(d) + ".1";
-                c1.cin = c1.cin_pad = c1.cout = u.cout;
+                c1.cin = c1.cout = u.cout;
+                c1.cin_pad = stage_pad(c, i + 1);
                 c1.K = k;
                 c1.dilation = c.resblock_dilations[j][d];
                 c1.padding = (k - 1) / 2 * c1.dilation;
@@ -336,6 +343,7 @@ extern "C" void hificar_destroy(hificar_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->d_tab) (void)hipFree(h->d_tab);
     if (h->h_tab) (void)hipHostFree(h->h_tab);
+    if (h->tap_scratch) (void)hipFree(h->tap_scratch);
     if (h->tab_copied) (void)hipEventDestroy(h->tab_copied);
     for (auto& kv : h->scheds) {
         (void)hipFree(kv.second.d_start);
@@ -407,6 +415,7 @@ static int pack_w16(hificar_handle* h, const ConvLayer& L, const HostTensor& W, 
                     uint16_t* lo = hi + frag;
                     for (int lane = 0; lane < 64; ++lane) {
                         const int g = lane >> 5, n = lane & 31, co = co0 + n;
+                        if (co >= L.cout) continue;
                         for (int j = 0; j < 8; ++j) {
                             const int ci = c * chunk + u * 16 + 8 * g + j;
                             if (ci >= L.cin) continue;
@@ -446,6 +455,7 @@ static int pack_w32(hificar_handle* h, const ConvLayer& L, const HostTensor& W, 
                         float* f = &w32[((((((size_t)nb * nchunk + c) * L.ntaps + t) * nc16 + u) * 2) + v) * frag];
                         for (int lane = 0; lane < 64; ++lane) {
                             const int g = lane >> 5, n = lane & 31, co = co0 + n;
+                            if (co >= L.cout) continue;
                             for (int j = 0; j < 4; ++j) {
                                 const int ci = c * chunk + u * 16 + 8 * v + 4 * g + j;
                                 if (ci >= L.cin) continue;
@@ -465,7 +475,7 @@ static int pack_conv(hificar_handle* h, ConvLayer& L) {
     if (L.has_bias) {
         const HostTensor& Bv = h->tensors.at(L.name + ".bias");
         for (int r = 0; r < L.n_phase; ++r)
-            for (int co = 0; co < L.cout; ++co) bias[(size_t)r * L.cout + co] = Bv.data[co];
+            for (int co = 0; co < L.cout; ++co) bias[(size_t)r * L.cout_pad + co] = Bv.data[co];
     }
     int rc = upload(h, bias, &L.d_bias);
     if (rc != HIFICAR_OK) return rc;
@@ -473,7 +483,7 @@ static int pack_conv(hificar_handle* h, ConvLayer& L) {
     if ((rc = pack_w16(h, L, W, L.chunk16, &L.d_w16)) != HIFICAR_OK) return rc;
     if ((rc = pack_w32(h, L, W, L.chunk16, &L.d_w32)) != HIFICAR_OK) return rc;
     if (!L.transposed && L.cin_pad == L.cin && (L.cin == 32 || L.cin == 64) && L.cout == L.cin)
-        if ((rc = pack_w16(h, L, W, L.cin, &L.d_w16c)) != HIFICAR_OK) return rc;
+        if ((rc = pack_w16(h, L, W, L.cin_pad, &L.d_w16c)) != HIFICAR_OK) return rc;
     return HIFICAR_OK;
 }
 
@@ -509,10 +519,10 @@ extern "C" int hificar_finalize(hificar_handle* h) {
         if ((rc = pack_conv(h, l)) != HIFICAR_OK) return rc;
     {   // output conv weight (1, C, K) -> [k][C]
         const HostTensor& W = h->tensors.at("output_conv.1.weight");
-        const int C = (int)W.shape[1], K = (int)W.shape[2];
-        std::vector<float> w((size_t)C * K);
+        const int C = (int)W.shape[1], K = (int)W.shape[2], Cp = round_up(C, 32);  // [k][padded channels]
+        std::vector<float> w((size_t)Cp * K, 0.f);
         for (int ch = 0; ch < C; ++ch)
-            for (int k = 0; k < K; ++k) w[(size_t)k * C + ch] = W.data[(size_t)ch * K + k];
+            for (int k = 0; k < K; ++k) w[(size_t)k * Cp + ch] = W.data[(size_t)ch * K + k];
         if ((rc = upload(h, w, &h->d_out_w)) != HIFICAR_OK) return rc;
         h->out_bias = h->tensors.at("output_conv.1.bias").data[0];
     }
@@ -577,7 +587,7 @@ static size_t stage_elems(const hificar_handle* h, int B, int T) {
     size_t mx = 0, L = (size_t)T;
     for (int i = 0; i < h->cfg.n_stages; ++i) {
         L *= h->cfg.upsample_scales[i];
-        mx = std::max(mx, L * (size_t)stage_channels(h->cfg, i + 1));
+        mx = std::max(mx, L * (size_t)stage_pad(h->cfg, i + 1));
     }
     return mx * (size_t)B;
 }
@@ -592,7 +602,7 @@ static Workspace plan_workspace(const hificar_handle* h, int B, int T, void* bas
         return p;
     };
     w.xin = take((size_t)B * T * h->cin_pad);
-    w.h0 = take((size_t)B * T * h->cfg.channels);
+    w.h0 = take((size_t)B * T * stage_pad(h->cfg, 0));
     const size_t se = stage_elems(h, B, T);
     w.u = take(se);
     for (int j = 0; j < 3; ++j) w.x[j] = take(se);
@@ -796,7 +806,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         mp.p[b].ys = io[b].ys;
         mp.p[b].zeros = h->d_zeros;
         mp.p[b].slope_out = slope_out;
-        mp.p[b].cout_real = Lb.cout;
+        mp.p[b].cout_real = Lb.cout_pad;
         if (f32) mp.p[b].w16 = reinterpret_cast<const bf16x8*>(Lb.d_w32);
         const double pos = (double)nseq * rows;
         flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K;
@@ -928,6 +938,47 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
     return HIFICAR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// debug taps: copy a named intermediate (channels-last, padded pitch) into the caller's buffer in the reference's (B, C, L) layout
+// ------------------------------------------------------------------------------------------------
+extern "C" int hificar_debug_tap(hificar_handle* h, const char* name, float* dst, size_t capacity) {
+    if (!h) return fail(HIFICAR_E_INVALID, "null handle");
+    if (!name) {
+        h->taps.clear();
+        return HIFICAR_OK;
+    }
+    if (!dst) {
+        h->taps.erase(name);
+        return HIFICAR_OK;
+    }
+    h->taps[name] = {dst, capacity};
+    return HIFICAR_OK;
+}
+
+static int emit_tap(hificar_handle* h, const std::string& name, const void* src, int pitch, int c0, int C, int nseq, int rows, int split,
+                    hipStream_t stream, int src_rows = 0) {
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return HIFICAR_OK;
+    const size_t need = (size_t)nseq * C * rows;
+    if (it->second.cap < need) return fail(HIFICAR_E_INVALID, "debug tap '%s' needs %zu floats, buffer has %zu", name.c_str(), need, it->second.cap);
+    TapParams tp;
+    tp.src = src;
+    tp.dst = it->second.dst;
+    tp.pitch = pitch;
+    tp.c0 = c0;
+    tp.C = C;
+    tp.rows = rows;
+    tp.src_rows = src_rows ? src_rows : rows;
+    tp.total = (long long)need;
+    tp.split = split;
+    const unsigned blocks = (unsigned)std::min<long long>((tp.total + 255) / 256, 4096);
+    hipLaunchKernelGGL(tap_copy_kernel, dim3(blocks), dim3(256), 0, stream, tp);
+    HIP_TRY(hipGetLastError());
+    return HIFICAR_OK;
+}
+
+static bool tap_wanted(const hificar_handle* h, const std::string& name) { return h->taps.count(name) != 0; }
+
 // One generator forward on B sequences of T frames.
 //   c: element (b, ch, t) at c[b*c_bstride + ch*c_cstride + t];  prev: (b, i) at prev[b*prev_bstride + i] or null
 //   out: sample (b, n) at out[b*out_bstride + n]
@@ -974,6 +1025,25 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
 
     int rc;
     int rows = T;
+    const bool tapping = !h->taps.empty();
+    bool tap_convs1 = false;  // a conv1 output is wanted: those pairs run layer by layer (the fused kernel keeps it in LDS)
+    if (tapping) {
+        for (auto& kv : h->taps) tap_convs1 = tap_convs1 || kv.first.find(".convs1.") != std::string::npos;
+        // pre-activation copies that the normal path never writes: 3 stage-sized scratch buffers
+        const size_t need = 3 * stage_elems(h, B, T) + (size_t)B * T * stage_pad(cfg, 0);
+        if (need > h->tap_scratch_elems) {
+            if (h->tap_scratch) HIP_TRY(hipFree(h->tap_scratch));
+            h->tap_scratch = nullptr;
+            h->tap_scratch_elems = 0;
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, need * sizeof(float)));
+            h->tap_scratch = static_cast<float*>(p);
+            h->tap_scratch_elems = need;
+        }
+        if (cfg.use_ar && (rc = emit_tap(h, "ar_feats", ws.xin, f32 ? h->cin_pad : -h->cin_pad, h->cf, cfg.ar_output, B, 1, f32 ? 0 : 1, stream, T)) != HIFICAR_OK)
+            return rc;
+    }
+    const size_t tap_se = tapping ? stage_elems(h, B, T) : 0;
     const int nbk = cfg.n_blocks;
     // residual blocks of a stage run side by side, heaviest kernel size first
     int order[3] = {0, 1, 2};
@@ -990,8 +1060,10 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
         char* xt_s[3] = {reinterpret_cast<char*>(ws.xt[0]), reinterpret_cast<char*>(ws.xt[1]), reinterpret_cast<char*>(ws.xt[2])};
         {   // 2. input conv (no activation in front of it: hifigan.py:221); its consumer applies LeakyReLU(slope)
             const ConvLayer* lay[1] = {&h->input_conv};
-            const ConvIO io[1] = {{xin_s, nullptr, nullptr, h0_s}};
+            float* y_tap = tap_wanted(h, "input_conv") ? h->tap_scratch + 3 * tap_se : nullptr;
+            const ConvIO io[1] = {{xin_s, nullptr, y_tap, h0_s}};
             if ((rc = launch_conv(h, lay, 1, B, T, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+            if (y_tap && (rc = emit_tap(h, "input_conv", y_tap, stage_pad(cfg, 0), 0, cfg.channels, B, T, 0, stream)) != HIFICAR_OK) return rc;
         }
         for (int i = 0; i < cfg.n_stages; ++i) {
             const char* up_in = h0_s;
@@ -1003,7 +1075,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 mq.x2 = nbk > 2 ? fin[2] : nullptr;
                 mq.out = fin[0] == ws.xt[0] ? ws.x_s[0] : xt_s[0];  // a buffer none of the inputs lives in
                 mq.nin = nbk;
-                mq.C = stage_channels(cfg, i);
+                mq.C = stage_pad(cfg, i);
                 mq.rows = (long long)B * rows;
                 mq.slope = cfg.lrelu_slope;
                 mq.f32 = f32 ? 1 : 0;
@@ -1020,7 +1092,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             // kernel activates + splits its input while staging), ping-ponging between x[j] and xt[j]; no activated copies
             // are written at all.  Otherwise: activated copies ("_s") travel next to the fp32 stream.
             static const bool f32in = !getenv("HIFICAR_PAIR_F32IN") || atoi(getenv("HIFICAR_PAIR_F32IN")) != 0;  // A/B runs
-            bool all_pairs = f32in;
+            bool all_pairs = f32in && !tap_convs1;
             for (int j = 0; j < nbk; ++j)
                 for (int d = 0; d < cfg.n_dilations[j]; ++d) {
                     const int ci = conv_index(h, i, j, d);
@@ -1032,6 +1104,15 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 if ((rc = launch_conv(h, lay, 1, B, rows, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
             }
             rows *= cfg.upsample_scales[i];
+            const int Cs = stage_channels(cfg, i + 1), Cp = stage_pad(cfg, i + 1);
+            if (tapping && (rc = emit_tap(h, "upsamples." + std::to_string(i), ws.u, Cp, 0, Cs, B, rows, 0, stream)) != HIFICAR_OK) return rc;
+            auto tap_block = [&](int j, int d, const float* xcur) -> int {  // residual stream of block j after dilation d
+                if (!tapping) return HIFICAR_OK;
+                const std::string base = "blocks." + std::to_string(i * nbk + j);
+                int r = emit_tap(h, base + ".x." + std::to_string(d), xcur, Cp, 0, Cs, B, rows, 0, stream);
+                if (r == HIFICAR_OK && d + 1 == cfg.n_dilations[j]) r = emit_tap(h, base, xcur, Cp, 0, Cs, B, rows, 0, stream);
+                return r;
+            };
             if (all_pairs) {
                 const float* cur_f[3] = {ws.u, ws.u, ws.u};
                 for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
@@ -1052,6 +1133,8 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                         ++n;
                     }
                     if ((rc = launch_pair_bf16x3(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    for (int j = 0; j < nbk; ++j)
+                        if (d < cfg.n_dilations[j] && (rc = tap_block(j, d, cur_f[j])) != HIFICAR_OK) return rc;
                 }
                 for (int j = 0; j < nbk; ++j) fin[j] = cur_f[j];
                 continue;
@@ -1076,13 +1159,13 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     const int ci = conv_index(h, i, j, d);
                     l1[n] = &h->convs1[ci];
                     l2[n] = &h->convs2[ci];
-                    fuse = fuse && pair_eligible(h, *l1[n], *l2[n]);
+                    fuse = fuse && !tap_convs1 && pair_eligible(h, *l1[n], *l2[n]);
                     const bool last = d + 1 == cfg.n_dilations[j];
                     // fused pair: cur -> the other buffer.  Layer by layer: cur -> mid -> the buffer that is not mid.
                     pair_out[n] = cur_s[j] == ws.x_s[j] ? xt_s[j] : ws.x_s[j];
                     char* mid = cur_s[j] == xt_s[j] ? ws.x_s[j] : xt_s[j];
                     lbl_out[n] = mid == xt_s[j] ? ws.x_s[j] : xt_s[j];
-                    io1[n] = {cur_s[j], nullptr, nullptr, mid};
+                    io1[n] = {cur_s[j], nullptr, tap_convs1 ? h->tap_scratch + (size_t)n * tap_se : nullptr, mid};
                     io2[n] = {mid, d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : lbl_out[n]};
                     iop[n] = {nullptr, cur_s[j], d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : pair_out[n]};
                     jn[n] = j;
@@ -1092,8 +1175,15 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     if ((rc = launch_pair_bf16x3(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                 } else {
                     if ((rc = launch_conv(h, l1, n, B, rows, io1, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    if (tap_convs1)
+                        for (int q = 0; q < n; ++q)
+                            if ((rc = emit_tap(h, "blocks." + std::to_string(i * nbk + jn[q]) + ".convs1." + std::to_string(d), io1[q].y, Cp, 0, Cs,
+                                               B, rows, 0, stream)) != HIFICAR_OK)
+                                return rc;
                     if ((rc = launch_conv(h, l2, n, B, rows, io2, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                 }
+                for (int q = 0; q < n; ++q)
+                    if ((rc = tap_block(jn[q], d, ws.x[jn[q]])) != HIFICAR_OK) return rc;
                 for (int q = 0; q < n; ++q) cur_s[jn[q]] = fuse ? pair_out[q] : lbl_out[q];
             }
         }
@@ -1110,7 +1200,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     op.out = out;
     op.out_bstride = out_bstride;
     op.L = rows;
-    op.C = stage_channels(cfg, cfg.n_stages);
+    op.C = stage_pad(cfg, cfg.n_stages);
     op.K = cfg.kernel_size;
     op.slope = 0.01f;
     op.use_tanh = cfg.use_tanh;

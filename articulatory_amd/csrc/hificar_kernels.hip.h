@@ -338,6 +338,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         }
         __syncthreads();  // the last tile's accumulators are in the out-buffer
         if (have_prev) write_out(Tprev, tid, 512);  // all eight waves share the final output pass (nothing left to hide it behind)
+        HIFICAR_STAMP(63);
         return;
     }
 
@@ -541,7 +542,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         }
     }
     __syncthreads();  // matches the loader waves' final barrier
+    HIFICAR_STAMP(62);
     if (last >= 0) write_out(decode(tile_of(last)), tid, 512);
+    HIFICAR_STAMP(63);
 }
 
 template <int MI, int WM, int WN, int NC16>
@@ -1225,6 +1228,37 @@ __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p)
         }
         const size_t obase = p.slots ? (size_t)p.slots[seq].x * p.out_bstride + (size_t)p.hop * p.slots[seq].y : (size_t)seq * p.out_bstride;
         p.out[obase + t] = p.use_tanh ? tanhf(s) : s;
+    }
+}
+
+// Debug tap (hificar_debug_tap): channels-last rows (pitch floats per row; channels c0 .. c0+C) -> (sequence, channel, row), the
+// reference's (B, C, L) layout.  split = 1: the source holds split rows [hi | lo] of bf16 (|pitch| channels each): value = hi + lo.
+struct TapParams {
+    const void* src;
+    float* dst;
+    int pitch;  // floats per source row (negative: split rows of -pitch channels)
+    int c0, C, rows;
+    int src_rows;     // rows per sequence in the source (>= rows)
+    long long total;  // sequences * C * rows
+    int split;
+};
+
+__global__ __launch_bounds__(256) void tap_copy_kernel(const TapParams p) {
+    const int pitch = p.pitch < 0 ? -p.pitch : p.pitch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i % p.rows);
+        const long long bc = i / p.rows;
+        const int c = (int)(bc % p.C);
+        const long long b = bc / p.C;
+        const size_t row = (size_t)b * p.src_rows + r;
+        float v;
+        if (p.split) {
+            const __bf16* rp = reinterpret_cast<const __bf16*>(p.src) + row * pitch * 2;
+            v = (float)rp[p.c0 + c] + (float)rp[pitch + p.c0 + c];
+        } else {
+            v = reinterpret_cast<const float*>(p.src)[row * pitch + p.c0 + c];
+        }
+        p.dst[i] = v;
     }
 }
 

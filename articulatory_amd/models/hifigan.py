@@ -142,7 +142,8 @@ class HiFiGANGenerator(torch.nn.Module):
         use_ph_loss=False,
         final_scale=None,  # present in e2w_hifigan_car.yaml:42; unused by the network
         extra_art=None,  # present in e2w_hifigan_car.yaml:54; only read by the WSOLA driver
-        precision=None,  # "bf16x3" (default; or $HIFICAR_PRECISION) | "f32": conv arithmetic, see DESIGN.md §3
+        precision=None,  # "f32" (default: the reference's IEEE fp32 products; or $HIFICAR_PRECISION) | "bf16x3" (opt-in fast mode,
+                         # 16-bit-significand products): conv arithmetic, see DESIGN.md §3
     ):
         super().__init__()
         # same validity checks as the reference (hifigan.py:78-80)
@@ -157,7 +158,7 @@ class HiFiGANGenerator(torch.nn.Module):
             if val is not None and any(v != "default" for v in val):
                 raise NotImplementedError(f"{name}: only None / 'default' entries are supported (as in the reference)")
         if precision is None:
-            precision = os.environ.get("HIFICAR_PRECISION", "bf16x3")
+            precision = os.environ.get("HIFICAR_PRECISION", "f32")
         if precision not in _native.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_native.PRECISIONS)}")
 
@@ -360,6 +361,40 @@ class HiFiGANGenerator(torch.nn.Module):
         return [dict(name=stats[i].name.decode(), launches=int(stats[i].launches), total_ms=float(stats[i].total_ms),
                      flops=float(stats[i].flops), bytes=float(stats[i].bytes)) for i in range(min(n.value, 96))]
 
+    def debug_taps(self, names, c, ar=None):
+        """Parity aid (C ABI: hificar_debug_tap): one forward that also returns the named per-layer intermediates in the
+        reference's (B, C, L) layout — what forward hooks on the reference's modules see.  Names: "ar_feats", "input_conv",
+        "upsamples.<i>", "blocks.<n>.convs1.<d>", "blocks.<n>.x.<d>" (residual stream after dilation d), "blocks.<n>".
+        Returns (out, {name: tensor})."""
+        handle = self._native_handle()
+        B, _, T = c.shape
+        p = self._params
+        taps = {}
+        for name in names:
+            parts = name.split(".")
+            if name == "ar_feats":
+                shape = (B, p["ar_output"])
+            elif name == "input_conv":
+                shape = (B, p["channels"], T)
+            else:
+                if parts[0] == "upsamples":
+                    stage = int(parts[1])
+                elif parts[0] == "blocks":
+                    stage = int(parts[1]) // self.num_blocks
+                else:
+                    raise ValueError(f"unknown tap {name!r}")
+                L = T * int(np.prod(p["upsample_scales"][:stage + 1]))
+                shape = (B, p["channels"] // (2 ** (stage + 1)), L)
+            taps[name] = torch.full(shape, float("nan"), dtype=torch.float32, device=c.device)
+        try:
+            for name, t in taps.items():
+                _native.check(self._lib.hificar_debug_tap(handle, name.encode(), t.data_ptr(), t.numel()), "hificar_debug_tap")
+            out = self.forward(c, ar=ar)
+            torch.cuda.synchronize(c.device)
+        finally:
+            self._lib.hificar_debug_tap(handle, None, None, 0)
+        return out, taps
+
     # ------------------------------------------------------------------ forward paths
     def _check_input(self, c):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
@@ -374,12 +409,15 @@ class HiFiGANGenerator(torch.nn.Module):
 
     def _lengths_arg(self, lengths, B, T, device):
         """lengths (sequence / tensor of B frame counts) -> int32 device tensor for the ragged entry points."""
-        lengths = torch.as_tensor(lengths, dtype=torch.int32).reshape(-1)
-        if lengths.numel() != B:
-            raise RuntimeError(f"lengths has {lengths.numel()} entries for a batch of {B}")
-        if int(lengths.min()) < 0 or int(lengths.max()) > T:
+        if isinstance(lengths, torch.Tensor):
+            host = lengths.detach().to("cpu", torch.int32).reshape(-1).contiguous()  # the C ABI reads the host copy on the host
+        else:
+            host = torch.as_tensor(lengths, dtype=torch.int32).reshape(-1).contiguous()
+        if host.numel() != B:
+            raise RuntimeError(f"lengths has {host.numel()} entries for a batch of {B}")
+        if B and (int(host.min()) < 0 or int(host.max()) > T):
             raise RuntimeError(f"lengths must lie in [0, {T}]")
-        return lengths.contiguous(), lengths.to(device).contiguous()  # (host copy, device copy)
+        return host, host.to(device).contiguous()  # (host copy, device copy)
 
     def forward(self, c, spk_id=None, ar=None, ph=None, lengths=None):
         """c: (B, in_channels[-ar_output], T) -> (B, out_channels, T * prod(upsample_scales))  (hifigan.py:198-239).

@@ -12,6 +12,11 @@ PastFCEncoder and the sample feedback included.  Inputs and weights are resident
 region.  With N > 1 every rank synthesises its own 64 utterances (weak scaling, no data-path collective)
 and the step ends with the one RCCL all-gather that collects the waveforms.
 
+The headline (`value`, `dtype: "fp32"`, `roofline`) is the reference's arithmetic: exact IEEE fp32 products on
+v_mfma_f32_32x32x2_f32.  The split-bf16 fast mode (`--precision bf16x3`, 16-bit-significand products, 1.5e-5 of
+max|y| from fp32) is opt-in and reported as the labelled secondary leg `fast_bf16x3` with the same steps / warm-up
+and its own roofline block.  `batch_sweep` repeats the fp32 measurement at batch 1 and 8 (north_star: 1/8/64).
+
 Prints ONE JSON line on rank 0.  `roofline` is measured in a second pass of the same K steps with every
 kernel launch bracketed by HIP events on the launch stream (libhificar's profile hooks) so that the
 event traffic does not perturb `value`; `cpu_baseline` times the CPU oracle on a bounded sample.
@@ -39,6 +44,9 @@ CAR_PARAMS = dict(
 HOP = 80
 SAMPLING_RATE = 16000
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}  # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_HBM_GBS = 8000.0                              # same guide: HBM3E 8 TB/s spec
+DTYPE_NAME = {"f32": "fp32", "bf16x3": "bf16x3"}
+MFMA_PER_MAC = {"f32": 1, "bf16x3": 3}             # bf16x3 issues 3 bf16 MFMAs per algorithmic MAC
 
 
 def cpu_baseline(params, sd, chunk_frames, seed):
@@ -82,7 +90,98 @@ def cpu_baseline(params, sd, chunk_frames, seed):
     }
 
 
-def main():
+def make_step(synth, feats, use_dist, world, gather="f32", pcm16=None):
+    """One bench step on this rank: synthesise this rank's batch, then (N > 1) the one collective that collects the
+    waveforms ("waveform collection only").  ``gather="pcm16"`` converts to PCM_16 on the device first
+    and gathers bytes (half the traffic on the links; RCCL / gloo have no int16 type).  Returns (step, gathered)."""
+    import torch
+    import torch.distributed as dist
+
+    state = {"gathered": None}
+
+    def step():
+        y = synth(feats)
+        if use_dist:
+            send = pcm16(y) if gather == "pcm16" else y
+            if state["gathered"] is None:
+                state["gathered"] = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+            out = state["gathered"]
+            if send.dtype == torch.int16:
+                dist.all_gather_into_tensor(out.view(torch.uint8), send.contiguous().view(torch.uint8))
+            else:
+                dist.all_gather_into_tensor(out, send.contiguous())
+        return y
+
+    return step, state
+
+
+def timed_steps(step, fence, steps, warmup, use_dist=False, device=None):
+    """W untimed warm-up steps, then exactly K steps between two fences (barrier + device sync); MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    y = None
+    for _ in range(warmup):
+        y = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, y
+
+
+def roofline_block(stats, precision, wall_s, steps, traffic_table):
+    """`roofline` object for the kernel with the largest total time of an event-bracketed pass.
+
+    achieved = algorithmic flops (or bytes) of the launches / their summed event time; `bound` is derived from the
+    kernel's own arithmetic intensity against the machine balance of its MFMA instruction (not hard-coded)."""
+    dom = stats[0]
+    total_ms = sum(s["total_ms"] for s in stats)
+    sec = dom["total_ms"] * 1e-3
+    tflops = dom["flops"] / sec / 1e12
+    gbs = dom["bytes"] / sec / 1e9
+    peak_tf = PEAK_TFLOPS[precision]
+    intensity = dom["flops"] / max(dom["bytes"], 1.0)
+    balance = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+    bound = "mfma" if intensity >= balance else "hbm"
+    traffic = (traffic_table or {}).get(precision, {}).get(dom["name"])
+    alg_bytes = dom["bytes"] / dom["launches"]
+    mm = MFMA_PER_MAC[precision]
+    blk = {
+        "bound": bound, "kernel": dom["name"],
+        "achieved": round(tflops if bound == "mfma" else gbs, 2),
+        "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
+        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+        "frac": round((tflops / peak_tf) if bound == "mfma" else (gbs / PEAK_HBM_GBS), 4),
+        "traffic": traffic,
+        "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, per launch)" if traffic else None,
+        "algorithmic_bytes": round(alg_bytes),
+        "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
+        "flops_per_byte": round(intensity, 1), "machine_balance_flops_per_byte": round(balance, 1),
+        "achieved_tflops": round(tflops, 2), "achieved_hbm_gbs_algorithmic": round(gbs, 1),
+        "mfma_issue_tflops": round(tflops * mm, 2), "mfma_issue_frac": round(tflops * mm / peak_tf, 4),
+        "launches": dom["launches"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
+        "flops_per_launch": round(dom["flops"] / dom["launches"], 1),
+        "kernel_time_share": round(dom["total_ms"] / total_ms, 4),
+        "all_kernels": [{"name": s["name"], "launches": s["launches"], "total_ms": round(s["total_ms"], 3),
+                         "avg_us": round(s["total_ms"] * 1e3 / s["launches"], 2),
+                         "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2),
+                         "algorithmic_bytes": round(s["bytes"] / s["launches"]),
+                         "traffic": (traffic_table or {}).get(precision, {}).get(s["name"])} for s in stats],
+        "events_pass_ms_per_step": round(wall_s / steps * 1e3, 3),
+    }
+    return blk
+
+
+def main(argv=None, synth_factory=None):
+    """``synth_factory`` is a test hook (tests/test_distributed_gloo.py runs this very function under a 2-process gloo
+    torchrun on CPU with a stand-in synthesis function); the product path never passes it."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -90,18 +189,20 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0, help="clip length")
     ap.add_argument("--chunk-frames", type=int, default=25, help="batch_max_steps // hop_size (e2w_hifigan_car.yaml: 2000/80)")
-    ap.add_argument("--precision", default=os.environ.get("HIFICAR_PRECISION", "bf16x3"), choices=["f32", "bf16x3"])
+    ap.add_argument("--precision", default=os.environ.get("HIFICAR_PRECISION", "f32"), choices=["f32", "bf16x3"],
+                    help="conv arithmetic of the headline: f32 = the reference's IEEE fp32 products (default)")
+    ap.add_argument("--gather", default="f32", choices=["f32", "pcm16"],
+                    help="N > 1: collect float waveforms (default) or PCM_16 converted on the device (half the bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact-check", action="store_true",
-                    help="skip the extra leg that re-runs the batch with the exact-fp32 arithmetic (N=1 only)")
+    ap.add_argument("--no-fast-leg", action="store_true", help="skip the secondary bf16x3 leg (N=1 only)")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the batch 1 / 8 legs (N=1 only)")
     ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
-    from articulatory_amd.models import HiFiGANGenerator
     from articulatory_amd.utils.synth import synth_features, synth_state_dict
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,62 +213,74 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
                              f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a MI355X: no GPU visible (the generator has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    on_gpu = synth_factory is None
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a MI355X: no GPU visible (the generator has no CPU path)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun the RCCL path is exercised even at world size 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm
+        if on_gpu:
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
 
     params = dict(CAR_PARAMS)
     sd = synth_state_dict(params, seed=1234)
-    g = HiFiGANGenerator(**params, precision=args.precision)
-    g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    g.remove_weight_norm()
-    g = g.eval().to(dev)
+    g = None
+    if on_gpu:
+        from articulatory_amd.models import HiFiGANGenerator
+        from articulatory_amd.utils import pcm16
+
+        g = HiFiGANGenerator(**params, precision=args.precision)
+        g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        g.remove_weight_norm()
+        g = g.eval().to(dev)
+
+        def synth(x):
+            return g.ar_synthesis(x, args.chunk_frames)
+    else:
+        synth, pcm16 = synth_factory(params, sd, args)
 
     B = args.batch
     T = int(round(args.seconds * SAMPLING_RATE / HOP))
     n_samples = B * T * HOP
-    # synthetic 13-dim pitch+EMA, seed 20260929 + config index 3 + rank
-    feats = torch.from_numpy(synth_features(B, T, 13, seed=20260929 + 3 + 1000 * rank)).permute(0, 2, 1).contiguous().to(dev)
-    gathered = torch.empty((world * B, T * HOP), dtype=torch.float32, device=dev) if use_dist else None
 
-    def step():
-        y = g.ar_synthesis(feats, args.chunk_frames)
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, y)  # waveform collection only
-        return y
+    def features(batch):
+        # synthetic 13-dim pitch+EMA, seed 20260929 + config index 3 + rank
+        return torch.from_numpy(synth_features(batch, T, 13, seed=20260929 + 3 + 1000 * rank)).permute(0, 2, 1).contiguous().to(dev)
+
+    feats = features(B)
+    step, gstate = make_step(synth, feats, use_dist, world, args.gather, pcm16)
 
     def fence():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            y = step()
-        fence()
-        dt = time.perf_counter() - t0
+        dt, y = timed_steps(step, fence, args.steps, args.warmup, use_dist, dev)
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         # the gathered block of this rank must be its own waveform (collection only, no arithmetic)
-        assert torch.equal(gathered[rank * B:(rank + 1) * B], y), "all-gather returned a different waveform"
+        mine = gstate["gathered"][rank * B:(rank + 1) * B]
+        assert torch.equal(mine, pcm16(y) if args.gather == "pcm16" else y), "all-gather returned a different waveform"
     assert bool(torch.isfinite(y).all()), "non-finite output"
 
     ms_per_step = dt / args.steps * 1e3
     value = world * n_samples * args.steps / dt
-    macs_step = g.macs(B, args.chunk_frames) * (T // args.chunk_frames) + (g.macs(B, T % args.chunk_frames) if T % args.chunk_frames else 0.0)
 
+    def macs_per_step(batch):
+        if g is None:
+            return 0.0
+        return g.macs(batch, args.chunk_frames) * (T // args.chunk_frames) + (g.macs(batch, T % args.chunk_frames) if T % args.chunk_frames else 0.0)
+
+    macs_step = macs_per_step(B)
     out = {
         "metric": "audio samples/sec (16 kHz) EMA->wav HiFi-CAR, batch 64",
         "value": round(value, 1),
@@ -179,79 +292,96 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": args.precision,
+        "dtype": DTYPE_NAME[args.precision],
         "data": "synthetic",
         "config": {
             "workload": "configs[2]: HiFi-CAR (e2w_hifigan_car.yaml generator) 13-dim pitch+EMA -> 16 kHz, "
                         f"batch {B}/GPU, {args.seconds:g} s clips, {T // args.chunk_frames} sequential chunks of {args.chunk_frames} frames",
             "batch_per_gpu": B, "frames": T, "chunk_frames": args.chunk_frames, "samples_per_step_per_gpu": n_samples,
             "weights": "synthetic seed 1234 (articulatory_amd.utils.synth)", "parallelism": f"utterance-sharded x{world}",
+            "arithmetic": "exact fp32 products (v_mfma_f32_32x32x2_f32), fp32 accumulate" if args.precision == "f32"
+                          else "split-bf16 products hi*hi + hi*lo + lo*hi (3 x v_mfma_f32_32x32x16_bf16), fp32 accumulate",
+            "gather": (args.gather if use_dist else "none"),
         },
         "x_realtime": round(value / SAMPLING_RATE, 1),
         "algorithmic_tflops": round(2.0 * macs_step * world * args.steps / dt / 1e12, 2),
     }
+    if not on_gpu:
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return out
+
+    traffic_table = None
+    tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic_table = json.load(f)
+
+    def event_pass(x, steps):
+        g.profile_begin()
+        te0 = time.perf_counter()
+        for _ in range(steps):
+            g.ar_synthesis(x, args.chunk_frames)
+        stats = g.profile_end()
+        return stats, time.perf_counter() - te0
 
     if rank == 0 and not args.no_roofline:
         with torch.no_grad():
-            g.profile_begin()
-            te0 = time.perf_counter()
-            for _ in range(args.steps):
-                g.ar_synthesis(feats, args.chunk_frames)
-            stats = g.profile_end()
-            te = time.perf_counter() - te0
-        dom = stats[0]
-        total_ms = sum(s["total_ms"] for s in stats)
-        achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.precision]
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(args.precision, {}).get(dom["name"])
-        out["roofline"] = {
-            "bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            # bf16x3 issues 3 bf16 MFMAs per algorithmic MAC: the matrix pipe itself runs at 3x `achieved`
-            "mfma_issue_tflops": round(achieved * (3 if args.precision == "bf16x3" else 1), 2),
-            "mfma_issue_frac": round(achieved * (3 if args.precision == "bf16x3" else 1) / peak, 4),
-            "launches": dom["launches"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
-            "flops_per_launch": round(dom["flops"] / dom["launches"], 1),
-            "kernel_time_share": round(dom["total_ms"] / total_ms, 4),
-            "all_kernels": [{"name": s["name"], "launches": s["launches"], "total_ms": round(s["total_ms"], 3),
-                             "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2)} for s in stats],
-            "events_pass_ms_per_step": round(te / args.steps * 1e3, 3),
-        }
+            stats, te = event_pass(feats, args.steps)
+        out["roofline"] = roofline_block(stats, args.precision, te, args.steps, traffic_table)
     if use_dist:
         dist.barrier()
 
-    if rank == 0 and world == 1 and args.precision != "f32" and not args.no_exact_check:
-        # Same batch through the exact-fp32 MFMA arithmetic of the same library: its throughput, and how far the
-        # default (split-bf16) arithmetic is from it on this very input — the parity figure that goes with `value`.
-        with torch.no_grad():
-            y_fast = g.ar_synthesis(feats, args.chunk_frames)
-            g.set_precision("f32")
-            y_exact = g.ar_synthesis(feats, args.chunk_frames)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(2):
-                g.ar_synthesis(feats, args.chunk_frames)
-            torch.cuda.synchronize()
-            dte = (time.perf_counter() - t0) / 2
-            g.set_precision(args.precision)
-        out["exact_f32"] = {
-            "value": round(n_samples / dte, 1), "unit": "samples/s", "x_realtime": round(n_samples / dte / SAMPLING_RATE, 1),
-            "algorithmic_tflops": round(2.0 * macs_step / dte / 1e12, 2),
-            "max_rel_diff_of_default_arithmetic": float((y_fast - y_exact).abs().max() / y_exact.abs().max()),
-            "tolerance": 1e-3,
-        }
+    solo = rank == 0 and world == 1
+    if solo and not args.no_batch_sweep:
+        # north_star: throughput at batch 1 / 8 / 64 (the headline above is batch 64), same clips, same arithmetic
+        sweep = []
+        for b in (1, 8):
+            xb = feats[:b].contiguous() if b <= B else features(b)
+            with torch.no_grad():
+                k = max(3, min(args.steps, 10))
+                dtb, _ = timed_steps(lambda: g.ar_synthesis(xb, args.chunk_frames), torch.cuda.synchronize, k, 2)
+            vb = b * T * HOP * k / dtb
+            tf = 2.0 * macs_per_step(b) * k / dtb / 1e12
+            sweep.append({"batch": b, "value": round(vb, 1), "unit": "samples/s", "x_realtime": round(vb / SAMPLING_RATE, 1),
+                          "ms_per_step": round(dtb / k * 1e3, 3), "steps": k, "algorithmic_tflops": round(tf, 2),
+                          "frac_of_mfma_peak": round(tf / PEAK_TFLOPS[args.precision], 4)})
+        sweep.append({"batch": B, "value": out["value"], "unit": "samples/s", "x_realtime": out["x_realtime"],
+                      "ms_per_step": out["ms_per_step"], "steps": args.steps, "algorithmic_tflops": out["algorithmic_tflops"],
+                      "frac_of_mfma_peak": round(out["algorithmic_tflops"] / PEAK_TFLOPS[args.precision], 4)})
+        out["batch_sweep"] = sweep
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if solo and args.precision == "f32" and not args.no_fast_leg:
+        # Secondary leg: the same batch through the opt-in split-bf16 arithmetic of the same library, same steps and warm-up,
+        # its own roofline block, and how far its waveform is from the fp32 one on this very input.
+        with torch.no_grad():
+            y_exact = g.ar_synthesis(feats, args.chunk_frames)
+            g.set_precision("bf16x3")
+            dtf, y_fast = timed_steps(lambda: g.ar_synthesis(feats, args.chunk_frames), torch.cuda.synchronize, args.steps, args.warmup)
+            vf = n_samples * args.steps / dtf
+            leg = {
+                "dtype": "bf16x3", "note": "opt-in fast mode (precision='bf16x3'): 16-bit-significand products, NOT the reference's arithmetic",
+                "value": round(vf, 1), "unit": "samples/s", "x_realtime": round(vf / SAMPLING_RATE, 1),
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dtf / args.steps * 1e3, 3),
+                "algorithmic_tflops": round(2.0 * macs_step * args.steps / dtf / 1e12, 2),
+                "max_rel_diff_vs_fp32": float((y_fast - y_exact).abs().max() / y_exact.abs().max()), "tolerance": 1e-3,
+            }
+            if not args.no_roofline:
+                stats, te = event_pass(feats, args.steps)
+                leg["roofline"] = roofline_block(stats, "bf16x3", te, args.steps, traffic_table)
+            g.set_precision(args.precision)
+        out["fast_bf16x3"] = leg
+
+    if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, sd, args.chunk_frames, seed=20260929)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

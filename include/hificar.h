@@ -167,6 +167,19 @@ typedef struct hificar_kernel_stat {
 int hificar_profile_begin(hificar_handle* h);
 int hificar_profile_end(hificar_handle* h, hificar_kernel_stat* stats, int max_stats, int* n_stats);
 
+/* Parity aid: per-layer intermediates of the forwards that follow, copied into caller buffers in the reference's (B, C, L)
+ * layout — what a forward hook on the reference's modules (articulatory/models/hifigan.py:221-231,
+ * articulatory/layers/residual_block.py:217-221) returns.  Names:
+ *   "ar_feats"                (B, ar_output)            PastFCEncoder output (pytorch_layers.py:459-460)
+ *   "input_conv"              (B, channels, T)          hifigan.py:221
+ *   "upsamples.<i>"           (B, C_i, L_i)             LeakyReLU + ConvTranspose1d output, hifigan.py:224
+ *   "blocks.<n>.convs1.<d>"   (B, C_i, L_i)             residual_block.py:218 (runs that layer pair unfused)
+ *   "blocks.<n>.x.<d>"        (B, C_i, L_i)             residual stream after dilation d: xt + x, residual_block.py:221
+ *   "blocks.<n>"              (B, C_i, L_i)             block output, hifigan.py:228
+ * dst: device pointer to `capacity` floats (an error is returned by the forward if it is too small); dst = NULL removes the
+ * tap, name = NULL removes all.  Taps add copies and (for convs1) extra launches: not for timed runs. */
+int hificar_debug_tap(hificar_handle* h, const char* name, float* dst, size_t capacity);
+
 void hificar_destroy(hificar_handle* h);
 
 const char* hificar_last_error(void);

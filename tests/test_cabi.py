@@ -82,7 +82,7 @@ def test_set_weight_validation(lib):
     (dict(out_channels=4), b"out_channels"),
     (dict(kernel_size=6), b"odd"),
     (dict(upsample_scales=[5, 4, 2, 2], upsample_kernel_sizes=[11, 8, 4, 4]), b"L_out"),
-    (dict(channels=64), b"multiple of 32"),
+    (dict(channels=8), b"halvings"),
     (dict(resblock_kernel_sizes=[3, 7, 11, 13], resblock_dilations=[[1]] * 4), b"n_blocks"),
 ])
 def test_create_rejects_unsupported(lib, over, msg):
@@ -91,6 +91,16 @@ def test_create_rejects_unsupported(lib, over, msg):
     rc = lib.hificar_create(ctypes.byref(cfg), ctypes.byref(h))
     assert rc == -1
     assert msg in lib.hificar_last_error(), lib.hificar_last_error()
+
+
+def test_create_accepts_any_width(lib):
+    """The reference builds channels // 2**i wide stages for any `channels` (hifigan.py:108-145); widths below / between MFMA-tile
+    multiples are padded to 32 channels internally (no compute call here: creation only needs no GPU)."""
+    for channels in (64, 48, 100, 16):
+        cfg = _native.make_config(_full_params(channels=channels), _native.PREC_F32)
+        h = ctypes.c_void_p()
+        assert lib.hificar_create(ctypes.byref(cfg), ctypes.byref(h)) == 0, lib.hificar_last_error()
+        lib.hificar_destroy(h)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

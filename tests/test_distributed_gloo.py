@@ -84,6 +84,30 @@ def test_sharded_synthesis_world2_gloo():
     assert err < 1e-6  # each rank's slice equals the unsharded result (utterances are independent)
 
 
+@pytest.mark.parametrize("gather", ["f32", "pcm16"])
+def test_bench_main_world2_gloo(gather):
+    """bench.py's own main() — step function, barrier + MAX-over-ranks timing, the waveform all-gather (float, or PCM_16
+    as bytes) and its self-check — under a 2-process torchrun on CPU/gloo with a stand-in synthesis function."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(repo, "tests", "dev", "bench_gloo_worker.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--seconds", "0.25", "--gather", gather]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["gather"] == gather and d["config"]["parallelism"] == "utterance-sharded x2"
+    # whole-job aggregate: both ranks' samples over the max-over-ranks time
+    assert abs(d["value"] - 2 * 2 * 50 * 80 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+
+
 def test_shard_items_deals_by_length():
     items = [("a", 5), ("b", 50), ("c", 7), ("d", 40), ("e", 6), ("f", 45)]
     shares = [shard_items(items, 2, r, length_of=lambda kv: kv[1]) for r in range(2)]

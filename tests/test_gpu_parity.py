@@ -101,6 +101,50 @@ def test_golden_nonar_inference(prec):
     assert rel_err(y.cpu().numpy(), gold["out"]) < g.tol
 
 
+def test_golden_small_model_every_layer(prec):
+    """The width-64 model of the reference's per-layer fixture (stage widths 32 / 16 / 8 / 4: narrower than an MFMA tile,
+    padded to 32 channels internally) — EVERY tapped layer output of the real reference (forward hooks on its modules,
+    oracle/make_golden.py) against the device's intermediates (hificar_debug_tap), not just the final waveform."""
+    params = dict(E2W_PARAMS, channels=64)
+    g, _ = make(params, prec)
+    gold = np.load(os.path.join(GOLDEN, "gold_fwd_small.npz"))
+    names = ["ar_feats", "input_conv"] + [f"upsamples.{i}" for i in range(4)] + [f"blocks.{b}" for b in range(12)]
+    for b in (0, 7):
+        names += [f"blocks.{b}.convs1.{d}" for d in range(3)] + [f"blocks.{b}.x.{d}" for d in range(3)]
+    with torch.no_grad():
+        y, taps = g.debug_taps(names, torch.from_numpy(gold["c"]).cuda(), ar=torch.from_numpy(gold["ar"]).cuda())
+        y_plain = g(torch.from_numpy(gold["c"]).cuda(), ar=torch.from_numpy(gold["ar"]).cuda())
+    tol = TOLS[prec]
+    assert rel_err(y.cpu().numpy(), gold["out"]) < tol and rel_err(y_plain.cpu().numpy(), gold["out"]) < tol
+    want = {"ar_feats": gold["tap.ar_feats"], "input_conv": gold["tap.input_conv"]}
+    for i in range(4):
+        want[f"upsamples.{i}"] = gold[f"tap.upsample{i}"]
+    for b in range(12):
+        want[f"blocks.{b}"] = gold[f"tap.block{b}"]
+    for b in (0, 7):
+        x = gold[f"tap.upsample{b // 3}"]
+        for d in range(3):
+            want[f"blocks.{b}.convs1.{d}"] = gold[f"tap.block{b}.convs1.{d}"]
+            x = gold[f"tap.block{b}.convs2.{d}"] + x  # residual_block.py:221
+            want[f"blocks.{b}.x.{d}"] = x
+    assert sorted(want) == sorted(names)
+    for name in names:
+        got = taps[name].cpu().numpy()
+        assert got.shape == want[name].shape, name
+        assert np.isfinite(got).all(), name
+        assert rel_err(got, want[name]) < tol, name
+
+
+def test_golden_small_mri_model(prec):
+    """MRI-shaped narrow model (scales 8/5/3/2, stage widths 32/16/8/4) against the reference's own output."""
+    params = dict(E2W_PARAMS, channels=64, in_channels=20 + 128, upsample_scales=[8, 5, 3, 2], upsample_kernel_sizes=[16, 10, 6, 4])
+    g, _ = make(params, prec)
+    gold = np.load(os.path.join(GOLDEN, "gold_fwd_small_mri.npz"))
+    with torch.no_grad():
+        y = g(torch.from_numpy(gold["c"]).cuda(), ar=torch.from_numpy(gold["ar"]).cuda())
+    assert rel_err(y.cpu().numpy(), gold["out"]) < TOLS[prec]
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (1, 7), (3, 33), (8, 25), (2, 129), (5, 64)])
 def test_forward_vs_oracle_shapes(car, B, T):
     g, w = car
@@ -139,6 +183,11 @@ UNIT_CONFIGS = {
                                      use_tanh=False),
     "nonar_in80": dict(in_channels=80, use_ar=False, channels=128, upsample_scales=[4, 2], upsample_kernel_sizes=[8, 4]),
     "k9_input_kernel": dict(channels=128, kernel_size=9, upsample_scales=[3, 2], upsample_kernel_sizes=[6, 4]),
+    # widths that are not MFMA-tile multiples (the reference accepts any, hifigan.py:108-145: channels // 2**i)
+    "narrow_c48_24_12": dict(channels=48, upsample_scales=[4, 2], upsample_kernel_sizes=[8, 4]),
+    "odd_c100_50_25_12": dict(channels=100, upsample_scales=[2, 3, 2], upsample_kernel_sizes=[4, 6, 4], resblock_kernel_sizes=[3, 7],
+                              resblock_dilations=[[1, 3], [1, 3, 5]]),
+    "tiny_c8_nonar": dict(channels=8, in_channels=5, use_ar=False, upsample_scales=[2, 2], upsample_kernel_sizes=[4, 4]),
 }
 
 

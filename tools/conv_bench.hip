@@ -5,10 +5,36 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 using namespace hificar;
 
-template <int MI, int WM, int WN, int NC16>
+static void summarize(const std::vector<unsigned long long>& ht, int G) {
+    // per-workgroup timeline summary over ALL workgroups (s_memtime ticks; MFMA wave 0 = row 0, loader wave 4 = row 1)
+    auto stat = [&](const char* what, std::vector<double> v) {
+        if (v.empty()) return;
+        std::sort(v.begin(), v.end());
+        printf("    %-34s min %8.0f  med %8.0f  p90 %8.0f  max %8.0f\n", what, v.front(), v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+    };
+    unsigned long long t0 = ~0ull;
+    for (int w = 0; w < G; ++w) t0 = std::min(t0, ht[(size_t)w * 128]);
+    std::vector<double> start, first_ready, mfma_end, wg_end, busy;
+    for (int w = 0; w < G; ++w) {
+        const unsigned long long* m = &ht[(size_t)w * 128];
+        start.push_back((double)(m[0] - t0));
+        if (m[2]) first_ready.push_back((double)(m[2] - m[0]));  // first barrier released: first item staged
+        if (m[62]) mfma_end.push_back((double)(m[62] - t0));
+        if (m[63]) wg_end.push_back((double)(m[63] - t0));
+        if (m[62] && m[2]) busy.push_back((double)(m[62] - m[2]));
+    }
+    stat("WG start (vs first WG)", start);
+    stat("start -> first item staged", first_ready);
+    stat("MFMA phase (first item -> last acc)", busy);
+    stat("last accumulators ready (abs)", mfma_end);
+    stat("WG end (abs)", wg_end);
+}
+
+template <int MI, int WM, int WN, int NC16, bool F32 = false>
 void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int dil, bool residual, int mode = 0) {
     constexpr int TM = WM * MI * 32;
     const int CH = NC16 * 16;
@@ -59,11 +85,12 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
     hipMalloc(&trace, (size_t)G * 2 * 64 * 8);
     hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
     mp.trace = trace;
-    auto kern = conv_bf16x3_kernel<MI, WM, WN, NC16>;
+    void (*kern)(const MultiConvParams) = conv_bf16x3_kernel<MI, WM, WN, NC16>;
+    if (F32) kern = conv_f32_kernel<MI, WM, WN, NC16>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    float ms = 0;
+    float ms = 0, ms1 = 0;
     for (int it = 0; it < 3; ++it) {
         hipEventRecord(e0);
         for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3(512), 2 * mp.buf_bytes + TM * (WN * 32 + 4) * 4, 0, mp);
@@ -71,9 +98,18 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
     }
-    printf("%-28s tiles=%d G=%d lds=%dKB  %.1f us/launch  %.0f TF-alg\n", label, mp.total_tiles, G, 2 * mp.buf_bytes / 1024, ms * 100, flops / (ms * 1e-4) / 1e12);
+    hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(512), 2 * mp.buf_bytes + TM * (WN * 32 + 4) * 4, 0, mp);  // the traced launch: alone
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms1, e0, e1);
+    printf("%-28s %s tiles=%d G=%d lds=%dKB  %.1f us/launch (back to back), %.1f us alone  %.0f TF-alg\n", label, F32 ? "f32" : "bf16x3", mp.total_tiles, G,
+           2 * mp.buf_bytes / 1024, ms * 100, ms1 * 1000, flops / (ms * 1e-4) / 1e12);
     std::vector<unsigned long long> ht((size_t)G * 2 * 64);
     hipMemcpy(ht.data(), trace, ht.size() * 8, hipMemcpyDeviceToHost);
+    summarize(ht, G);
     for (int wg : {0, G / 2}) {
         const unsigned long long* m = &ht[(size_t)wg * 2 * 64];
         const unsigned long long* l = m + 64;
@@ -157,13 +193,29 @@ void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks,
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
     {
         const int k3[3] = {11, 7, 3};
         run_pair<4, 2, 2, 4>("PAIR stage2 C64 L1000", 64, 1000, 64, 3, k3, 1);
         run_pair<4, 4, 1, 2>("PAIR stage3 C32 L2000", 64, 2000, 32, 3, k3, 1);
     }
     const int k3[3] = {11, 7, 3};
+    if (argc > 1 && !strcmp(argv[1], "f32")) {
+        run<2, 1, 4, 4, true>("stage0 (2,1,4) conv1", 64, 125, 256, 3, k3, 1, false);
+        run<2, 1, 4, 4, true>("stage0 (2,1,4) conv2+res", 64, 125, 256, 3, k3, 1, true);
+        run<2, 1, 4, 4, true>("stage0 (2,1,4) conv1 B=128", 128, 125, 256, 3, k3, 1, false);
+        run<4, 1, 4, 4, true>("stage0 (4,1,4) conv1", 64, 125, 256, 3, k3, 1, false);
+        run<4, 1, 4, 4, true>("stage1 (4,1,4) conv1", 64, 500, 128, 3, k3, 1, false);
+        run<4, 1, 4, 4, true>("stage1 (4,1,4) conv2+res", 64, 500, 128, 3, k3, 1, true);
+        run<4, 1, 4, 4, true>("stage1 (4,1,4) conv1 B=128", 128, 500, 128, 3, k3, 1, false);
+        run<4, 2, 2, 2, true>("stage2 C64 (4,2,2) conv1", 64, 1000, 64, 3, k3, 1, false);
+        run<4, 2, 2, 2, true>("stage2 C64 (4,2,2) conv2+res", 64, 1000, 64, 3, k3, 1, true);
+        run<4, 2, 2, 2, true>("stage2 C64 conv1 B=128", 128, 1000, 64, 3, k3, 1, false);
+        run<4, 4, 1, 1, true>("stage3 C32 (4,4,1) conv1", 64, 2000, 32, 3, k3, 1, false);
+        run<4, 4, 1, 1, true>("stage3 C32 (4,4,1) conv2+res", 64, 2000, 32, 3, k3, 1, true);
+        run<4, 4, 1, 1, true>("stage3 C32 conv1 B=128", 128, 2000, 32, 3, k3, 1, false);
+        return 0;
+    }
     run<4, 1, 4, 4>("stage0 TM128 TN128 (4,1,4)", 64, 125, 256, 3, k3, 1, false);
     run<2, 1, 4, 4>("stage0 TM64 TN128 (2,1,4)", 64, 125, 256, 3, k3, 1, false);
     run<2, 2, 2, 4>("stage0 TM128 TN64 (2,2,2)", 64, 125, 256, 3, k3, 1, false);

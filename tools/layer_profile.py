@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer kernel times of one AR chunk step (HIP-event profile hooks, HIFICAR_PROFILE_DETAIL=1).
-   python tools/layer_profile.py [--precision bf16x3] [--batch 64] [--frames 25] [--steps 20]"""
+   python tools/layer_profile.py [--precision f32|bf16x3] [--batch 64] [--frames 25] [--steps 20]"""
 import argparse
 import os
 import sys
@@ -15,7 +15,7 @@ from articulatory_amd.utils.synth import synth_features, synth_state_dict  # noq
 from bench import CAR_PARAMS  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--precision", default="bf16x3")
+ap.add_argument("--precision", default="f32")
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--frames", type=int, default=25)
 ap.add_argument("--steps", type=int, default=20)

@@ -13,7 +13,7 @@ from bench import CAR_PARAMS
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=256)
 ap.add_argument("--batch", type=int, default=64)
-ap.add_argument("--precision", default="bf16x3")
+ap.add_argument("--precision", default="f32")
 a = ap.parse_args()
 sd = synth_state_dict(CAR_PARAMS, seed=1234)
 g = HiFiGANGenerator(**CAR_PARAMS, precision=a.precision)
