@@ -126,11 +126,12 @@ def length_batches(items, batch_size, window=8):
 _A2W_MODES = ("default", "m2w", "a2w", "a2w_pcd")
 
 
-def iter_features(feats_scp=None, dumpdir=None, fmt="npy"):
-    """(utt_id, (T, C) ndarray) pairs from a kaldi-style ``utt_id path.npy`` scp (the reference's NpyScpLoader,
-    utils/utils.py:240-291) or from a dump dir of ``<utt_id>-feats.npy`` files (decode.py:207-222)."""
+def list_features(feats_scp=None, dumpdir=None, fmt="npy"):
+    """(utt_id, path) pairs of a kaldi-style ``utt_id path.npy`` scp (the reference's NpyScpLoader, utils/utils.py:240-291)
+    or of a dump dir of ``<utt_id>-feats.npy`` files (decode.py:207-222).  Nothing is loaded here."""
     if (feats_scp is not None) == (dumpdir is not None):
         raise ValueError("Please specify either --dumpdir or --feats-scp.")
+    pairs = []
     if feats_scp is not None:
         with open(feats_scp) as f:
             for line in f:
@@ -139,12 +140,29 @@ def iter_features(feats_scp=None, dumpdir=None, fmt="npy"):
                     continue
                 if not parts[1].endswith(".npy"):
                     raise ValueError("Not supported feats.scp type (only 'utt_id /path/to/utt_id.npy' entries are read here).")
-                yield parts[0], np.load(parts[1])
+                pairs.append((parts[0], parts[1]))
     else:
         if fmt != "npy":
             raise ValueError("Support only npy format here (h5py is not available in this image).")
         for path in sorted(glob.glob(os.path.join(dumpdir, "**", "*-feats.npy"), recursive=True)):
-            yield os.path.basename(path)[: -len("-feats.npy")], np.load(path)
+            pairs.append((os.path.basename(path)[: -len("-feats.npy")], path))
+    return pairs
+
+
+def npy_frames(path):
+    """Frame count of a (T, C) .npy feature file from its header alone (no data is read)."""
+    return int(np.load(path, mmap_mode="r").shape[0])
+
+
+def load_features(pairs):
+    """(utt_id, path) pairs -> (utt_id, (T, C) ndarray), one utterance at a time, as the reference's loop streams them."""
+    for utt_id, path in pairs:
+        yield utt_id, np.load(path)
+
+
+def iter_features(feats_scp=None, dumpdir=None, fmt="npy"):
+    """(utt_id, (T, C) ndarray) pairs, loaded lazily."""
+    return load_features(list_features(feats_scp, dumpdir, fmt))
 
 
 def get_parser():
@@ -246,15 +264,19 @@ def main(argv=None):
                                   f"{_A2W_MODES} are built (SURVEY.md §8 f3)")
     if config.get("transform") or config.get("input_transform"):
         raise NotImplementedError("feature transforms are not built")
-    items = list(iter_features(args.feats_scp, args.dumpdir, config.get("format", "npy")))
-    logging.info(f"The number of features to be decoded = {len(items)}.")
+    pairs = list_features(args.feats_scp, args.dumpdir, config.get("format", "npy"))
+    logging.info(f"The number of features to be decoded = {len(pairs)}.")
 
     if not torch.cuda.is_available():
         raise RuntimeError("decode: no GPU visible; this package has no CPU synthesis path")
     # under torchrun (one process per GPU) every rank decodes its own share of the list and writes its own files
     from articulatory_amd.bin.shard import shard_items
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    items = shard_items(items, length_of=lambda kv: kv[1].shape[0])
+    # shard the (utt_id, path) list first — lengths from the .npy headers — and load each rank's utterances lazily, one at a
+    # time (every rank loading the whole dataset would cost N x the I/O and a full copy in host RAM per rank)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        pairs = shard_items(pairs, length_of=lambda kv: npy_frames(kv[1]))
+    items = load_features(pairs)
     device = torch.device("cuda")
     model = load_model(args.checkpoint, config)
     logging.info(f"Loaded model parameters from {args.checkpoint}.")

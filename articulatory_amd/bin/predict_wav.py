@@ -23,12 +23,16 @@ from articulatory_amd.utils import load_model
 
 
 def write_wav(path, y, sampling_rate):
-    """float waveform in [-1, 1] -> mono PCM_16 WAV (what sf.write's default subtype produces for .wav)."""
+    """float waveform in [-1, 1] -> mono PCM_16 WAV (what sf.write's default subtype produces for .wav).
+
+    Sample conversion as libsndfile does it for float32 input (src/pcm.c f2s_array: lrintf(src * 32767.f), i.e. a FLOAT32
+    product rounded to nearest-even), so files match the reference's ``sf.write`` sample for sample inside [-1, 1]; outside it
+    libsndfile (clipping off, its default) wraps around where this writer clips."""
     y = np.asarray(y).reshape(-1)
     if y.dtype == np.int16:  # already converted on the device (articulatory_amd.utils.pcm16)
         pcm = y.astype("<i2")
     else:
-        pcm = np.clip(np.rint(y.astype(np.float64) * 32767.0), -32768, 32767).astype("<i2")
+        pcm = np.clip(np.rint(y.astype(np.float32) * np.float32(32767.0)), -32768, 32767).astype("<i2")
     with wave.open(path, "wb") as f:
         f.setnchannels(1)
         f.setsampwidth(2)

@@ -65,6 +65,7 @@ struct ConvLayer {
     uint16_t* d_w16 = nullptr;   // bf16x3 arithmetic: hi/lo bf16 weight fragments in MFMA lane order
     uint16_t* d_w16c = nullptr;  // same fragments packed with one K chunk = all channels (fused pair kernel, C <= 64)
     float* d_w32 = nullptr;      // exact-fp32 arithmetic: fp32 fragments in the same order
+    float* d_w32c = nullptr;     // fp32 fragments with one K chunk = all channels (fused pair kernel, C <= 64)
 };
 
 struct hificar_handle {
@@ -96,12 +97,25 @@ struct hificar_handle {
     void* h_tab = nullptr;
     size_t tab_bytes = 0;
     hipEvent_t tab_copied = nullptr;  // recorded behind the last upload: the staging copy may be rewritten once it has fired
-    // tile schedules (LPT assignment of tiles to workgroups), cached per launch shape
+    // tile schedules (LPT assignment of tiles to workgroups), cached per launch shape.  They live in append-only arenas: a
+    // device block plus a pinned host mirror, filled on the host and uploaded with ONE hipMemcpyAsync on the launch stream, so
+    // the first use of a new launch shape neither allocates nor synchronises (the first arena is allocated in hificar_finalize)
     struct Sched {
         int* d_start = nullptr;
         int* d_tiles = nullptr;
     };
     std::map<std::string, Sched> scheds;
+    struct Arena {
+        char* d = nullptr;
+        char* h = nullptr;
+        size_t cap = 0, used = 0;
+    };
+    std::vector<Arena> arenas;
+    // every call's work is ordered behind the previous call's even when the caller switches streams (the schedules, the packed
+    // step table and the workspace are shared state of the handle)
+    hipStream_t last_stream = nullptr;
+    bool have_last_stream = false;
+    hipEvent_t xstream_ev = nullptr;
     // debug taps (hificar_debug_tap): name -> (destination, capacity in floats); scratch for pre-activation copies
     struct Tap {
         float* dst;
@@ -143,6 +157,8 @@ struct ProfScope {
 };
 
 static size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+static int arena_add(hificar_handle* h, size_t min_bytes);
+static int bucket_frames(int T);
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static int stage_channels(const hificar_config& c, int i) { return c.channels >> i; }  // channels // 2**i
@@ -345,10 +361,11 @@ extern "C" void hificar_destroy(hificar_handle* h) {
     if (h->h_tab) (void)hipHostFree(h->h_tab);
     if (h->tap_scratch) (void)hipFree(h->tap_scratch);
     if (h->tab_copied) (void)hipEventDestroy(h->tab_copied);
-    for (auto& kv : h->scheds) {
-        (void)hipFree(kv.second.d_start);
-        (void)hipFree(kv.second.d_tiles);
+    for (auto& a : h->arenas) {
+        (void)hipFree(a.d);
+        (void)hipHostFree(a.h);
     }
+    if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
     delete h;
 }
 
@@ -482,8 +499,10 @@ static int pack_conv(hificar_handle* h, ConvLayer& L) {
 
     if ((rc = pack_w16(h, L, W, L.chunk16, &L.d_w16)) != HIFICAR_OK) return rc;
     if ((rc = pack_w32(h, L, W, L.chunk16, &L.d_w32)) != HIFICAR_OK) return rc;
-    if (!L.transposed && L.cin_pad == L.cin && (L.cin == 32 || L.cin == 64) && L.cout == L.cin)
+    if (!L.transposed && L.cin_pad == L.cin && (L.cin == 32 || L.cin == 64) && L.cout == L.cin) {
         if ((rc = pack_w16(h, L, W, L.cin_pad, &L.d_w16c)) != HIFICAR_OK) return rc;
+        if ((rc = pack_w32(h, L, W, L.cin_pad, &L.d_w32c)) != HIFICAR_OK) return rc;
+    }
     return HIFICAR_OK;
 }
 
@@ -548,11 +567,19 @@ extern "C" int hificar_finalize(hificar_handle* h) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 4, 1, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<4, 2, 2, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<4, 4, 1, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define HIFICAR_SET_ATTR(mi, wm, wn, nc)         \
     HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>())); \
     HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>()));
     HIFICAR_FOR_ALL_TILES(HIFICAR_SET_ATTR)
 #undef HIFICAR_SET_ATTR
+    if (h->arenas.empty()) {
+        int rca = arena_add(h, 0);
+        if (rca != HIFICAR_OK) return rca;
+    }
     HIP_TRY(hipDeviceSynchronize());
     h->tensors.clear();  // host copies no longer needed
     h->finalized = true;
@@ -615,7 +642,7 @@ static Workspace plan_workspace(const hificar_handle* h, int B, int T, void* bas
 
 extern "C" size_t hificar_workspace_bytes(const hificar_handle* h, int B, int T) {
     if (!h || B < 1 || T < 1) return 0;
-    return plan_workspace(h, B, T, nullptr).bytes;
+    return plan_workspace(h, B, bucket_frames(T), nullptr).bytes;
 }
 
 extern "C" double hificar_macs(const hificar_handle* h, int B, int T) {
@@ -641,12 +668,18 @@ extern "C" double hificar_macs(const hificar_handle* h, int B, int T) {
 // covers frames [f0, f0 + frames) of every utterance.
 struct Ragged {
     const int32_t* seq_len = nullptr;
+    int const_len = -1;  // >= 0 (and seq_len null): every utterance has this many frames, fewer than the launch covers (bucketed lengths)
     int f0 = 0;
     int frames = 0;
 };
 
+// Launch geometry of a non-AR forward is rounded up to a bucket of frames (the extra frames are masked exactly like the tail of a
+// ragged batch: bit-identical results), so that a dataset of many distinct utterance lengths shares launch shapes / schedules.
+static int bucket_frames(int T) { return T <= 32 ? T : round_up(T, 32); }
+
 static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, const float* res, float* y, const Ragged& rg) {
     p.seq_len = rg.seq_len;
+    p.len_const = rg.seq_len ? -1 : rg.const_len;
     p.len_f0 = rg.f0;
     p.len_max = rg.frames;
     p.len_mul = rg.frames > 0 ? rows / rg.frames : 1;
@@ -667,23 +700,56 @@ static void fill_params(ConvParams& p, const ConvLayer& L, int rows, int TM, con
     for (int r = 0; r < kMaxPhase; ++r) p.tap_off0[r] = r < L.n_phase ? L.tap_off[r][0] : 0;
 }
 
-// Launch nbr (1..3) same-shape conv layers ("branches") as one grid; branch = blockIdx.z.
+static constexpr size_t kArenaBytes = 16u << 20;
+static constexpr size_t kMaxArenas = 8;
+
+static int arena_add(hificar_handle* h, size_t min_bytes) {
+    hificar_handle::Arena a;
+    a.cap = std::max(kArenaBytes, round_up_sz(min_bytes, 4096));
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, a.cap));
+    a.d = static_cast<char*>(p);
+    hipError_t e = hipHostMalloc(&p, a.cap, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipFree(a.d);
+        return fail(HIFICAR_E_HIP, "hipHostMalloc(schedule arena) failed: %s", hipGetErrorString(e));
+    }
+    a.h = static_cast<char*>(p);
+    h->arenas.push_back(a);
+    return HIFICAR_OK;
+}
+
+// `bytes` of arena space: device pointer + the pinned host mirror to fill before the upload
+static int arena_take(hificar_handle* h, size_t bytes, char** d, char** hm) {
+    bytes = round_up_sz(bytes, 256);
+    if (h->arenas.empty() || h->arenas.back().used + bytes > h->arenas.back().cap) {
+        if (h->arenas.size() >= kMaxArenas) {
+            // a very large number of distinct launch shapes: recycle.  Kernels in flight may still read old schedules, so drain
+            // the device first (rare, off the hot path; hificar_forward buckets non-AR lengths so that keys repeat)
+            HIP_TRY(hipDeviceSynchronize());
+            h->scheds.clear();
+            for (auto& a : h->arenas) a.used = 0;
+            std::sort(h->arenas.begin(), h->arenas.end(), [](const hificar_handle::Arena& x, const hificar_handle::Arena& y) { return x.cap < y.cap; });
+            if (bytes > h->arenas.back().cap) return fail(HIFICAR_E_INVALID, "tile schedule of %zu bytes exceeds the arena", bytes);
+        } else {
+            int rc = arena_add(h, bytes);  // allocates: only when the pre-allocated arena is full
+            if (rc != HIFICAR_OK) return rc;
+        }
+    }
+    hificar_handle::Arena& a = h->arenas.back();
+    *d = a.d + a.used;
+    *hm = a.h + a.used;
+    a.used += bytes;
+    return HIFICAR_OK;
+}
+
 // Longest-processing-time-first assignment of `costs.size()` tiles to G workgroups; each workgroup's list is then
-// ordered light -> heavy (the kernel walks it in that order).  Uploaded once per launch shape and cached.
-static int get_schedule(hificar_handle* h, const std::string& key, const std::vector<double>& costs, int G,
+// ordered light -> heavy (the kernel walks it in that order).  Built once per launch shape, uploaded asynchronously on the
+// launch stream (the launch that follows is ordered behind the copy) and cached.
+static int get_schedule(hificar_handle* h, const std::string& key, const std::vector<double>& costs, int G, hipStream_t stream,
                         const int** d_start, const int** d_tiles) {
     auto it = h->scheds.find(key);
     if (it == h->scheds.end()) {
-        if (h->scheds.size() >= 4096) {
-            // many distinct launch shapes (e.g. non-AR inference over utterances of every length): drop the cache.
-            // Kernels still in flight may be reading old schedules, so drain the device first (rare, off the hot path).
-            HIP_TRY(hipDeviceSynchronize());
-            for (auto& kv : h->scheds) {
-                (void)hipFree(kv.second.d_start);
-                (void)hipFree(kv.second.d_tiles);
-            }
-            h->scheds.clear();
-        }
         const int n = (int)costs.size();
         std::vector<int> order(n);
         for (int i = 0; i < n; ++i) order[i] = i;
@@ -703,26 +769,40 @@ static int get_schedule(hificar_handle* h, const std::string& key, const std::ve
             top.first += costs[t];
             std::push_heap(heap.begin(), heap.end(), cmp);
         }
-        std::vector<int> start(G + 1, 0), tiles;
-        tiles.reserve(n);
+        const size_t n_start = (size_t)G + 1;
+        const size_t bytes = (round_up_sz(n_start, 4) + (size_t)std::max(n, 1)) * sizeof(int);
+        char *dp = nullptr, *hp = nullptr;
+        int rc = arena_take(h, bytes, &dp, &hp);
+        if (rc != HIFICAR_OK) return rc;
+        int* start = reinterpret_cast<int*>(hp);
+        int* tiles = start + round_up_sz(n_start, 4);
+        int pos = 0;
         for (int w = 0; w < G; ++w) {
-            std::reverse(lists[w].begin(), lists[w].end());  // heavy-first insertion order -> light first
-            start[w] = (int)tiles.size();
-            tiles.insert(tiles.end(), lists[w].begin(), lists[w].end());
+            start[w] = pos;
+            for (auto r = lists[w].rbegin(); r != lists[w].rend(); ++r) tiles[pos++] = *r;  // heavy-first insertion order -> light first
         }
-        start[G] = (int)tiles.size();
+        start[G] = pos;
+        HIP_TRY(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, stream));  // pinned source, never rewritten while cached
         hificar_handle::Sched sc;
-        void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, start.size() * sizeof(int)));
-        sc.d_start = static_cast<int*>(p);
-        HIP_TRY(hipMalloc(&p, std::max<size_t>(tiles.size(), 1) * sizeof(int)));
-        sc.d_tiles = static_cast<int*>(p);
-        HIP_TRY(hipMemcpy(sc.d_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(sc.d_tiles, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
+        sc.d_start = reinterpret_cast<int*>(dp);
+        sc.d_tiles = sc.d_start + round_up_sz(n_start, 4);
         it = h->scheds.emplace(key, sc).first;
     }
     *d_start = it->second.d_start;
     *d_tiles = it->second.d_tiles;
+    return HIFICAR_OK;
+}
+
+// Order this call's work behind the previous call's when the caller changed streams (shared handle state: schedules, step
+// table, workspace).  Same stream: nothing to do.
+static int enter_stream(hificar_handle* h, hipStream_t stream) {
+    if (h->have_last_stream && h->last_stream != stream) {
+        if (!h->xstream_ev) HIP_TRY(hipEventCreateWithFlags(&h->xstream_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(h->xstream_ev, h->last_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, h->xstream_ev, 0));
+    }
+    h->last_stream = stream;
+    h->have_last_stream = true;
     return HIFICAR_OK;
 }
 
@@ -830,8 +910,8 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
             key += "|" + layers[b]->name;
             for (int i = 0; i < tpb; ++i) costs[(size_t)b * tpb + i] = layers[b]->ntaps + 1.0;  // + fixed per-tile overhead
         }
-        key += "|" + std::to_string(nseq) + "x" + std::to_string(rows) + "t" + std::to_string(TM) + "w" + std::to_string(tc.WN);
-        int rc2 = get_schedule(h, key, costs, (int)grid.x, &mp.sched_start, &mp.sched_tiles);
+        key += "|" + std::to_string(nseq) + "x" + std::to_string((rows + TM - 1) / TM) + "t" + std::to_string(TM) + "w" + std::to_string(tc.WN);
+        int rc2 = get_schedule(h, key, costs, (int)grid.x, stream, &mp.sched_start, &mp.sched_tiles);
         if (rc2 != HIFICAR_OK) return rc2;
     }
     char kname[96];
@@ -850,7 +930,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     return HIFICAR_OK;
 }
 
-// Fused conv1 -> LeakyReLU -> conv2 (+ residual) for C = 32 / 64 (conv_pair_bf16x3_kernel).
+// Fused conv1 -> LeakyReLU -> conv2 (+ residual) for C = 32 / 64 (conv_pair_bf16x3_kernel / conv_pair_f32_kernel).
 struct PairIOB {
     const float* xf;  // fp32 pre-activation input of conv1 (activated + split while staging), or null when xs is given
     const char* xs;   // split input of conv1
@@ -860,21 +940,22 @@ struct PairIOB {
 };
 
 static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const ConvLayer& b) {
-    if (!(h->use_pair && h->precision == HIFICAR_PREC_BF16X3 && a.d_w16c && b.d_w16c && a.cin == b.cin && a.ntaps >= 2 &&
+    if (!(h->use_pair && a.d_w16c && b.d_w16c && a.d_w32c && b.d_w32c && a.cin == b.cin && a.ntaps >= 2 &&
           b.ntaps >= 2 && b.dilation == 1 && a.K == b.K))
         return false;
-    // the LDS budget of launch_pair_bf16x3 (wide dilations x long kernels do not fit: those pairs run layer by layer)
+    // the LDS budget of launch_pair (wide dilations x long kernels do not fit: those pairs run layer by layer)
     const int C = a.cin, TMc = (C == 64 ? 2 : 4) * 4 * 32;
     const size_t in_bytes = round_up_sz((size_t)(TMc + a.off_max - a.off_min) * C * 4, 1024);
     const size_t ts_bytes = std::max<size_t>((size_t)(TMc + 16) * C * 4, (size_t)TMc * (C + 4) * sizeof(float));
     return in_bytes + ts_bytes <= 160 * 1024;
 }
 
-static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, const ConvLayer* const* l2, int nbr, int nseq, int rows,
+static int launch_pair(hificar_handle* h, const ConvLayer* const* l1, const ConvLayer* const* l2, int nbr, int nseq, int rows,
                               const PairIOB* io, float slope, const Ragged& rg, hipStream_t stream) {
     const int C = l1[0]->cin;
     const int MI = 4, WM = C == 64 ? 2 : 4;
     const int TMc = WM * MI * 32, RB = C * 4;
+    const bool f32 = h->precision == HIFICAR_PREC_F32;
     PairParams pp;
     memset(&pp, 0, sizeof(pp));
     int halo_max = 0;
@@ -885,8 +966,8 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
         const ConvLayer& B = *l2[b];
         fill_params(pp.p1[b], A, rows, TMc, nullptr, nullptr, rg);
         fill_params(pp.p2[b], B, rows, TMc, io[b].res, io[b].y, rg);
-        pp.p1[b].w16 = reinterpret_cast<const bf16x8*>(A.d_w16c);
-        pp.p2[b].w16 = reinterpret_cast<const bf16x8*>(B.d_w16c);
+        pp.p1[b].w16 = f32 ? reinterpret_cast<const bf16x8*>(A.d_w32c) : reinterpret_cast<const bf16x8*>(A.d_w16c);
+        pp.p2[b].w16 = f32 ? reinterpret_cast<const bf16x8*>(B.d_w32c) : reinterpret_cast<const bf16x8*>(B.d_w16c);
         pp.p1[b].xs = io[b].xs;
         pp.p1[b].xf = io[b].xf;
         pp.p1[b].slope_in = slope;
@@ -920,19 +1001,25 @@ static int launch_pair_bf16x3(hificar_handle* h, const ConvLayer* const* l1, con
             key += "|" + l1[b]->name;
             for (int i = pp.tile_start[b]; i < pp.tile_start[b + 1]; ++i) costs[i] = l1[b]->ntaps + l2[b]->ntaps + 2.0;
         }
-        key += "|" + std::to_string(nseq) + "x" + std::to_string(rows);
-        int rc2 = get_schedule(h, key, costs, (int)grid.x, &pp.sched_start, &pp.sched_tiles);
+        key += "|" + std::to_string(nseq);
+        for (int b = 0; b < nbr; ++b) key += "x" + std::to_string(pp.tiles_per_seq[b]);
+        int rc2 = get_schedule(h, key, costs, (int)grid.x, stream, &pp.sched_start, &pp.sched_tiles);
         if (rc2 != HIFICAR_OK) return rc2;
     }
     char kname[96];
-    snprintf(kname, sizeof(kname), "conv_pair_bf16x3_kernel<%d,%d,%d,%d>", MI, WM, 4 / WM, C / 16);
+    snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_pair_f32_kernel" : "conv_pair_bf16x3_kernel", MI, WM, 4 / WM, C / 16);
     if (h->profile_detail) {
         const size_t n = strlen(kname);
         snprintf(kname + n, sizeof(kname) - n, "|%s x%d", l1[0]->name.c_str(), nbr);
     }
     ProfScope prof(h, stream, kname, flops, bytes);
-    if (C == 64) hipLaunchKernelGGL((conv_pair_bf16x3_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
-    else hipLaunchKernelGGL((conv_pair_bf16x3_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
+    if (f32) {
+        if (C == 64) hipLaunchKernelGGL((conv_pair_f32_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
+        else hipLaunchKernelGGL((conv_pair_f32_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
+    } else {
+        if (C == 64) hipLaunchKernelGGL((conv_pair_bf16x3_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
+        else hipLaunchKernelGGL((conv_pair_bf16x3_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(HIFICAR_E_HIP, "pair launch (%s) failed: %s", l1[0]->name.c_str(), hipGetErrorString(e));
     return HIFICAR_OK;
@@ -984,10 +1071,13 @@ static bool tap_wanted(const hificar_handle* h, const std::string& name) { retur
 //   out: sample (b, n) at out[b*out_bstride + n]
 static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, int64_t c_cstride, const float* prev,
                         int64_t prev_bstride, float* out, int64_t out_bstride, int B, int T, const Workspace& ws,
-                        hipStream_t stream, const int32_t* seq_len = nullptr, int f0 = 0, const int2* slots = nullptr) {
+                        hipStream_t stream, const int32_t* seq_len = nullptr, int f0 = 0, const int2* slots = nullptr, int T_valid = -1) {
+    // T: frames the launches cover; T_valid (<= T, default T): frames that exist in c / out (bucketed non-AR lengths)
     const hificar_config& cfg = h->cfg;
+    if (T_valid < 0) T_valid = T;
     Ragged rg;
     rg.seq_len = seq_len;
+    rg.const_len = T_valid < T ? f0 + T_valid : -1;
     rg.f0 = f0;
     rg.frames = T;
     // 1. front end
@@ -1005,6 +1095,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     fp.xin = f32 ? ws.xin : nullptr;
     fp.xin_s = f32 ? nullptr : reinterpret_cast<char*>(ws.xin);
     fp.T = T;
+    fp.t_valid = T_valid;
     fp.cf = h->cf;
     fp.cin_pad = h->cin_pad;
     fp.use_ar = cfg.use_ar;
@@ -1132,7 +1223,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                         cur_f[j] = out_f;
                         ++n;
                     }
-                    if ((rc = launch_pair_bf16x3(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    if ((rc = launch_pair(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                     for (int j = 0; j < nbk; ++j)
                         if (d < cfg.n_dilations[j] && (rc = tap_block(j, d, cur_f[j])) != HIFICAR_OK) return rc;
                 }
@@ -1172,7 +1263,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     ++n;
                 }
                 if (fuse) {
-                    if ((rc = launch_pair_bf16x3(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    if ((rc = launch_pair(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                 } else {
                     if ((rc = launch_conv(h, l1, n, B, rows, io1, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                     if (tap_convs1)
@@ -1205,6 +1296,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     op.slope = 0.01f;
     op.use_tanh = cfg.use_tanh;
     op.seq_len = seq_len;
+    op.len_const = seq_len ? -1 : rg.const_len;
     op.len_f0 = f0;
     op.len_max = T;
     op.len_mul = rows / T;
@@ -1240,9 +1332,11 @@ extern "C" int hificar_forward_ragged(hificar_handle* h, const float* c, const f
     if (rc != HIFICAR_OK) return rc;
     if (!c || !out) return fail(HIFICAR_E_INVALID, "hificar_forward: null tensor");
     if (h->cfg.use_ar && !ar) return fail(HIFICAR_E_INVALID, "use_ar model needs the ar context (got NULL)");
-    const Workspace ws = plan_workspace(h, B, T, workspace);
+    if ((rc = enter_stream(h, static_cast<hipStream_t>(stream))) != HIFICAR_OK) return rc;
+    const int Tb = bucket_frames(T);
+    const Workspace ws = plan_workspace(h, B, Tb, workspace);
     return forward_impl(h, c, (int64_t)h->cf * T, T, h->cfg.use_ar ? ar : nullptr, h->cfg.ar_input, out,
-                        (int64_t)h->hop * T, B, T, ws, static_cast<hipStream_t>(stream), lengths, 0);
+                        (int64_t)h->hop * T, B, Tb, ws, static_cast<hipStream_t>(stream), lengths, 0, nullptr, T);
 }
 
 extern "C" int hificar_forward(hificar_handle* h, const float* c, const float* ar, float* out, int B, int T, void* workspace,
@@ -1262,6 +1356,7 @@ extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const i
     if (h->cfg.ar_input > h->hop * chunk_frames && T_total > chunk_frames)
         return fail(HIFICAR_E_INVALID, "ar_input (%d) > chunk audio length (%d): the reference loop (decode.py:79-81) is ill-formed there",
                     h->cfg.ar_input, h->hop * chunk_frames);
+    if ((rc = enter_stream(h, static_cast<hipStream_t>(stream))) != HIFICAR_OK) return rc;
     const int64_t out_bstride = (int64_t)h->hop * T_total;
     if (lengths_host && !lengths) return fail(HIFICAR_E_INVALID, "hificar_ar_loop_ragged: lengths_host without the device copy");
     if (lengths_host)
@@ -1309,6 +1404,7 @@ extern "C" int hificar_ar_loop_packed(hificar_handle* h, const float* c, const i
         if (lengths_host[u] < 0 || lengths_host[u] > T_max)
             return fail(HIFICAR_E_INVALID, "lengths[%d]=%d outside [0, %d]", u, lengths_host[u], T_max);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if ((rc = enter_stream(h, stream)) != HIFICAR_OK) return rc;
     // step table: row s lists the utterances advanced by step s as (utterance, first frame) + their valid frames
     struct Step {
         int n, frames;

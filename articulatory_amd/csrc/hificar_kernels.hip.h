@@ -65,14 +65,18 @@ struct ConvParams {
     // ragged batches: utterance b is seq_len[b] frames long; this launch covers frames [len_f0, len_f0 + len_max) at
     // len_mul rows per frame, so sequence b has clamp(seq_len[b] - len_f0, 0, len_max) * len_mul valid rows (<= L): rows
     // beyond them read as zero padding and are never written.  seq_len == null: every sequence has L rows.
+    // len_const >= 0 (seq_len null): every sequence has len_const frames (a launch over a bucketed length).
     const int* seq_len;
+    int len_const;
     int len_f0, len_max, len_mul;
 };
 
+__device__ __forceinline__ bool is_ragged(const ConvParams& p) { return p.seq_len != nullptr || p.len_const >= 0; }
+
 // valid rows of sequence `seq` (wave-uniform: one scalar load)
 __device__ __forceinline__ int seq_rows(const ConvParams& p, int seq) {
-    if (!p.seq_len) return p.L;
-    const int n = p.seq_len[__builtin_amdgcn_readfirstlane(seq)] - p.len_f0;
+    if (!is_ragged(p)) return p.L;
+    const int n = (p.seq_len ? p.seq_len[__builtin_amdgcn_readfirstlane(seq)] : p.len_const) - p.len_f0;
     return min(max(n, 0), p.len_max) * p.len_mul;
 }
 
@@ -103,6 +107,41 @@ struct MultiConvParams {
 #endif
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+// Software-pipeline pin for one K-slab step of the conv kernels.  The source issues the NEXT slab's LDS fragment reads (and the weight
+// fragment loads two taps ahead) before the CURRENT slab's MFMAs, but hipcc's scheduler sinks every ds_read to just above its first use
+// and waits on it at once (ds_read ; s_waitcnt lgkmcnt ; v_mfma ...), which exposes the LDS latency once per slab: 17 % of the fp32 K loop
+// and ~40 % of the bf16x3 one (measured: s_memtime timeline / rocprof).  HIFICAR_PIN = 1: a scheduling barrier between the issue group and
+// the MFMA group; 2: additionally interleave one read behind each of the first MFMAs (sched_group_barrier: MFMA 0x8, DS read 0x100,
+// VMEM read 0x20); 0: leave it to the compiler (A/B builds).
+#ifndef HIFICAR_PIN
+#define HIFICAR_PIN 2
+#endif
+template <int I, int NDS, int NVMEM, int NMFMA>
+__device__ __forceinline__ void pin_slab_slot() {
+    if constexpr (I < NMFMA) {
+        // MFMA I, then this slot's even share of the memory instructions (LDS reads first, then the weight loads)
+        constexpr int NMEM = NDS + NVMEM;
+        constexpr int lo = NMEM * I / NMFMA, hi = NMEM * (I + 1) / NMFMA;
+        constexpr int ds = (hi < NDS ? hi : NDS) - (lo < NDS ? lo : NDS);
+        constexpr int vm = (hi - lo) - ds;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (ds > 0) __builtin_amdgcn_sched_group_barrier(0x100, ds, 0);
+        if constexpr (vm > 0) __builtin_amdgcn_sched_group_barrier(0x020, vm, 0);
+        pin_slab_slot<I + 1, NDS, NVMEM, NMFMA>();
+    }
+}
+template <int NDS, int NVMEM, int NMFMA>
+__device__ __forceinline__ void pin_slab_step() {
+#if HIFICAR_PIN == 2
+    pin_slab_slot<0, NDS, NVMEM, NMFMA>();
+#endif
+}
+#if HIFICAR_PIN == 1
+#define HIFICAR_PIN_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define HIFICAR_PIN_BARRIER() do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution with fp32 operands split into bf16 hi + lo ("bf16x3"):
@@ -198,7 +237,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     // ragged batches: tiles past the end of their sequence are skipped by both roles (same predicate, so the barrier
     // counts stay in step); nxt(i) = first non-empty position of this workgroup's list at or after i
     auto nxt = [&](int i) {
-        if (mp.p[0].seq_len)
+        if (is_ragged(mp.p[0]))
             while (i < my_rounds) {
                 const Tile T = decode(tile_of(i));
                 if (T.t0 < seq_rows(mp.p[T.b], T.seq)) break;
@@ -345,9 +384,12 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     // ---------------- MFMA role ----------------
     __builtin_amdgcn_s_setprio(1);  // the MFMA wave outranks the loader wave sharing its SIMD for issue slots
     f32x16 acc[MI];
-    // weight fragments: bq = current tap, bn = next tap; loads run two taps ahead of their use
+    // weight fragments: wr[u] holds slab u's fragments for its NEXT use; right after a slab's MFMAs have been issued its registers are
+    // reloaded for the following tap (one tap = NC16 slab steps ahead).  One register set per slab and no rotation: a two-deep ring
+    // needs register copies at every loop back-edge, and hipcc waits for the just-issued loads there (a full L2 latency per item).
     using frag_t = typename std::conditional<F32, f32x4, bf16x8>::type;  // 16 bytes per lane either way
-    frag_t bq[NC16][2], bn[NC16][2];
+    constexpr int NMF = (F32 ? 8 : 3) * MI;  // MFMAs of one K-slab step
+    frag_t wr[NC16][2];
     auto wstream = [&](const Tile& T) {
         const ConvParams& p = mp.p[T.b];
         const int nb = T.ng * WN + wn;
@@ -360,13 +402,11 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         wp = wstream(T);
 #pragma unroll
         for (int u = 0; u < NC16; ++u) {
-            bq[u][0] = wp[u * 128];
-            bq[u][1] = wp[u * 128 + 64];
-            bn[u][0] = wp[(NC16 + u) * 128];   // a tile always has >= 2 tap-groups (>= 2 chunks)
-            bn[u][1] = wp[(NC16 + u) * 128 + 64];
+            wr[u][0] = wp[u * 128];
+            wr[u][1] = wp[u * 128 + 64];
         }
-        wp += 2 * NC16 * 128;
-        groups_left = nchunks * mp.p[T.b].ntaps - 2;
+        wp += NC16 * 128;
+        groups_left = nchunks * mp.p[T.b].ntaps - 1;
     };
     const int wave_row0 = wm * (MI * 32);
 
@@ -464,22 +504,24 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                     for (int u = 0; u < NC16; u += 2) {
                         load_x(x1h, x1l, ad[u + 1]);
                         {
-                            const frag_t wh = bq[u][0], wl = bq[u][1];
-                            bq[u][0] = bn[u][0];
-                            bq[u][1] = bn[u][1];
-                            bn[u][0] = wp[u * 128];
-                            bn[u][1] = wp[u * 128 + 64];
+                            const frag_t wh = wr[u][0], wl = wr[u][1];
+                            wr[u][0] = wp[u * 128];
+                            wr[u][1] = wp[u * 128 + 64];
+                            HIFICAR_PIN_BARRIER();
                             mfma_step(x0h, x0l, wh, wl);
+                            pin_slab_step<2 * MI, 2, NMF>();
+                            HIFICAR_PIN_BARRIER();
                         }
                         if (u + 2 < NC16) load_x(x0h, x0l, ad[u + 2]);
                         else load_x(x0h, x0l, adn[0]);
                         {
-                            const frag_t wh = bq[u + 1][0], wl = bq[u + 1][1];
-                            bq[u + 1][0] = bn[u + 1][0];
-                            bq[u + 1][1] = bn[u + 1][1];
-                            bn[u + 1][0] = wp[(u + 1) * 128];
-                            bn[u + 1][1] = wp[(u + 1) * 128 + 64];
+                            const frag_t wh = wr[u + 1][0], wl = wr[u + 1][1];
+                            wr[u + 1][0] = wp[(u + 1) * 128];
+                            wr[u + 1][1] = wp[(u + 1) * 128 + 64];
+                            HIFICAR_PIN_BARRIER();
                             mfma_step(x1h, x1l, wh, wl);
+                            pin_slab_step<2 * MI, 2, NMF>();
+                            HIFICAR_PIN_BARRIER();
                         }
                     }
                     wp += NC16 * 128;
@@ -500,13 +542,14 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                         groups_left = groups_next;
                     }
                     --groups_left;
-                    const frag_t wh = bq[0][0], wl = bq[0][1];
-                    bq[0][0] = bn[0][0];
-                    bq[0][1] = bn[0][1];
-                    bn[0][0] = wp[0];
-                    bn[0][1] = wp[64];
+                    const frag_t wh = wr[0][0], wl = wr[0][1];
+                    wr[0][0] = wp[0];
+                    wr[0][1] = wp[64];
                     wp += NC16 * 128;
+                    HIFICAR_PIN_BARRIER();
                     mfma_step(xh, xl, wh, wl);
+                    pin_slab_step<2 * MI, 2, NMF>();
+                    HIFICAR_PIN_BARRIER();
                 };
                 for (int t = 0; t < ntaps; t += 2) {
                     if (t + 1 < ntaps) {
@@ -590,8 +633,8 @@ struct PairParams {
     unsigned long long* trace;
 };
 
-template <int MI, int WM, int WN, int NC16>
-__global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams mp) {
+template <int MI, int WM, int WN, int NC16, bool F32>
+__device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
     static_assert(WM * WN == 4, "4 MFMA waves per workgroup");
     static_assert(NC16 == 2 || NC16 == 4, "C = 32 or 64");
     static_assert(WN * 32 == NC16 * 16, "the workgroup covers all C channels");
@@ -645,7 +688,7 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         return (int)blockIdx.x + (my_rounds - 1 - i) * (int)gridDim.x;
     };
     auto nxt = [&](int i) {  // first non-empty position at or after i (ragged batches; see conv_ws_body)
-        if (mp.p1[0].seq_len)
+        if (is_ragged(mp.p1[0]))
             while (i < my_rounds) {
                 const Tile T = decode(tile_of(i));
                 if (T.t0 < seq_rows(mp.p1[T.b], T.seq)) break;
@@ -696,16 +739,25 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
                     *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
                     *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
                     if (p.ys) {
-                        bf16x8 hi, lo;
+                        if constexpr (F32) {
+                            float a[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float a = fmaxf(o[e], o[e] * slope_out);
-                            hi[e] = (__bf16)a;
-                            lo[e] = (__bf16)(a - (float)hi[e]);
+                            for (int e = 0; e < 8; ++e) a[e] = fmaxf(o[e], o[e] * slope_out);
+                            float* orow = reinterpret_cast<float*>(p.ys) + row * (size_t)TN + c8;
+                            *reinterpret_cast<f32x4*>(orow) = f32x4{a[0], a[1], a[2], a[3]};
+                            *reinterpret_cast<f32x4*>(orow + 4) = f32x4{a[4], a[5], a[6], a[7]};
+                        } else {
+                            bf16x8 hi, lo;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float a = fmaxf(o[e], o[e] * slope_out);
+                                hi[e] = (__bf16)a;
+                                lo[e] = (__bf16)(a - (float)hi[e]);
+                            }
+                            char* orow = p.ys + row * (size_t)TN * 4 + c8 * 2;
+                            *reinterpret_cast<bf16x8*>(orow) = hi;
+                            *reinterpret_cast<bf16x8*>(orow + TN * 2) = lo;
                         }
-                        char* orow = p.ys + row * (size_t)TN * 4 + c8 * 2;
-                        *reinterpret_cast<bf16x8*>(orow) = hi;
-                        *reinterpret_cast<bf16x8*>(orow + TN * 2) = lo;
                     }
                 }
             }
@@ -729,8 +781,10 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
                 const int sl = (n & (SPR - 1)) ^ ((r >> LOG_RPB) & (SPR - 1));
                 const int t = tfirst + r;
                 const char* src = p.zeros;
-                if (r < R && t >= 0 && t < Ls)
-                    src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? sl * 16 : p.cin * 2 + (sl - SPR / 2) * 16);
+                if (r < R && t >= 0 && t < Ls) {
+                    if constexpr (F32) src = (p.xf ? reinterpret_cast<const char*>(p.xf) : p.xs) + (seq_base + t) * row_bytes + sl * 16;
+                    else src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? sl * 16 : p.cin * 2 + (sl - SPR / 2) * 16);
+                }
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(smem_b + i * 1024), 16, 0, 2);
             }
@@ -784,9 +838,15 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
                 }
             }
         };
+        // exact-fp32 arithmetic: raw fp32 rows (xf) are staged by pure DMA too; the MFMA waves apply LeakyReLU(slope_in) to
+        // their conv1 fragments (a handful of VALU ops beside eight 64-cycle MFMAs: free)
         auto stage_in = [&](const Tile& T) {
-            if (mp.p1[T.b].xf) stage_f32(T);
-            else dma_in(T);
+            if constexpr (F32) {
+                dma_in(T);
+            } else {
+                if (mp.p1[T.b].xf) stage_f32(T);
+                else dma_in(T);
+            }
         };
         Tile Tprev;
         if (first < my_rounds) stage_in(decode(tile_of(first)));
@@ -813,23 +873,23 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
     // ---------------- MFMA role ----------------
     __builtin_amdgcn_s_setprio(1);  // the MFMA wave outranks the loader wave sharing its SIMD for issue slots
     f32x16 acc[MI];
-    bf16x8 bq[NC16][2], bn[NC16][2];
-    const bf16x8* wp = nullptr;
+    using frag_t = typename std::conditional<F32, f32x4, bf16x8>::type;  // 16 bytes per lane either way
+    constexpr int NMF = (F32 ? 8 : 3) * MI;  // MFMAs of one K-slab step
+    frag_t wr[NC16][2];  // weight ring, one register set per slab, reloaded one tap ahead (see conv_ws_body)
+    const frag_t* wp = nullptr;
     int groups_left = 0;
-    auto stream1 = [&](const Tile& T) { return mp.p1[T.b].w16 + (size_t)wn * mp.p1[T.b].ntaps * NC16 * 128 + lane; };
-    auto stream2 = [&](const Tile& T) { return mp.p2[T.b].w16 + (size_t)wn * mp.p2[T.b].ntaps * NC16 * 128 + lane; };
+    auto stream1 = [&](const Tile& T) { return reinterpret_cast<const frag_t*>(mp.p1[T.b].w16) + (size_t)wn * mp.p1[T.b].ntaps * NC16 * 128 + lane; };
+    auto stream2 = [&](const Tile& T) { return reinterpret_cast<const frag_t*>(mp.p2[T.b].w16) + (size_t)wn * mp.p2[T.b].ntaps * NC16 * 128 + lane; };
     if (first < my_rounds) {
         const Tile T0 = decode(tile_of(first));
         wp = stream1(T0);
 #pragma unroll
         for (int u = 0; u < NC16; ++u) {
-            bq[u][0] = wp[u * 128];
-            bq[u][1] = wp[u * 128 + 64];
-            bn[u][0] = wp[(NC16 + u) * 128];  // every conv here has >= 2 taps (checked on the host)
-            bn[u][1] = wp[(NC16 + u) * 128 + 64];
+            wr[u][0] = wp[u * 128];
+            wr[u][1] = wp[u * 128 + 64];
         }
-        wp += 2 * NC16 * 128;
-        groups_left = mp.p1[T0.b].ntaps - 2;
+        wp += NC16 * 128;
+        groups_left = mp.p1[T0.b].ntaps - 1;
     }
     const int wave_row0 = wm * (MI * 32);
 
@@ -838,34 +898,65 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         const int base = buf_off + r0 * RB;
 #pragma unroll
         for (int u = 0; u < NC16; ++u) {
-            ad[u][0] = base + (((2 * u + g) ^ swz) << 4);
-            ad[u][1] = base + (((SPR / 2 + 2 * u + g) ^ swz) << 4);
+            if constexpr (F32) {  // slab u = slots 4u .. 4u+3 (see conv_ws_body)
+                ad[u][0] = base + (((4 * u + g) ^ swz) << 4);
+                ad[u][1] = base + (((4 * u + 2 + g) ^ swz) << 4);
+            } else {
+                ad[u][0] = base + (((2 * u + g) ^ swz) << 4);
+                ad[u][1] = base + (((SPR / 2 + 2 * u + g) ^ swz) << 4);
+            }
         }
     };
-    auto load_x = [&](bf16x8 (&xh)[MI], bf16x8 (&xl)[MI], const int (&ad)[2]) {
+    float act_slope = 1.f;  // F32 only: LeakyReLU slope applied to the activation fragments as they are read (1 = none)
+    bool act_on = false;
+    auto load_x = [&](frag_t (&xh)[MI], frag_t (&xl)[MI], const int (&ad)[2]) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            xh[mi] = *reinterpret_cast<const bf16x8*>(smem_b + ad[0] + mi * 32 * RB);
-            xl[mi] = *reinterpret_cast<const bf16x8*>(smem_b + ad[1] + mi * 32 * RB);
+            xh[mi] = *reinterpret_cast<const frag_t*>(smem_b + ad[0] + mi * 32 * RB);
+            xl[mi] = *reinterpret_cast<const frag_t*>(smem_b + ad[1] + mi * 32 * RB);
         }
     };
-    auto mfma_step = [&](const bf16x8 (&xh)[MI], const bf16x8 (&xl)[MI], const bf16x8& wh, const bf16x8& wl) {
+    auto mfma_step = [&](const frag_t (&xh_)[MI], const frag_t (&xl_)[MI], const frag_t& wh, const frag_t& wl) {
+        if constexpr (F32) {
+            frag_t xh[MI], xl[MI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[mi], acc[mi], 0, 0, 0);
+            for (int mi = 0; mi < MI; ++mi) {
+                xh[mi] = xh_[mi];
+                xl[mi] = xl_[mi];
+                if (act_on) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[mi], acc[mi], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        xh[mi][e] = fmaxf(xh[mi][e], xh[mi][e] * act_slope);
+                        xl[mi][e] = fmaxf(xl[mi][e], xl[mi][e] * act_slope);
+                    }
+                }
+            }
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[mi], acc[mi], 0, 0, 0);
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[s4], xh[mi][s4], acc[mi], 0, 0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[s4], xl[mi][s4], acc[mi], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl_[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh_[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh_[mi], acc[mi], 0, 0, 0);
+        }
     };
     // one convolution: taps x NC16 K slabs out of the LDS image at buf_off; lane's row for tap t is row0 + t*tap_rows
-    auto run_conv = [&](int buf_off, int row0, int tap_rows, int ntaps, const bf16x8* wp_next, int groups_next) {
+    auto run_conv = [&](int buf_off, int row0, int tap_rows, int ntaps, const frag_t* wp_next, int groups_next) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
         int ad[NC16][2];
         addr_set(buf_off, row0, ad);
-        bf16x8 x0h[MI], x0l[MI], x1h[MI], x1l[MI];
+        frag_t x0h[MI], x0l[MI], x1h[MI], x1l[MI];
         load_x(x0h, x0l, ad[0]);
         for (int t = 0; t < ntaps; ++t) {
             const bool last_tap = t + 1 == ntaps;
@@ -880,22 +971,24 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
             for (int u = 0; u < NC16; u += 2) {
                 load_x(x1h, x1l, ad[u + 1]);
                 {
-                    const bf16x8 wh = bq[u][0], wl = bq[u][1];
-                    bq[u][0] = bn[u][0];
-                    bq[u][1] = bn[u][1];
-                    bn[u][0] = wp[u * 128];
-                    bn[u][1] = wp[u * 128 + 64];
+                    const frag_t wh = wr[u][0], wl = wr[u][1];
+                    wr[u][0] = wp[u * 128];
+                    wr[u][1] = wp[u * 128 + 64];
+                    HIFICAR_PIN_BARRIER();
                     mfma_step(x0h, x0l, wh, wl);
+                    pin_slab_step<2 * MI, 2, NMF>();
+                    HIFICAR_PIN_BARRIER();
                 }
                 if (u + 2 < NC16) load_x(x0h, x0l, ad[u + 2]);
                 else load_x(x0h, x0l, adn[0]);
                 {
-                    const bf16x8 wh = bq[u + 1][0], wl = bq[u + 1][1];
-                    bq[u + 1][0] = bn[u + 1][0];
-                    bq[u + 1][1] = bn[u + 1][1];
-                    bn[u + 1][0] = wp[(u + 1) * 128];
-                    bn[u + 1][1] = wp[(u + 1) * 128 + 64];
+                    const frag_t wh = wr[u + 1][0], wl = wr[u + 1][1];
+                    wr[u + 1][0] = wp[(u + 1) * 128];
+                    wr[u + 1][1] = wp[(u + 1) * 128 + 64];
+                    HIFICAR_PIN_BARRIER();
                     mfma_step(x1h, x1l, wh, wl);
+                    pin_slab_step<2 * MI, 2, NMF>();
+                    HIFICAR_PIN_BARRIER();
                 }
             }
             wp += NC16 * 128;
@@ -922,7 +1015,12 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
         __syncthreads();  // A: input landed
         HIFICAR_STAMP(6 * it + 1);
         // ---- conv1 over TMc rows (time t0 - pad2 + r1) ----
+        if constexpr (F32) {
+            act_on = p1.xf != nullptr;  // raw rows staged: LeakyReLU(slope_in) on the fragments; activated rows (xs): none
+            act_slope = p1.slope_in;
+        }
         run_conv(0, wave_row0 + li + (p1.tap_off0[0] - p1.off_min), p1.tap_step, p1.ntaps, stream2(T), k2);
+        if constexpr (F32) act_on = false;
         HIFICAR_STAMP(6 * it + 2);
         __syncthreads();  // F: the loaders are done with the previous tile's out-buffer (same LDS region as TS)
         {   // bias + LeakyReLU + split -> TS (zero outside the sequence: conv2's padding)
@@ -939,17 +1037,28 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
                 char* trow = smem_b + ts_off + r1 * RB + 8 * g;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    bf16x4 hi, lo;
+                    if constexpr (F32) {
+                        f32x4 a4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = acc[mi][4 * q + e] + bias4[q][e];
-                        const float a = in_seq ? fmaxf(v, v * slope) : 0.f;
-                        hi[e] = (__bf16)a;
-                        lo[e] = (__bf16)(a - (float)hi[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[mi][4 * q + e] + bias4[q][e];
+                            a4[e] = in_seq ? fmaxf(v, v * slope) : 0.f;
+                        }
+                        const int slot = wn * 8 + 2 * q + g;  // this lane's 4 channels 32*wn + 8q + 4g .. +3 are one 16-byte slot
+                        *reinterpret_cast<f32x4*>(smem_b + ts_off + r1 * RB + ((slot ^ swz) << 4)) = a4;
+                    } else {
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[mi][4 * q + e] + bias4[q][e];
+                            const float a = in_seq ? fmaxf(v, v * slope) : 0.f;
+                            hi[e] = (__bf16)a;
+                            lo[e] = (__bf16)(a - (float)hi[e]);
+                        }
+                        const int slot = wn * 4 + q;  // 8-channel group of this lane's 4 channels
+                        *reinterpret_cast<bf16x4*>(trow + ((slot ^ swz) << 4)) = hi;
+                        *reinterpret_cast<bf16x4*>(trow + (((SPR / 2 + slot) ^ swz) << 4)) = lo;
                     }
-                    const int slot = wn * 4 + q;  // 8-channel group of this lane's 4 channels
-                    *reinterpret_cast<bf16x4*>(trow + ((slot ^ swz) << 4)) = hi;
-                    *reinterpret_cast<bf16x4*>(trow + (((SPR / 2 + slot) ^ swz) << 4)) = lo;
                 }
             }
         }
@@ -975,6 +1084,18 @@ __global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams 
     }
     __syncthreads();  // Z
     if (last >= 0) write_out(decode(tile_of(last)), tid, 512);
+}
+
+template <int MI, int WM, int WN, int NC16>
+__global__ __launch_bounds__(512) void conv_pair_bf16x3_kernel(const PairParams mp) {
+    conv_pair_body<MI, WM, WN, NC16, false>(mp);
+}
+
+// Exact-fp32 arithmetic of the fused pair: fp32 rows staged by pure DMA (raw residual-stream rows: LeakyReLU is applied to the
+// conv1 fragments by the MFMA waves; no activated copy exists anywhere), fp32 intermediate in LDS, v_mfma_f32_32x32x2_f32.
+template <int MI, int WM, int WN, int NC16>
+__global__ __launch_bounds__(512) void conv_pair_f32_kernel(const PairParams mp) {
+    conv_pair_body<MI, WM, WN, NC16, true>(mp);
 }
 
 // MRF mean + LeakyReLU + split for the upsample convs' input: out = split(lrelu(((x0 + x1) + x2) / n, slope)).
@@ -1067,6 +1188,7 @@ struct FrontParams {
     const int2* slots;
     const int* valid;
     int hop;
+    int t_valid;          // frames that exist in c (<= T): later frames read as zeros (bucketed launch lengths)
 };
 
 __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
@@ -1130,7 +1252,7 @@ __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
     const float* feats = act[cur];
     const int n = p.T * p.cin_pad;
     size_t cbase = (size_t)b * p.c_bstride;
-    int tmax = p.T;
+    int tmax = p.t_valid;
     if (p.slots) {
         cbase = (size_t)p.slots[b].x * p.c_bstride + p.slots[b].y;
         tmax = p.valid[b];  // frames past the utterance's end may lie outside the packed tensor
@@ -1172,6 +1294,7 @@ struct OutConvParams {
     float slope;
     int use_tanh;
     const int* seq_len;  // ragged batches, as in ConvParams (rows = samples)
+    int len_const;
     int len_f0, len_max, len_mul;
     const int2* slots;   // packed mode, as in FrontParams: sequence -> (utterance, first frame); out is the packed waveform
     int hop;
@@ -1189,7 +1312,7 @@ __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p)
     float* ws = smem + R * P;  // weights [k][C]
     for (int i = tid; i < p.K * p.C; i += 256) ws[i] = p.w[i];
     const size_t base = (size_t)seq * p.L;
-    const int Ls = p.seq_len ? min(max(p.seq_len[seq] - p.len_f0, 0), p.len_max) * p.len_mul : p.L;
+    const int Ls = (p.seq_len || p.len_const >= 0) ? min(max((p.seq_len ? p.seq_len[seq] : p.len_const) - p.len_f0, 0), p.len_max) * p.len_mul : p.L;
     if (t0 >= Ls) return;  // nothing of this sequence in the block (uniform)
     const int c4n = p.C >> 2;  // C is a multiple of 32: 16-byte loads
     for (int idx = tid; idx < R * c4n; idx += 256) {
@@ -1265,8 +1388,10 @@ __global__ __launch_bounds__(256) void tap_copy_kernel(const TapParams p) {
 // float waveform -> PCM_16 (reference: sf.write(..., "PCM_16") on the host, decode.py:319-324)
 __global__ __launch_bounds__(256) void pcm16_kernel(const float* __restrict__ x, int16_t* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const double v = rint((double)x[i] * 32767.0);  // the product is exact in fp64: bit-identical to the host writer
-        y[i] = (int16_t)fmin(fmax(v, -32768.0), 32767.0);
+        // libsndfile's float32 -> PCM_16 (src/pcm.c f2s_array): lrintf(src * 32767.f) — a float32 product, round to nearest even;
+        // clipped here where libsndfile (clipping off) would wrap.  Bit-identical to the host writer (bin/predict_wav.py::write_wav).
+        const float v = rintf(x[i] * 32767.0f);
+        y[i] = (int16_t)fminf(fmaxf(v, -32768.0f), 32767.0f);
     }
 }
 

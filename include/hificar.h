@@ -142,7 +142,8 @@ int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const int32_t* len
 int hificar_ar_loop_packed(hificar_handle* h, const float* c, const int32_t* lengths_host, float* out, int N, int T_max,
                            int chunk_frames, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
-/* float waveform in [-1, 1] -> 16-bit PCM on the device: y = clip(round_half_even(x * 32767), -32768, 32767).
+/* float waveform in [-1, 1] -> 16-bit PCM on the device: y = clip(round_half_even(x *_f32 32767.f), -32768, 32767) — the product in
+ * float32, as libsndfile's f2s_array computes it (lrintf(src * 32767.f)); libsndfile wraps outside [-1, 1] where this clips.
  * What the reference's sf.write(..., "PCM_16") does on the host after the device->host copy
  * (articulatory/bin/decode.py:319-324); doing it before the copy / the multi-GPU gather halves the bytes moved.
  * x, y: device pointers, n elements. */

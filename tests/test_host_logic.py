@@ -263,3 +263,38 @@ def test_decode_cli_plumbing(tmp_path):
         assert np.load(out / f"uttA_{i}.npy").shape[0] == int(gw[f"in_len{i}"])
     with pytest.raises(AssertionError):  # odd chunk length: the reference asserts too (decode.py:87)
         D.ar_loop(model, torch.from_numpy(gold["x"]), dict(config, wsola=True), do_wsola=True)
+
+
+def test_decode_lists_then_loads_lazily(tmp_path):
+    """articulatory-decode counterpart: the utterance list is (utt_id, path) pairs, lengths come from the .npy headers, and
+    feature files are read one at a time while decoding (a rank never loads utterances of another rank's share)."""
+    from articulatory_amd.bin import decode as D
+    from articulatory_amd.bin.shard import shard_items
+    lens = [30, 300, 31, 290, 32, 280]
+    with open(tmp_path / "feats.scp", "w") as f:
+        for i, T in enumerate(lens):
+            np.save(tmp_path / f"u{i}.npy", np.zeros((T, 13)))
+            f.write(f"u{i} {tmp_path / f'u{i}.npy'}\n")
+    pairs = D.list_features(str(tmp_path / "feats.scp"))
+    assert [u for u, _ in pairs] == [f"u{i}" for i in range(6)]
+    assert [D.npy_frames(p) for _, p in pairs] == lens
+    shares = [shard_items(pairs, 2, r, length_of=lambda kv: D.npy_frames(kv[1])) for r in range(2)]
+    assert sorted(shares[0] + shares[1]) == sorted(pairs) and not set(shares[0]) & set(shares[1])
+    loaded = []
+    real_load = np.load
+
+    def spy(path, *a, **kw):
+        if not kw.get("mmap_mode"):
+            loaded.append(os.path.basename(str(path)))
+        return real_load(path, *a, **kw)
+
+    np.load = spy
+    try:
+        it = D.load_features(shares[0])
+        assert loaded == []  # nothing read before the loop asks for it
+        first = next(it)
+        assert loaded == [os.path.basename(shares[0][0][1])] and first[1].shape[1] == 13
+    finally:
+        np.load = real_load
+    with pytest.raises(ValueError):
+        D.list_features(None, None)

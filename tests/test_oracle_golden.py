@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from conftest import E2W_PARAMS, GOLDEN, rel_err
-from articulatory_amd.utils.synth import generator_param_spec, synth_state_dict
+from articulatory_amd.utils.synth import generator_param_spec, synth_features, synth_state_dict
 from oracle import hificar_oracle as O
 
 TOL = 2e-6
@@ -173,3 +173,22 @@ def test_ar_loop_wsola_variant(full_w):
     for i, (o, a) in enumerate(zip(outs, ins)):
         assert len(a) == int(g[f"in_len{i}"])
         assert rel_err(o.numpy(), g[f"out{i}"]) < 2e-5, i
+
+
+def test_saturated_synthetic_network_is_chaotic_on_cpu_too():
+    """Conditioning note behind tests/test_gpu_parity.py::test_trained_checkpoint_scale_full_ar_loop: scaling EVERY conv of the
+    synthetic checkpoint by 1.3 saturates tanh AND makes the AR feedback loop chaotic — the same oracle evaluated in fp32 and in
+    fp64 on the CPU ends 80 chained steps more than 1e-3 (in fact ~0.6 of full scale) apart, although its first chunk agrees to
+    1e-5.  No implementation can be held to the reference there; the GPU suite therefore reaches full scale through the output
+    conv's gain, where the loop is well conditioned (fp32 vs fp64: ~1e-6)."""
+    x = torch.from_numpy(synth_features(64, 2000, 13, seed=20260929 + 3)[:1])
+    out = {}
+    for gain in (1.3, 1.0):
+        sd = synth_state_dict(dict(E2W_PARAMS), seed=1234, gain=gain)
+        with torch.no_grad():
+            y32 = O.ar_loop_batched(O.fold_weight_norm(sd), E2W_PARAMS, x, 2000, 80)
+            y64 = O.ar_loop_batched(O.fold_weight_norm(sd, torch.float64), E2W_PARAMS, x.double(), 2000, 80)
+        e = (y32.double() - y64).abs()
+        out[gain] = (float(e[:, :2000].max()), float(e.max() / y64.abs().max()))
+    assert out[1.3][0] < 1e-4 and out[1.3][1] > 1e-2, out
+    assert out[1.0][1] < 1e-5, out

@@ -67,6 +67,7 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
         for (size_t i = 0; i < wel; ++i) hw[i] = 0x3c00 + (uint16_t)((i * 40503u) & 0xff);  // small bf16 values
         hipMemcpy(w16, hw.data(), wel * 2, hipMemcpyHostToDevice);
         ConvParams& p = mp.p[b];
+        p.len_const = -1;
         p.w16 = reinterpret_cast<const bf16x8*>(w16); p.bias = bias; p.res = residual ? x : nullptr; p.y = residual ? y[b] : nullptr;
         p.xs = xs; p.ys = (mode & 1) ? nullptr : ys[b]; if (mode & 2) p.y = y[b]; p.zeros = zeros; p.slope_out = 0.1f; p.cout_real = C;
         p.L = L; p.tiles_per_seq = (L + TM - 1) / TM; p.cin = C; p.cout_total = C;
@@ -147,6 +148,8 @@ void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks,
         hipMemcpy(w1, hw.data(), wel * 2, hipMemcpyHostToDevice);
         hipMemcpy(w2, hw.data(), wel * 2, hipMemcpyHostToDevice);
         ConvParams& p = pp.p1[b];
+        p.len_const = -1;
+        pp.p2[b].len_const = -1;
         p.xs = xs; p.w16 = reinterpret_cast<const bf16x8*>(w1); p.bias = bias; p.zeros = zeros;
         p.L = L; p.cin = C; p.cout_total = C; p.n_blocks32 = C / 32; p.nb32_per_phase = C / 32; p.ntaps = K; p.off_min = -pad; p.halo = 2 * pad;
         p.tap_step = dil; p.tap_off0[0] = -pad;
