@@ -519,6 +519,8 @@ static hipError_t set_lds_attr_f() {
 }
 
 // every (MI, WM, WN) x NC16 instantiation of the conv kernels (both arithmetics)
+// (The kernel body also supports 8 MFMA waves per workgroup — two per SIMD, e.g. X(2, 2, 4, nc) — measured 3-5 % SLOWER than the
+// 4-wave shapes of the same tile in both arithmetics: the matrix pipe's idle share is not an issue-gap problem, see DESIGN.md.)
 #define HIFICAR_FOR_TILES(X, nc) \
     X(4, 1, 4, nc) X(4, 2, 2, nc) X(4, 4, 1, nc) X(2, 1, 4, nc) X(2, 2, 2, nc) X(2, 4, 1, nc) X(1, 1, 4, nc) X(1, 2, 2, nc) X(1, 4, 1, nc)
 #define HIFICAR_FOR_ALL_TILES(X) HIFICAR_FOR_TILES(X, 1) HIFICAR_FOR_TILES(X, 2) HIFICAR_FOR_TILES(X, 4)
@@ -815,8 +817,8 @@ static const TileCfg kTileCfgs[9] = {{4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {2, 1, 4},
 
 template <int MI, int WM, int WN, int NC16>
 static hipError_t launch_conv_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
-    if (f32) hipLaunchKernelGGL((conv_f32_kernel<MI, WM, WN, NC16>), grid, dim3(512), lds, stream, mp);
-    else hipLaunchKernelGGL((conv_bf16x3_kernel<MI, WM, WN, NC16>), grid, dim3(512), lds, stream, mp);
+    if (f32) hipLaunchKernelGGL((conv_f32_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
+    else hipLaunchKernelGGL((conv_bf16x3_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
     return hipGetLastError();
 }
 
@@ -939,7 +941,8 @@ struct PairIOB {
     char* ys;         // split copy of LeakyReLU(y) for the next pair (must NOT alias xs: neighbouring tiles read xs halos), or null
 };
 
-static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const ConvLayer& b) {
+// nseq / rows: the launch the pair would run in (0 / 0: only the static conditions)
+static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const ConvLayer& b, int nseq = 0, int rows = 0) {
     if (!(h->use_pair && a.d_w16c && b.d_w16c && a.d_w32c && b.d_w32c && a.cin == b.cin && a.ntaps >= 2 &&
           b.ntaps >= 2 && b.dilation == 1 && a.K == b.K))
         return false;
@@ -947,7 +950,19 @@ static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const Con
     const int C = a.cin, TMc = (C == 64 ? 2 : 4) * 4 * 32;
     const size_t in_bytes = round_up_sz((size_t)(TMc + a.off_max - a.off_min) * C * 4, 1024);
     const size_t ts_bytes = std::max<size_t>((size_t)(TMc + 16) * C * 4, (size_t)TMc * (C + 4) * sizeof(float));
-    return in_bytes + ts_bytes <= 160 * 1024;
+    if (in_bytes + ts_bytes > 160 * 1024) return false;
+    if (nseq > 0) {
+        // The fused kernel's tiles are tall (TMc conv1 rows for TMc - (k-1) output rows).  (i) A launch with few tiles leaves most
+        // CUs idle behind long serial tiles: small batches run layer by layer.  (ii) Tile quantisation: 1000 rows at k = 11 need 5
+        // tiles of 256 (28 % extra conv1 work); the exact-fp32 arithmetic gains little from fusion (its layer-by-layer kernels are
+        // matrix-pipe-bound already), so it only fuses when the waste is small; the bf16x3 ones are memory-path-bound and gain more.
+        const int tmo = TMc - (b.ntaps - 1);
+        const long long tiles = (long long)nseq * ((rows + tmo - 1) / tmo);
+        if (3 * tiles < h->num_cus) return false;
+        const double waste = (double)((rows + tmo - 1) / tmo) * TMc / rows;
+        if (waste > (h->precision == HIFICAR_PREC_F32 ? 1.12 : 1.35)) return false;
+    }
+    return true;
 }
 
 static int launch_pair(hificar_handle* h, const ConvLayer* const* l1, const ConvLayer* const* l2, int nbr, int nseq, int rows,
@@ -1187,7 +1202,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             for (int j = 0; j < nbk; ++j)
                 for (int d = 0; d < cfg.n_dilations[j]; ++d) {
                     const int ci = conv_index(h, i, j, d);
-                    all_pairs = all_pairs && pair_eligible(h, h->convs1[ci], h->convs2[ci]);
+                    all_pairs = all_pairs && pair_eligible(h, h->convs1[ci], h->convs2[ci], B, rows * cfg.upsample_scales[i]);
                 }
             {   // LeakyReLU + ConvTranspose1d (hifigan.py:224): fp32 u (first residual) (+ activated copy: first conv input)
                 const ConvLayer* lay[1] = {&h->ups[i]};
@@ -1250,7 +1265,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     const int ci = conv_index(h, i, j, d);
                     l1[n] = &h->convs1[ci];
                     l2[n] = &h->convs2[ci];
-                    fuse = fuse && !tap_convs1 && pair_eligible(h, *l1[n], *l2[n]);
+                    fuse = fuse && !tap_convs1 && pair_eligible(h, *l1[n], *l2[n], B, rows);
                     const bool last = d + 1 == cfg.n_dilations[j];
                     // fused pair: cur -> the other buffer.  Layer by layer: cur -> mid -> the buffer that is not mid.
                     pair_out[n] = cur_s[j] == ws.x_s[j] ? xt_s[j] : ws.x_s[j];

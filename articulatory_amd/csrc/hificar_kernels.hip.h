@@ -99,8 +99,8 @@ struct MultiConvParams {
 #ifdef HIFICAR_TRACE
 #define HIFICAR_STAMP(slot)                                                                            \
     do {                                                                                               \
-        if (mp.trace && lane == 0 && (wave == 0 || wave == 4) && (slot) < 64)                          \
-            mp.trace[((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        if (mp.trace && lane == 0 && (wave == 0 || wave == kFirstLoader) && (slot) < 64)               \
+            mp.trace[((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define HIFICAR_STAMP(slot) do { } while (0)
@@ -178,9 +178,17 @@ __device__ __forceinline__ void pin_slab_step() {
 // ds_read_b128 = four v_mfma_f32_32x32x2_f32 steps), weights are fp32 fragments in the same [slab][half][lane][16 B]
 // order.  8 MFMAs of 64 cycles per slab and accumulator instead of 3 of 32: staging, weight stream and output pass
 // vanish behind the matrix pipe.
+//
+// WM * WN = 4 or 8 MFMA waves.  8 (a 768-thread workgroup: two MFMA waves and one loader wave per SIMD) is supported by the body but
+// not instantiated: measured 3-5 % slower than 4 waves on the same tile in both arithmetics (tools/conv_bench.hip has the runs) —
+// the ~13 % of K-loop cycles without MFMA issue are the same with one or two MFMA waves per SIMD, i.e. not an issue-gap problem.
 template <int MI, int WM, int WN, int NC16, bool F32>
 __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
-    static_assert(WM * WN == 4, "4 MFMA waves per workgroup");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 MFMA waves per workgroup");
+    constexpr int NW = WM * WN;            // MFMA waves; waves NW .. NW+3 are the loaders
+    constexpr int NTHR = (NW + 4) * 64;
+    constexpr int kFirstLoader = NW;
+    (void)kFirstLoader;
     static_assert(NC16 == 1 || NC16 == 2 || NC16 == 4, "chunk of 16, 32 or 64 channels");
     constexpr int TM = WM * MI * 32;
     constexpr int CH = NC16 * 16;
@@ -193,8 +201,8 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave >= 4;
-    const int cw = wave & 3;
+    const bool loader = wave >= NW;
+    const int cw = loader ? 0 : wave;
     const int wm = cw / WN;
     const int wn = cw % WN;
     const int li = lane & 31;
@@ -329,8 +337,8 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     };
     if (loader) {
         // ---------------- loader role: LDS-DMA of split rows + the finished tile's output pass ----------------
-        const int lw = wave - 4;
-        const int ltid = tid - 256;
+        const int lw = wave - NW;
+        const int ltid = tid - NW * 64;
 
         auto dma_item = [&](const Tile& T, int c, int jj) {
             const ConvParams& p = mp.p[T.b];
@@ -376,7 +384,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             have_prev = true;
         }
         __syncthreads();  // the last tile's accumulators are in the out-buffer
-        if (have_prev) write_out(Tprev, tid, 512);  // all eight waves share the final output pass (nothing left to hide it behind)
+        if (have_prev) write_out(Tprev, tid, NTHR);  // all waves share the final output pass (nothing left to hide it behind)
         HIFICAR_STAMP(63);
         return;
     }
@@ -586,17 +594,17 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     }
     __syncthreads();  // matches the loader waves' final barrier
     HIFICAR_STAMP(62);
-    if (last >= 0) write_out(decode(tile_of(last)), tid, 512);
+    if (last >= 0) write_out(decode(tile_of(last)), tid, NTHR);
     HIFICAR_STAMP(63);
 }
 
 template <int MI, int WM, int WN, int NC16>
-__global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams mp) {
+__global__ __launch_bounds__((WM * WN + 4) * 64) void conv_bf16x3_kernel(const MultiConvParams mp) {
     conv_ws_body<MI, WM, WN, NC16, false>(mp);
 }
 
 template <int MI, int WM, int WN, int NC16>
-__global__ __launch_bounds__(512) void conv_f32_kernel(const MultiConvParams mp) {
+__global__ __launch_bounds__((WM * WN + 4) * 64) void conv_f32_kernel(const MultiConvParams mp) {
     conv_ws_body<MI, WM, WN, NC16, true>(mp);
 }
 
@@ -639,6 +647,8 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
     static_assert(NC16 == 2 || NC16 == 4, "C = 32 or 64");
     static_assert(WN * 32 == NC16 * 16, "the workgroup covers all C channels");
     constexpr int TMc = WM * MI * 32;
+    constexpr int kFirstLoader = 4;
+    (void)kFirstLoader;
     constexpr int CH = NC16 * 16;
     constexpr int RB = CH * 4;
     constexpr int SPR = CH / 4;

@@ -332,14 +332,14 @@ class HiFiGANGenerator(torch.nn.Module):
         return handle
 
     def _workspace(self, B, T):
-        key = (B, T)
-        ws = self._workspaces.get(key)
-        if ws is None:
-            n = self._lib.hificar_workspace_bytes(self._handle, B, T)
-            if len(self._workspaces) > 8:
-                self._workspaces.clear()
-            ws = torch.empty(n + 256, dtype=torch.uint8, device=self._device())
-            self._workspaces[key] = ws
+        """One grow-only scratch buffer per model (the library plans its layout per call): a dataset of many distinct
+        utterance lengths re-uses it instead of allocating per shape."""
+        n = self._lib.hificar_workspace_bytes(self._handle, B, T) + 256
+        ws = self._workspaces.get("buf")
+        if ws is None or ws.numel() < n:
+            # work already enqueued on the old buffer keeps it alive through the caching allocator's stream ordering
+            ws = torch.empty(int(n * 1.25) if ws is not None else n, dtype=torch.uint8, device=self._device())
+            self._workspaces["buf"] = ws
         off = (-ws.data_ptr()) % 256
         return ws.data_ptr() + off, ws.numel() - off
 

@@ -43,7 +43,19 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
     const size_t n = (size_t)nseq * L * C;
     hipMalloc(&x, n * 4);
     hipMalloc(&xs, n * 4);
-    hipMemset(xs, 0x3c, n * 4);
+    static const bool zero_data = getenv("CONV_BENCH_ZERO") != nullptr;    // all-zero operands: no toggling -> the clock DVFS allows
+    static const bool rand_data = getenv("CONV_BENCH_RAND") != nullptr;    // random activations and weights (realistic toggling)
+    hipMemset(xs, zero_data ? 0 : 0x3c, n * 4);
+    if (rand_data) {
+        std::vector<float> hr(n);
+        unsigned st = 12345u;
+        for (size_t i = 0; i < n; ++i) { st = st * 1664525u + 1013904223u; hr[i] = ((st >> 8) & 0xffff) / 32768.f - 1.f; }
+        if (!F32) {  // split rows hold bf16 pairs: random bf16 bit patterns of moderate magnitude
+            uint16_t* hb = reinterpret_cast<uint16_t*>(hr.data());
+            for (size_t i = 0; i < 2 * n; ++i) { st = st * 1664525u + 1013904223u; hb[i] = 0x3c00 + ((st >> 10) & 0x1ff) + ((st >> 3) & 0x8000); }
+        }
+        hipMemcpy(xs, hr.data(), n * 4, hipMemcpyHostToDevice);
+    }
     hipMalloc(&zeros, 256);
     hipMemset(zeros, 0, 256);
     hipMalloc(&bias, C * 4);
@@ -65,6 +77,12 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
         hipMalloc(&w16, wel * 2);
         std::vector<uint16_t> hw(wel);
         for (size_t i = 0; i < wel; ++i) hw[i] = 0x3c00 + (uint16_t)((i * 40503u) & 0xff);  // small bf16 values
+        if (zero_data) std::fill(hw.begin(), hw.end(), 0);
+        if (rand_data) {
+            unsigned st = 777u + b;
+            if (F32) { float* hf = reinterpret_cast<float*>(hw.data()); for (size_t i = 0; i < wel / 2; ++i) { st = st * 1664525u + 1013904223u; hf[i] = (((st >> 8) & 0xffff) / 32768.f - 1.f) * 0.05f; } }
+            else for (size_t i = 0; i < wel; ++i) { st = st * 1664525u + 1013904223u; hw[i] = 0x3a00 + ((st >> 10) & 0x1ff) + ((st >> 3) & 0x8000); }
+        }
         hipMemcpy(w16, hw.data(), wel * 2, hipMemcpyHostToDevice);
         ConvParams& p = mp.p[b];
         p.len_const = -1;
@@ -94,7 +112,7 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
     float ms = 0, ms1 = 0;
     for (int it = 0; it < 3; ++it) {
         hipEventRecord(e0);
-        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3(512), 2 * mp.buf_bytes + TM * (WN * 32 + 4) * 4, 0, mp);
+        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3((WM * WN + 4) * 64), 2 * mp.buf_bytes + TM * (WN * 32 + 4) * 4, 0, mp);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
@@ -102,7 +120,7 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
     hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(G), dim3(512), 2 * mp.buf_bytes + TM * (WN * 32 + 4) * 4, 0, mp);  // the traced launch: alone
+    hipLaunchKernelGGL(kern, dim3(G), dim3((WM * WN + 4) * 64), 2 * mp.buf_bytes + TM * (WN * 32 + 4) * 4, 0, mp);  // the traced launch: alone
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms1, e0, e1);
@@ -204,6 +222,15 @@ int main(int argc, char** argv) {
     }
     const int k3[3] = {11, 7, 3};
     if (argc > 1 && !strcmp(argv[1], "f32")) {
+        run<2, 2, 4, 4, true>("stage0 8w (2,2,4) conv1", 64, 125, 256, 3, k3, 1, false);
+        run<2, 2, 4, 4, true>("stage0 8w (2,2,4) conv2+res", 64, 125, 256, 3, k3, 1, true);
+        run<1, 2, 4, 4, true>("stage0 8w (1,2,4) conv1", 64, 125, 256, 3, k3, 1, false);
+        run<2, 2, 4, 4, true>("stage1 8w (2,2,4) conv1", 64, 500, 128, 3, k3, 1, false);
+        run<2, 2, 4, 4, true>("stage1 8w (2,2,4) conv2+res", 64, 500, 128, 3, k3, 1, true);
+        run<2, 4, 2, 2, true>("stage2 8w C64 (2,4,2) conv1", 64, 1000, 64, 3, k3, 1, false);
+        run<2, 4, 2, 2, true>("stage2 8w C64 (2,4,2) conv2+res", 64, 1000, 64, 3, k3, 1, true);
+        run<2, 8, 1, 1, true>("stage3 8w C32 (2,8,1) conv1", 64, 2000, 32, 3, k3, 1, false);
+        run<2, 8, 1, 1, true>("stage3 8w C32 (2,8,1) conv2+res", 64, 2000, 32, 3, k3, 1, true);
         run<2, 1, 4, 4, true>("stage0 (2,1,4) conv1", 64, 125, 256, 3, k3, 1, false);
         run<2, 1, 4, 4, true>("stage0 (2,1,4) conv2+res", 64, 125, 256, 3, k3, 1, true);
         run<2, 1, 4, 4, true>("stage0 (2,1,4) conv1 B=128", 128, 125, 256, 3, k3, 1, false);
@@ -219,6 +246,10 @@ int main(int argc, char** argv) {
         run<4, 4, 1, 1, true>("stage3 C32 conv1 B=128", 128, 2000, 32, 3, k3, 1, false);
         return 0;
     }
+    run<2, 2, 4, 4>("stage0 8w (2,2,4) conv1", 64, 125, 256, 3, k3, 1, false);
+    run<2, 2, 4, 4>("stage0 8w (2,2,4) conv2+res", 64, 125, 256, 3, k3, 1, true);
+    run<2, 2, 4, 4>("stage1 8w (2,2,4) conv1", 64, 500, 128, 3, k3, 1, false);
+    run<2, 2, 4, 4>("stage1 8w (2,2,4) conv2+res", 64, 500, 128, 3, k3, 1, true);
     run<4, 1, 4, 4>("stage0 TM128 TN128 (4,1,4)", 64, 125, 256, 3, k3, 1, false);
     run<2, 1, 4, 4>("stage0 TM64 TN128 (2,1,4)", 64, 125, 256, 3, k3, 1, false);
     run<2, 2, 2, 4>("stage0 TM128 TN64 (2,2,2)", 64, 125, 256, 3, k3, 1, false);
