@@ -30,6 +30,7 @@ SYMBOLS = (
     "hificar_forward",
     "hificar_ar_loop",
     "hificar_forward_ragged",
+    "hificar_forward_cond",
     "hificar_ar_loop_ragged",
     "hificar_ar_loop_packed",
     "hificar_macs",
@@ -65,6 +66,13 @@ class HificarConfig(ctypes.Structure):
         ("ar_hidden", ctypes.c_int32),
         ("ar_output", ctypes.c_int32),
         ("precision", ctypes.c_int32),
+        ("use_spk_id", ctypes.c_int32),
+        ("num_spk", ctypes.c_int32),
+        ("spk_emb_size", ctypes.c_int32),
+        ("use_ph", ctypes.c_int32),
+        ("num_ph", ctypes.c_int32),
+        ("ph_emb_size", ctypes.c_int32),
+        ("use_ph_loss", ctypes.c_int32),
     ]
 
 
@@ -110,6 +118,8 @@ def load_library():
     lib.hificar_ar_loop.restype = ctypes.c_int
     lib.hificar_forward_ragged.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
     lib.hificar_forward_ragged.restype = ctypes.c_int
+    lib.hificar_forward_cond.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.hificar_forward_cond.restype = ctypes.c_int
     lib.hificar_ar_loop_ragged.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
     lib.hificar_ar_loop_ragged.restype = ctypes.c_int
     lib.hificar_ar_loop_packed.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
@@ -173,4 +183,11 @@ def make_config(params: dict, precision: int) -> HificarConfig:
     cfg.ar_hidden = params["ar_hidden"]
     cfg.ar_output = params["ar_output"]
     cfg.precision = precision
+    cfg.use_spk_id = int(params.get("use_spk_id", False))
+    cfg.num_spk = int(params.get("num_spk") or 0)
+    cfg.spk_emb_size = int(params.get("spk_emb_size") or 0)
+    cfg.use_ph = int(params.get("use_ph", False))
+    cfg.num_ph = int(params.get("num_ph") or 0)
+    cfg.ph_emb_size = int(params.get("ph_emb_size") or 0)
+    cfg.use_ph_loss = int(params.get("use_ph_loss", False))
     return cfg

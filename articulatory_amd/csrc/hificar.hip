@@ -75,6 +75,7 @@ struct hificar_handle {
     bool profile_detail = false;   // HIFICAR_PROFILE_DETAIL=1: profile rows carry the layer name
     bool use_pair = true;          // HIFICAR_PAIR=0: run narrow stages layer by layer (A/B runs)
     bool use_lpt = true;           // HIFICAR_LPT=0: round-robin tile walk instead of the host LPT schedule (A/B runs)
+    int ksplit = 1;                // HIFICAR_KSPLIT: 0 = never use the split-K conv form, 1 = when it is estimated faster (default), 2 = always
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
     int cin_pad = 0;  // padded input-conv channels
     int hop = 1;
@@ -91,6 +92,13 @@ struct hificar_handle {
     // MLP
     float* d_mlp_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float* d_mlp_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // speaker / phoneme conditioning
+    float* d_spk_emb = nullptr;
+    float* d_spk_w = nullptr;
+    float* d_spk_b = nullptr;
+    float* d_ph_emb = nullptr;
+    float* d_phfc_w = nullptr;
+    float* d_phfc_b = nullptr;
     std::vector<void*> allocs;
     char* d_zeros = nullptr;  // 256 bytes of zeros: source of padding rows for the LDS DMA
     void* d_tab = nullptr;    // step table of hificar_ar_loop_packed (grown on demand) and its pinned host staging copy
@@ -251,6 +259,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (const char* e = getenv("HIFICAR_PROFILE_DETAIL")) h->profile_detail = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_PAIR")) h->use_pair = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_LPT")) h->use_lpt = atoi(e) != 0;
+    if (const char* e = getenv("HIFICAR_KSPLIT")) h->ksplit = atoi(e);
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -258,7 +267,24 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
             h->num_cus = prop.multiProcessorCount;
     }
     h->precision = c.precision;
-    h->cf = c.in_channels - (c.use_ar ? c.ar_output : 0);
+    if (c.use_spk_id && (c.num_spk < 1 || c.spk_emb_size < 1)) {
+        delete h;
+        return fail(HIFICAR_E_INVALID, "use_spk_id needs num_spk and spk_emb_size");
+    }
+    if ((c.use_ph || c.use_ph_loss) && c.num_ph < 1) {
+        delete h;
+        return fail(HIFICAR_E_INVALID, "use_ph / use_ph_loss need num_ph");
+    }
+    if (c.use_ph && c.ph_emb_size < 1) {
+        delete h;
+        return fail(HIFICAR_E_INVALID, "use_ph needs ph_emb_size");
+    }
+    if (c.use_spk_id && c.use_ph) {
+        delete h;
+        // spk_fc maps to in_channels values but is added before the phoneme channels are appended: the shapes disagree in the reference
+        return fail(HIFICAR_E_INVALID, "use_spk_id together with use_ph is ill-formed in the reference (hifigan.py:212-220)");
+    }
+    h->cf = c.in_channels - (c.use_ar ? c.ar_output : 0) - (c.use_ph ? c.ph_emb_size : 0);
     if (h->cf < 1) {
         delete h;
         return fail(HIFICAR_E_INVALID, "in_channels=%d leaves no feature channels", c.in_channels);
@@ -345,6 +371,18 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
             expect("ar_model.model." + std::to_string(2 * l) + ".weight", {dims[l + 1], dims[l]});
             expect("ar_model.model." + std::to_string(2 * l) + ".bias", {dims[l + 1]});
         }
+    }
+    if (c.use_spk_id) {
+        expect("spk_emb_mat.weight", {c.num_spk, c.spk_emb_size});
+        expect("spk_fc.weight", {c.in_channels, c.spk_emb_size});
+        expect("spk_fc.bias", {c.in_channels});
+    }
+    if (c.use_ph) expect("ph_emb_mat.weight", {c.num_ph, c.ph_emb_size});
+    if (c.use_ph_loss) {
+        if (c_last > 128) rc = fail(HIFICAR_E_INVALID, "use_ph_loss: the phoneme head handles up to 128 last-stage channels (got %d)", c_last);
+        if (h->hop % 2 != 0) rc = fail(HIFICAR_E_INVALID, "use_ph_loss: prod(upsample_scales) must be even (hifigan.py:186)");
+        expect("ph_fc.weight", {c.num_ph, c_last});
+        expect("ph_fc.bias", {c.num_ph});
     }
     if (rc != HIFICAR_OK) {
         delete h;
@@ -524,6 +562,8 @@ static hipError_t set_lds_attr_f() {
 #define HIFICAR_FOR_TILES(X, nc) \
     X(4, 1, 4, nc) X(4, 2, 2, nc) X(4, 4, 1, nc) X(2, 1, 4, nc) X(2, 2, 2, nc) X(2, 4, 1, nc) X(1, 1, 4, nc) X(1, 2, 2, nc) X(1, 4, 1, nc)
 #define HIFICAR_FOR_ALL_TILES(X) HIFICAR_FOR_TILES(X, 1) HIFICAR_FOR_TILES(X, 2) HIFICAR_FOR_TILES(X, 4)
+// split-K forms: (MI, NC16)
+#define HIFICAR_FOR_SK_TILES(X) X(1, 1) X(2, 1) X(4, 1) X(1, 2) X(2, 2) X(4, 2) X(1, 4) X(2, 4) X(4, 4)
 
 extern "C" int hificar_finalize(hificar_handle* h) {
     if (!h) return fail(HIFICAR_E_INVALID, "hificar_finalize: null handle");
@@ -558,6 +598,16 @@ extern "C" int hificar_finalize(hificar_handle* h) {
             if ((rc = upload(h, h->tensors.at("ar_model.model." + std::to_string(2 * l) + ".bias").data, &h->d_mlp_b[l])) != HIFICAR_OK) return rc;
         }
     }
+    if (h->cfg.use_spk_id) {
+        if ((rc = upload(h, h->tensors.at("spk_emb_mat.weight").data, &h->d_spk_emb)) != HIFICAR_OK) return rc;
+        if ((rc = upload(h, h->tensors.at("spk_fc.weight").data, &h->d_spk_w)) != HIFICAR_OK) return rc;
+        if ((rc = upload(h, h->tensors.at("spk_fc.bias").data, &h->d_spk_b)) != HIFICAR_OK) return rc;
+    }
+    if (h->cfg.use_ph && (rc = upload(h, h->tensors.at("ph_emb_mat.weight").data, &h->d_ph_emb)) != HIFICAR_OK) return rc;
+    if (h->cfg.use_ph_loss) {
+        if ((rc = upload(h, h->tensors.at("ph_fc.weight").data, &h->d_phfc_w)) != HIFICAR_OK) return rc;
+        if ((rc = upload(h, h->tensors.at("ph_fc.bias").data, &h->d_phfc_b)) != HIFICAR_OK) return rc;
+    }
     {
         void* z = nullptr;
         HIP_TRY(hipMalloc(&z, 256));
@@ -578,6 +628,12 @@ extern "C" int hificar_finalize(hificar_handle* h) {
     HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>()));
     HIFICAR_FOR_ALL_TILES(HIFICAR_SET_ATTR)
 #undef HIFICAR_SET_ATTR
+#define HIFICAR_SET_ATTR_SK(mi, nc)                                                                                              \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_bf16x3_kernel<mi, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                160 * 1024));                                                                                  \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_f32_kernel<mi, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIFICAR_FOR_SK_TILES(HIFICAR_SET_ATTR_SK)
+#undef HIFICAR_SET_ATTR_SK
     if (h->arenas.empty()) {
         int rca = arena_add(h, 0);
         if (rca != HIFICAR_OK) return rca;
@@ -668,6 +724,15 @@ extern "C" double hificar_macs(const hificar_handle* h, int B, int T) {
 // ------------------------------------------------------------------------------------------------
 // Ragged batch context of one forward: utterance b has seq_len[b] frames (device array, null = all equal); the forward
 // covers frames [f0, f0 + frames) of every utterance.
+// Conditioning inputs / extra output of one forward (hificar_forward_cond)
+struct Cond {
+    const int32_t* spk_id = nullptr;
+    const int32_t* ph = nullptr;
+    int ph_stride = 0;
+    float* ph_out = nullptr;
+    int ph_out_T = 0;
+};
+
 struct Ragged {
     const int32_t* seq_len = nullptr;
     int const_len = -1;  // >= 0 (and seq_len null): every utterance has this many frames, fewer than the launch covers (bucketed lengths)
@@ -810,10 +875,19 @@ static int enter_stream(hificar_handle* h, hipStream_t stream) {
 
 struct TileCfg {
     int MI, WM, WN;
+    int KS;  // 1: each MFMA wave owns a 32-channel block of the tile; 4: the four MFMA waves split the K loop of ONE block (WM = WN = 1)
 };
-static size_t out_buf_bytes(const TileCfg& t) { return (size_t)(t.WM * t.MI * 32) * (t.WN * 32 + 4) * sizeof(float); }
+static size_t out_buf_bytes(const TileCfg& t) { return (size_t)t.KS * (t.WM * t.MI * 32) * (t.WN * 32 + 4) * sizeof(float); }
 // preference order: ties keep the earlier entry (taller wave tiles re-read fewer weights per MFMA)
-static const TileCfg kTileCfgs[9] = {{4, 1, 4}, {4, 2, 2}, {4, 4, 1}, {2, 1, 4}, {2, 2, 2}, {2, 4, 1}, {1, 1, 4}, {1, 2, 2}, {1, 4, 1}};
+static const TileCfg kTileCfgs[12] = {{4, 1, 4, 1}, {4, 2, 2, 1}, {4, 4, 1, 1}, {2, 1, 4, 1}, {2, 2, 2, 1}, {2, 4, 1, 1},
+                                      {1, 1, 4, 1}, {1, 2, 2, 1}, {1, 4, 1, 1}, {4, 1, 1, 4}, {2, 1, 1, 4}, {1, 1, 1, 4}};
+
+template <int MI, int NC16>
+static hipError_t launch_conv_sk_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
+    if (f32) hipLaunchKernelGGL((conv_sk_f32_kernel<MI, NC16>), grid, dim3(512), lds, stream, mp);
+    else hipLaunchKernelGGL((conv_sk_bf16x3_kernel<MI, NC16>), grid, dim3(512), lds, stream, mp);
+    return hipGetLastError();
+}
 
 template <int MI, int WM, int WN, int NC16>
 static hipError_t launch_conv_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
@@ -843,6 +917,11 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     // lock step: 3*MI MFMAs of 32 cycles per 16-channel K slab) plus a fixed per-tile and per-item overhead.
     TileCfg tc = kTileCfgs[8];
     double best = 1e300;
+    const int nsteps_min = [&] {
+        int m = 1 << 30;
+        for (int b = 0; b < nbr; ++b) m = std::min(m, layers[b]->ntaps * (L0.chunk16 / 16));
+        return m;
+    }();
     // dev override: HIFICAR_TILE="cin,MI,WM,WN" forces the shape for layers with that many input channels
     static const char* force = getenv("HIFICAR_TILE");
     int fc = 0, fmi = 0, fwm = 0, fwn = 0;
@@ -851,6 +930,8 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         const int TM = t.WM * t.MI * 32;
         if (2 * round_up_sz((size_t)(TM + halo_all) * RB, 1024) + out_buf_bytes(t) > 160 * 1024) continue;
         if (fc == L0.cin_pad && nbr == 3 && !(t.MI == fmi && t.WM == fwm && t.WN == fwn)) continue;
+        if (t.KS == 4 && (h->ksplit == 0 || nsteps_min < 2)) continue;
+        if (t.KS == 1 && h->ksplit == 2 && nsteps_min >= 2) continue;
         const long long tiles_per_branch = (long long)nseq * ((rows + TM - 1) / TM) * ((L0.n_blocks32 + t.WN - 1) / t.WN);
         const long long total = tiles_per_branch * nbr;
         const int G = (int)std::min<long long>(total, h->num_cus);
@@ -860,7 +941,13 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         for (int b = 0; b < nbr; ++b) {
             // MFMA issue cycles per 16-channel slab and 32x32 accumulator: 3 x 32 (bf16x3, ~75 % sustained) or 8 x 64 (fp32)
             const double slab = f32 ? 8 * 64.0 : 3 * 32 / 0.75;
-            const double c = (double)layers[b]->ntaps * (L0.cin_pad / 16) * slab * t.MI + 2500.0 + 400.0 * nchunks;
+            double c = (double)layers[b]->ntaps * (L0.cin_pad / 16) * slab * t.MI + 2500.0 + 400.0 * nchunks;
+            if (t.KS == 4) {
+                // each wave runs ceil(steps / 4) of an item's (tap, slab) steps; exposed weight latency at every tile start, the partial
+                // sums' extra pass, and four times the staging per output
+                const int steps = layers[b]->ntaps * (L0.chunk16 / 16);
+                c = (double)((steps + 3) / 4) * nchunks * slab * t.MI + 4000.0 + 600.0 * nchunks;
+            }
             total_cost += c * tiles_per_branch;
             heaviest = std::max(heaviest, c);
             lightest = std::min(lightest, c);
@@ -869,6 +956,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         if (total % G != 0) worst = std::max(worst, total_cost / G + 0.5 * lightest);
         // shorter wave tiles re-read the weight stream more often per MFMA (MI = 2 measured ~10 % slower per flop)
         if (t.MI < 4) worst *= f32 ? (t.MI == 2 ? 1.02 : 1.05) : (t.MI == 2 ? 1.10 : 1.25);
+        if (t.KS == 4) worst *= 1.05;  // near-ties go to the dense form
         if (worst < best * 0.98) {  // near-ties keep the earlier (taller) shape
             best = worst;
             tc = t;
@@ -912,12 +1000,14 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
             key += "|" + layers[b]->name;
             for (int i = 0; i < tpb; ++i) costs[(size_t)b * tpb + i] = layers[b]->ntaps + 1.0;  // + fixed per-tile overhead
         }
-        key += "|" + std::to_string(nseq) + "x" + std::to_string((rows + TM - 1) / TM) + "t" + std::to_string(TM) + "w" + std::to_string(tc.WN);
+        key += "|" + std::to_string(nseq) + "x" + std::to_string((rows + TM - 1) / TM) + "t" + std::to_string(TM) + "w" + std::to_string(tc.WN) +
+               "k" + std::to_string(tc.KS);
         int rc2 = get_schedule(h, key, costs, (int)grid.x, stream, &mp.sched_start, &mp.sched_tiles);
         if (rc2 != HIFICAR_OK) return rc2;
     }
     char kname[96];
-    snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_f32_kernel" : "conv_bf16x3_kernel", tc.MI, tc.WM, tc.WN, nc16);
+    if (tc.KS == 4) snprintf(kname, sizeof(kname), "%s<%d,%d>", f32 ? "conv_sk_f32_kernel" : "conv_sk_bf16x3_kernel", tc.MI, nc16);
+    else snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_f32_kernel" : "conv_bf16x3_kernel", tc.MI, tc.WM, tc.WN, nc16);
     if (h->profile_detail) {  // per-layer rows in the profile (tools/layer_profile.py)
         const size_t n = strlen(kname);
         snprintf(kname + n, sizeof(kname) - n, "|%s x%d", L0.name.c_str(), nbr);
@@ -925,9 +1015,13 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     ProfScope prof(h, stream, kname, flops, bytes);
     hipError_t e = hipErrorInvalidValue;
 #define HIFICAR_DISPATCH(mi, wm, wn, nc) \
-    if (tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_t<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
+    if (tc.KS == 1 && tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_t<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
     HIFICAR_FOR_ALL_TILES(HIFICAR_DISPATCH)
 #undef HIFICAR_DISPATCH
+#define HIFICAR_DISPATCH_SK(mi, nc) \
+    if (tc.KS == 4 && tc.MI == mi && nc16 == nc) e = launch_conv_sk_t<mi, nc>(mp, grid, lds, stream, f32);
+    HIFICAR_FOR_SK_TILES(HIFICAR_DISPATCH_SK)
+#undef HIFICAR_DISPATCH_SK
     if (e != hipSuccess) return fail(HIFICAR_E_HIP, "conv launch (%s, %s) failed: %s", L0.name.c_str(), kname, hipGetErrorString(e));
     return HIFICAR_OK;
 }
@@ -1086,7 +1180,8 @@ static bool tap_wanted(const hificar_handle* h, const std::string& name) { retur
 //   out: sample (b, n) at out[b*out_bstride + n]
 static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, int64_t c_cstride, const float* prev,
                         int64_t prev_bstride, float* out, int64_t out_bstride, int B, int T, const Workspace& ws,
-                        hipStream_t stream, const int32_t* seq_len = nullptr, int f0 = 0, const int2* slots = nullptr, int T_valid = -1) {
+                        hipStream_t stream, const int32_t* seq_len = nullptr, int f0 = 0, const int2* slots = nullptr, int T_valid = -1,
+                        const Cond& cond = Cond()) {
     // T: frames the launches cover; T_valid (<= T, default T): frames that exist in c / out (bucketed non-AR lengths)
     const hificar_config& cfg = h->cfg;
     if (T_valid < 0) T_valid = T;
@@ -1111,6 +1206,19 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     fp.xin_s = f32 ? nullptr : reinterpret_cast<char*>(ws.xin);
     fp.T = T;
     fp.t_valid = T_valid;
+    if (cfg.use_spk_id) {
+        fp.spk_id = cond.spk_id;
+        fp.spk_emb = h->d_spk_emb;
+        fp.spk_w = h->d_spk_w;
+        fp.spk_b = h->d_spk_b;
+        fp.spk_e = cfg.spk_emb_size;
+    }
+    if (cfg.use_ph) {
+        fp.ph = cond.ph;
+        fp.ph_stride = cond.ph_stride;
+        fp.ph_emb = h->d_ph_emb;
+        fp.ph_e = cfg.ph_emb_size;
+    }
     fp.cf = h->cf;
     fp.cin_pad = h->cin_pad;
     fp.use_ar = cfg.use_ar;
@@ -1294,6 +1402,28 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             }
         }
     }
+    if (cfg.use_ph_loss && cond.ph_out) {  // phoneme-loss head on the last stage's MRF mean (hifigan.py:232-237)
+        PhHeadParams pq;
+        memset(&pq, 0, sizeof(pq));
+        pq.x0 = fin[0];
+        pq.x1 = nbk > 1 ? fin[1] : nullptr;
+        pq.x2 = nbk > 2 ? fin[2] : nullptr;
+        pq.nin = nbk;
+        pq.w = h->d_phfc_w;
+        pq.bias = h->d_phfc_b;
+        pq.out = cond.ph_out;
+        pq.C = stage_channels(cfg, cfg.n_stages);
+        pq.Cp = stage_pad(cfg, cfg.n_stages);
+        pq.L = rows;
+        pq.T = cond.ph_out_T;
+        pq.hop = h->hop;
+        pq.num_ph = cfg.num_ph;
+        pq.seq_len = seq_len;
+        pq.len_const = seq_len ? -1 : (T_valid < T ? T_valid : -1);
+        ProfScope prof(h, stream, "ph_head_kernel", 2.0 * B * T_valid * (double)pq.C * cfg.num_ph, 4.0 * B * (double)rows * pq.Cp * nbk);
+        hipLaunchKernelGGL(ph_head_kernel, dim3(T_valid, B), dim3(256), 0, stream, pq);
+        HIP_TRY(hipGetLastError());
+    }
     // 4. output conv: LeakyReLU(0.01) + Conv1d + tanh (hifigan.py:146-159)
     OutConvParams op;
     memset(&op, 0, sizeof(op));
@@ -1341,17 +1471,33 @@ static int check_ready(hificar_handle* h, int B, int T, void* ws, size_t ws_byte
     return HIFICAR_OK;
 }
 
-extern "C" int hificar_forward_ragged(hificar_handle* h, const float* c, const float* ar, const int32_t* lengths, float* out, int B,
-                                      int T, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int hificar_forward_cond(hificar_handle* h, const float* c, const float* ar, const int32_t* spk_id, const int32_t* ph,
+                                    const int32_t* lengths, float* out, float* ph_out, int B, int T, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
     int rc = check_ready(h, B, T, workspace, workspace_bytes);
     if (rc != HIFICAR_OK) return rc;
     if (!c || !out) return fail(HIFICAR_E_INVALID, "hificar_forward: null tensor");
     if (h->cfg.use_ar && !ar) return fail(HIFICAR_E_INVALID, "use_ar model needs the ar context (got NULL)");
+    if (h->cfg.use_spk_id && !spk_id) return fail(HIFICAR_E_INVALID, "use_spk_id model needs spk_id (got NULL)");
+    if (h->cfg.use_ph && !ph) return fail(HIFICAR_E_INVALID, "use_ph model needs ph (got NULL)");
+    Cond cond;
+    cond.spk_id = spk_id;
+    cond.ph = ph;
+    cond.ph_stride = T;
+    cond.ph_out = ph_out;
+    cond.ph_out_T = T;
     if ((rc = enter_stream(h, static_cast<hipStream_t>(stream))) != HIFICAR_OK) return rc;
     const int Tb = bucket_frames(T);
     const Workspace ws = plan_workspace(h, B, Tb, workspace);
     return forward_impl(h, c, (int64_t)h->cf * T, T, h->cfg.use_ar ? ar : nullptr, h->cfg.ar_input, out,
-                        (int64_t)h->hop * T, B, Tb, ws, static_cast<hipStream_t>(stream), lengths, 0, nullptr, T);
+                        (int64_t)h->hop * T, B, Tb, ws, static_cast<hipStream_t>(stream), lengths, 0, nullptr, T, cond);
+}
+
+extern "C" int hificar_forward_ragged(hificar_handle* h, const float* c, const float* ar, const int32_t* lengths, float* out, int B,
+                                      int T, void* workspace, size_t workspace_bytes, void* stream) {
+    if (h && (h->cfg.use_spk_id || h->cfg.use_ph))
+        return fail(HIFICAR_E_INVALID, "this model takes spk_id / ph: call hificar_forward_cond");
+    return hificar_forward_cond(h, c, ar, nullptr, nullptr, lengths, out, nullptr, B, T, workspace, workspace_bytes, stream);
 }
 
 extern "C" int hificar_forward(hificar_handle* h, const float* c, const float* ar, float* out, int B, int T, void* workspace,
@@ -1363,6 +1509,8 @@ extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const i
                                       float* out, int B, int T_total, int chunk_frames, void* workspace, size_t workspace_bytes,
                                       void* stream) {
     if (h && !h->cfg.use_ar) return fail(HIFICAR_E_INVALID, "hificar_ar_loop on a model built with use_ar=false");
+    if (h && (h->cfg.use_spk_id || h->cfg.use_ph))  // the reference's ar_loop calls model(c, ar=prev) only (decode.py:72)
+        return fail(HIFICAR_E_INVALID, "hificar_ar_loop: speaker / phoneme conditioned models are driven through hificar_forward_cond");
     if (chunk_frames < 1) return fail(HIFICAR_E_INVALID, "chunk_frames=%d must be positive", chunk_frames);
     int rc = check_ready(h, B, std::min(chunk_frames, std::max(T_total, 1)), workspace, workspace_bytes);
     if (rc != HIFICAR_OK) return rc;
@@ -1405,6 +1553,8 @@ extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const i
 extern "C" int hificar_ar_loop_packed(hificar_handle* h, const float* c, const int32_t* lengths_host, float* out, int N, int T_max,
                                       int chunk_frames, int batch, void* workspace, size_t workspace_bytes, void* stream_) {
     if (h && !h->cfg.use_ar) return fail(HIFICAR_E_INVALID, "hificar_ar_loop on a model built with use_ar=false");
+    if (h && (h->cfg.use_spk_id || h->cfg.use_ph))  // the reference's ar_loop calls model(c, ar=prev) only (decode.py:72)
+        return fail(HIFICAR_E_INVALID, "hificar_ar_loop: speaker / phoneme conditioned models are driven through hificar_forward_cond");
     if (chunk_frames < 1 || batch < 1 || N < 1 || T_max < 1)
         return fail(HIFICAR_E_INVALID, "hificar_ar_loop_packed: N=%d, T_max=%d, chunk_frames=%d, batch=%d must be positive", N, T_max,
                     chunk_frames, batch);

@@ -182,10 +182,17 @@ __device__ __forceinline__ void pin_slab_step() {
 // WM * WN = 4 or 8 MFMA waves.  8 (a 768-thread workgroup: two MFMA waves and one loader wave per SIMD) is supported by the body but
 // not instantiated: measured 3-5 % slower than 4 waves on the same tile in both arithmetics (tools/conv_bench.hip has the runs) —
 // the ~13 % of K-loop cycles without MFMA issue are the same with one or two MFMA waves per SIMD, i.e. not an issue-gap problem.
-template <int MI, int WM, int WN, int NC16, bool F32>
+//
+// KS = 4 is the split-K form for launches with few tiles (small batches: a chunk of one utterance is 25-125 rows per stage): the tile
+// is MI*32 rows x 32 channels and the four MFMA waves split its K loop — wave ks takes the (tap, slab) steps s = ks (mod 4) — so a
+// 32-channel block's dependent MFMA chain is a quarter as long and four times as many workgroups have work.  Each wave leaves a partial
+// accumulator in the out-buffer; the output pass sums them in the fixed order (p0 + p1) + (p2 + p3): deterministic, but a different
+// rounding order than the dense form (results agree to fp32 rounding, not bit for bit).
+template <int MI, int WM, int WN, int NC16, bool F32, int KS = 1>
 __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
-    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 MFMA waves per workgroup");
-    constexpr int NW = WM * WN;            // MFMA waves; waves NW .. NW+3 are the loaders
+    static_assert(KS == 1 || (KS == 4 && WM == 1 && WN == 1), "split-K: four waves share one 32-channel block");
+    static_assert(KS == 4 || WM * WN == 4 || WM * WN == 8, "4 or 8 MFMA waves per workgroup");
+    constexpr int NW = KS == 4 ? 4 : WM * WN;  // MFMA waves; waves NW .. NW+3 are the loaders
     constexpr int NTHR = (NW + 4) * 64;
     constexpr int kFirstLoader = NW;
     (void)kFirstLoader;
@@ -203,8 +210,8 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave >= NW;
     const int cw = loader ? 0 : wave;
-    const int wm = cw / WN;
-    const int wn = cw % WN;
+    const int wm = KS == 4 ? 0 : cw / WN;
+    const int wn = KS == 4 ? 0 : cw % WN;
     const int li = lane & 31;
     const int g = lane >> 5;
     const int nchunks = mp.p[0].cin / CH;  // identical for all branches of a launch
@@ -287,6 +294,16 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                 if (lane_on && row_l < rows) {
                     v0[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8]);
                     v1[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8 + 4]);
+                    if constexpr (KS == 4) {  // (p0 + p1) + (p2 + p3)
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&O[(TM + row_l) * OP + c8]);
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&O[(TM + row_l) * OP + c8 + 4]);
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(&O[(2 * TM + row_l) * OP + c8]);
+                        const f32x4 b1 = *reinterpret_cast<const f32x4*>(&O[(2 * TM + row_l) * OP + c8 + 4]);
+                        const f32x4 d0 = *reinterpret_cast<const f32x4*>(&O[(3 * TM + row_l) * OP + c8]);
+                        const f32x4 d1 = *reinterpret_cast<const f32x4*>(&O[(3 * TM + row_l) * OP + c8 + 4]);
+                        v0[q] = (v0[q] + a0) + (b0 + d0);
+                        v1[q] = (v1[q] + a1) + (b1 + d1);
+                    }
                     if (p.res) {
                         const float* rp = p.res + (seq_base + T.t0 + row_l) * p.cout_total + vc;
                         q0[q] = *reinterpret_cast<const f32x4*>(rp);
@@ -466,6 +483,93 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     int j = 0;
     int last = -1;  // position of the last tile computed
     HIFICAR_STAMP(0);
+    if constexpr (KS == 4) {
+        // ---------------- split-K: wave ks computes the steps s = ks, ks + 4, ... of every item ----------------
+        const int ks = cw;
+        constexpr int LOG_NC = NC16 == 4 ? 2 : NC16 == 2 ? 1 : 0;
+        for (int it = nxt(0); it < my_rounds; it = nxt(it + 1)) {
+            last = it;
+            const Tile T = decode(tile_of(it));
+            const ConvParams& p = mp.p[T.b];
+            const int nb = T.ng;  // one 32-channel block per tile
+            const int phase = nb / p.nb32_per_phase;
+            const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
+            const int tap_step = p.tap_step;
+            const int nsteps = p.ntaps * NC16;
+            const frag_t* wtile = reinterpret_cast<const frag_t*>(p.w16) + (size_t)nb * nchunks * nsteps * 128 + lane;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+            // this wave's first weight fragments of the tile do not depend on the staging barrier: request them before it
+            frag_t wh, wl;
+            if (ks < nsteps) {
+                wh = wtile[(size_t)ks * 128];
+                wl = wtile[(size_t)ks * 128 + 64];
+            }
+            auto x_addr = [&](int buf_off, int s, int (&ad)[2]) {
+                const int t = s >> LOG_NC, u = s & (NC16 - 1);
+                const int r0 = li + roff0 + t * tap_step;
+                const int swz = (r0 >> LOG_RPB) & (SPR - 1);
+                const int base = buf_off + r0 * RB;
+                if constexpr (F32) {
+                    ad[0] = base + (((4 * u + g) ^ swz) << 4);
+                    ad[1] = base + (((4 * u + 2 + g) ^ swz) << 4);
+                } else {
+                    ad[0] = base + (((2 * u + g) ^ swz) << 4);
+                    ad[1] = base + (((SPR / 2 + 2 * u + g) ^ swz) << 4);
+                }
+            };
+            for (int c = 0; c < nchunks; ++c, ++j) {
+                __syncthreads();  // item j is staged
+                const int buf_off = (j & 1) * buf_bytes;
+                const frag_t* wc = wtile + (size_t)c * nsteps * 128;
+                frag_t xh[MI], xl[MI];
+                int ad[2];
+                if (ks < nsteps) {
+                    x_addr(buf_off, ks, ad);
+                    load_x(xh, xl, ad);
+                }
+                for (int s = ks; s < nsteps; s += 4) {
+                    const frag_t cwh = wh, cwl = wl;
+                    frag_t nxh[MI], nxl[MI];
+                    const bool more = s + 4 < nsteps;
+                    if (more) {  // next step of this item: fragments and weights requested before this step's MFMAs
+                        x_addr(buf_off, s + 4, ad);
+                        load_x(nxh, nxl, ad);
+                        wh = wc[(size_t)(s + 4) * 128];
+                        wl = wc[(size_t)(s + 4) * 128 + 64];
+                    } else if (c + 1 < nchunks && ks < nsteps) {  // first step of the next item (its rows are not staged yet: weights only)
+                        wh = wc[(size_t)(nsteps + ks) * 128];
+                        wl = wc[(size_t)(nsteps + ks) * 128 + 64];
+                    }
+                    mfma_step(xh, xl, cwh, cwl);
+                    if (more) {
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            xh[mi] = nxh[mi];
+                            xl[mi] = nxl[mi];
+                        }
+                    }
+                }
+            }
+            {   // this wave's partial sums -> out-buffer slice ks
+                float* Ow = reinterpret_cast<float*>(smem_b + 2 * buf_bytes) + ks * TM * OP;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[mi][4 * q + e];
+                        *reinterpret_cast<f32x4*>(&Ow[(mi * 32 + li) * OP + 8 * q + 4 * g]) = v;
+                    }
+            }
+        }
+        __syncthreads();  // matches the loader waves' final barrier
+        if (last >= 0) write_out(decode(tile_of(last)), tid, NTHR);
+        return;
+    }
     for (int it = nxt(0), itn; it < my_rounds; it = itn) {
         itn = nxt(it + 1);
         last = it;
@@ -606,6 +710,17 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void conv_bf16x3_kernel(const M
 template <int MI, int WM, int WN, int NC16>
 __global__ __launch_bounds__((WM * WN + 4) * 64) void conv_f32_kernel(const MultiConvParams mp) {
     conv_ws_body<MI, WM, WN, NC16, true>(mp);
+}
+
+// split-K forms (small launches): tile = MI*32 rows x 32 channels, the four MFMA waves split the K loop
+template <int MI, int NC16>
+__global__ __launch_bounds__(512) void conv_sk_bf16x3_kernel(const MultiConvParams mp) {
+    conv_ws_body<MI, 1, 1, NC16, false, 4>(mp);
+}
+
+template <int MI, int NC16>
+__global__ __launch_bounds__(512) void conv_sk_f32_kernel(const MultiConvParams mp) {
+    conv_ws_body<MI, 1, 1, NC16, true, 4>(mp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1199,6 +1314,17 @@ struct FrontParams {
     const int* valid;
     int hop;
     int t_valid;          // frames that exist in c (<= T): later frames read as zeros (bucketed launch lengths)
+    // speaker conditioning (hifigan.py:212-216): spk_fc(spk_emb_mat[spk_id[b]]) is added to channels [0, cf + ar_output)
+    const int* spk_id;    // (B) or null
+    const float* spk_emb; // (num_spk, spk_e)
+    const float* spk_w;   // spk_fc.weight (cf + ar_output, spk_e)
+    const float* spk_b;   // spk_fc.bias
+    int spk_e;
+    // phoneme conditioning (hifigan.py:217-220): channels [cf + ar_output, + ph_e) of frame t hold ph_emb[ph[b, t]]
+    const int* ph;        // (B, ph_stride) or null
+    int ph_stride;
+    const float* ph_emb;  // (num_ph, ph_e)
+    int ph_e;
 };
 
 __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
@@ -1260,6 +1386,16 @@ __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
     }
     // act[cur][0:ar_output] now holds the AR features
     const float* feats = act[cur];
+    const int c_ar = p.use_ar ? p.ar_output : 0;
+    if (p.spk_id) {  // per-utterance speaker vector for channels [0, cf + ar_output): part[0][ch]
+        const float* e = p.spk_emb + (size_t)p.spk_id[b] * p.spk_e;
+        for (int ch = tid; ch < p.cf + c_ar; ch += 512) {
+            float v = p.spk_b[ch];
+            for (int k = 0; k < p.spk_e; ++k) v = fmaf(p.spk_w[(size_t)ch * p.spk_e + k], e[k], v);
+            part[0][ch] = v;
+        }
+        __syncthreads();
+    }
     const int n = p.T * p.cin_pad;
     size_t cbase = (size_t)b * p.c_bstride;
     int tmax = p.t_valid;
@@ -1272,7 +1408,9 @@ __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
         const int ch = idx - t * p.cin_pad;
         float v = 0.f;
         if (ch < p.cf) v = t < tmax ? p.c[cbase + (size_t)ch * p.c_cstride + t] : 0.f;
-        else if (p.use_ar && ch < p.cf + p.ar_output) v = feats[ch - p.cf];
+        else if (ch < p.cf + c_ar) v = feats[ch - p.cf];
+        else if (p.ph && ch < p.cf + c_ar + p.ph_e) v = t < tmax ? p.ph_emb[(size_t)p.ph[(size_t)b * p.ph_stride + t] * p.ph_e + (ch - p.cf - c_ar)] : 0.f;
+        if (p.spk_id && ch < p.cf + c_ar && t < tmax) v += part[0][ch];
         if (p.xin) p.xin[(size_t)b * n + idx] = v;
         if (p.xin_s) {
             __bf16* row = reinterpret_cast<__bf16*>(p.xin_s + ((size_t)b * p.T + t) * p.cin_pad * 4);
@@ -1392,6 +1530,64 @@ __global__ __launch_bounds__(256) void tap_copy_kernel(const TapParams p) {
             v = reinterpret_cast<const float*>(p.src)[row * pitch + p.c0 + c];
         }
         p.dst[i] = v;
+    }
+}
+
+// Phoneme-loss head (hifigan.py:183-189, 232-237): ph_out[b, p, f] = AvgPool1d(kernel 2*hop, stride hop, padding hop/2)(ph_fc(c))
+// with c the last stage's MRF mean.  ph_fc is linear, so the window's mean of c goes through it once: one workgroup per
+// (frame, utterance) sums the window's rows (zero padding counts in the divisor, as AvgPool1d's count_include_pad default does; the
+// bias only where a sample exists) and applies the (num_ph x C) matrix.
+struct PhHeadParams {
+    const float* x0;
+    const float* x1;
+    const float* x2;
+    int nin;          // ResBlock outputs averaged (1..3)
+    const float* w;   // ph_fc.weight (num_ph, C)
+    const float* bias;
+    float* out;       // (B, num_ph, T)
+    int C;            // real channels
+    int Cp;           // row pitch (padded channels)
+    int L;            // rows (samples) per sequence in the stage buffers
+    int T;            // output frames per utterance (row pitch of out)
+    int hop;
+    int num_ph;
+    const int* seq_len;
+    int len_const;
+};
+
+__global__ __launch_bounds__(256) void ph_head_kernel(const PhHeadParams p) {
+    __shared__ float part[8][128];
+    __shared__ float mean[128];
+    const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int frames = p.seq_len ? p.seq_len[b] : (p.len_const >= 0 ? p.len_const : p.T);
+    if (f >= frames) return;  // frames past the utterance's end are not written
+    const int Ls = frames * p.hop;
+    const int t0 = f * p.hop - p.hop / 2, K = 2 * p.hop;
+    const int lo = max(t0, 0), hi = min(t0 + K, Ls);
+    const int ch = tid & 31, rs = tid >> 5;  // 8 row slices x 32 channels per pass (C <= 128: up to 4 channel passes)
+    for (int c0 = 0; c0 < p.C; c0 += 32) {
+        float s = 0.f;
+        if (c0 + ch < p.C)
+            for (int t = lo + rs; t < hi; t += 8) {
+                const size_t off = ((size_t)b * p.L + t) * p.Cp + c0 + ch;
+                float v = p.x0[off];
+                if (p.nin == 2) v = (v + p.x1[off]) / 2.0f;
+                else if (p.nin == 3) v = ((v + p.x1[off]) + p.x2[off]) / 3.0f;
+                s += v;
+            }
+        part[rs][c0 + ch] = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        float s = 0.f;
+        for (int r = 0; r < 8; ++r) s += part[r][c];
+        mean[c] = s;
+    }
+    __syncthreads();
+    for (int q = tid; q < p.num_ph; q += 256) {
+        float s = p.bias[q] * (float)(hi - lo);
+        for (int c = 0; c < p.C; ++c) s = fmaf(p.w[(size_t)q * p.C + c], mean[c], s);
+        p.out[((size_t)b * p.num_ph + q) * p.T + f] = s / (float)K;
     }
 }
 

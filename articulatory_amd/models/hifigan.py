@@ -150,8 +150,10 @@ class HiFiGANGenerator(torch.nn.Module):
         assert kernel_size % 2 == 1, "Kernel size must be odd number."
         assert len(upsample_scales) == len(upsample_kernel_sizes)
         assert len(resblock_dilations) == len(resblock_kernel_sizes)
-        if use_spk_id or use_ph or use_ph_loss:
-            raise NotImplementedError("use_spk_id / use_ph / use_ph_loss are not built yet (SURVEY.md §8 row f4)")
+        if use_spk_id and use_ph:
+            # spk_fc maps to in_channels values but is added before the phoneme channels are appended (hifigan.py:212-220):
+            # the reference fails with a shape mismatch in forward; fail at construction here
+            raise ValueError("use_spk_id together with use_ph is ill-formed in the reference (shape mismatch at hifigan.py:216)")
         if nonlinear_activation != "LeakyReLU":
             raise NotImplementedError(f"nonlinear_activation={nonlinear_activation!r}: only LeakyReLU is built")
         for name, val in (("paddings", paddings), ("output_paddings", output_paddings)):
@@ -176,6 +178,8 @@ class HiFiGANGenerator(torch.nn.Module):
             use_additional_convs=use_additional_convs, bias=bias,
             nonlinear_activation_params={"negative_slope": slope}, use_tanh=use_tanh,
             use_ar=use_ar, ar_input=ar_input, ar_hidden=ar_hidden, ar_output=ar_output,
+            use_spk_id=use_spk_id, num_spk=num_spk, spk_emb_size=spk_emb_size, use_ph=use_ph, num_ph=num_ph,
+            ph_emb_size=ph_emb_size, use_ph_loss=use_ph_loss,
         )
         self.hop = int(np.prod(upsample_scales))
         self.precision = precision
@@ -198,6 +202,18 @@ class HiFiGANGenerator(torch.nn.Module):
         self.output_conv = torch.nn.Sequential(*out_mods)
         if use_ar:
             self.ar_model = _PastFCParams(ar_input, ar_hidden, ar_output)
+        # speaker / phoneme conditioning parameters (hifigan.py:176-189), same names and registration order as the reference
+        if use_spk_id:
+            assert num_spk is not None
+            self.spk_emb_mat = torch.nn.Embedding(num_spk, spk_emb_size)
+            self.spk_fc = torch.nn.Linear(spk_emb_size, in_channels)
+        if use_ph:
+            assert num_ph is not None
+            self.ph_emb_mat = torch.nn.Embedding(num_ph, ph_emb_size)
+        if use_ph_loss:
+            assert num_ph is not None
+            assert self.hop % 2 == 0
+            self.ph_fc = torch.nn.Linear(c_last, num_ph)
 
         if use_weight_norm:
             self.apply_weight_norm()
@@ -275,6 +291,8 @@ class HiFiGANGenerator(torch.nn.Module):
             elif isinstance(m, torch.nn.Linear):
                 out[name + ".weight"] = m.weight.detach().float().cpu().contiguous()
                 out[name + ".bias"] = m.bias.detach().float().cpu().contiguous()
+            elif isinstance(m, torch.nn.Embedding):
+                out[name + ".weight"] = m.weight.detach().float().cpu().contiguous()
         return out
 
     # ------------------------------------------------------------------ native handle
@@ -403,7 +421,8 @@ class HiFiGANGenerator(torch.nn.Module):
                 "call .eval() and wrap in torch.no_grad()")
         if not c.is_cuda:
             raise RuntimeError("HiFiGANGenerator.forward needs a CUDA/HIP tensor; there is no CPU fallback")
-        cf = self._params["in_channels"] - (self._params["ar_output"] if self.use_ar else 0)
+        cf = (self._params["in_channels"] - (self._params["ar_output"] if self.use_ar else 0)
+              - (self._params["ph_emb_size"] if self.use_ph else 0))
         if c.dim() != 3 or c.shape[1] != cf:
             raise RuntimeError(f"Expected input of shape (B, {cf}, T), got {tuple(c.shape)}")
 
@@ -420,7 +439,9 @@ class HiFiGANGenerator(torch.nn.Module):
         return host, host.to(device).contiguous()  # (host copy, device copy)
 
     def forward(self, c, spk_id=None, ar=None, ph=None, lengths=None):
-        """c: (B, in_channels[-ar_output], T) -> (B, out_channels, T * prod(upsample_scales))  (hifigan.py:198-239).
+        """c: (B, in_channels[-ar_output][-ph_emb_size], T) -> (B, out_channels, T * prod(upsample_scales))  (hifigan.py:198-239);
+        with use_ph_loss the reference's pair (out, ph_out), ph_out: (B, num_ph, T).  spk_id: (B,) speaker indices (use_spk_id);
+        ph: (B, T) phoneme indices (use_ph).
 
         ``lengths`` (not in the reference, which is batch-1 at inference): frame counts of a padded batch of utterances of
         different lengths; utterance b is computed exactly as if it were alone and out[b, :, hop*lengths[b]:] is zero."""
@@ -433,20 +454,35 @@ class HiFiGANGenerator(torch.nn.Module):
             ar = ar.to(device=c.device, dtype=torch.float32).contiguous()
         c = c.to(torch.float32).contiguous()
         B, _, T = c.shape
+        if self.use_spk_id:
+            if spk_id is None or spk_id.numel() != B:
+                raise RuntimeError("use_spk_id=True: forward() needs spk_id=(B,) speaker indices")
+            if int(spk_id.min()) < 0 or int(spk_id.max()) >= self._params["num_spk"]:
+                raise IndexError("index out of range in self")  # torch.nn.Embedding's message
+            spk_id = spk_id.to(device=c.device, dtype=torch.int32).contiguous()
+        if self.use_ph:
+            if ph is None or tuple(ph.shape) != (B, T):
+                raise RuntimeError(f"use_ph=True: forward() needs ph=(B, T)=({B}, {T}) phoneme indices")
+            if int(ph.min()) < 0 or int(ph.max()) >= self._params["num_ph"]:
+                raise IndexError("index out of range in self")
+            ph = ph.to(device=c.device, dtype=torch.int32).contiguous()
         handle = self._native_handle()
         if lengths is None:
             out = torch.empty((B, 1, T * self.hop), dtype=torch.float32, device=c.device)
         else:
             _, lengths = self._lengths_arg(lengths, B, T, c.device)
             out = torch.zeros((B, 1, T * self.hop), dtype=torch.float32, device=c.device)
+        ph_out = torch.zeros((B, self._params["num_ph"], T), dtype=torch.float32, device=c.device) if self.use_ph_loss else None
         with torch.cuda.device(c.device):
             ws_ptr, ws_bytes = self._workspace(B, T)
             stream = torch.cuda.current_stream().cuda_stream
-            rc = self._lib.hificar_forward_ragged(handle, c.data_ptr(), ar.data_ptr() if self.use_ar else None,
-                                                  lengths.data_ptr() if lengths is not None else None, out.data_ptr(),
-                                                  B, T, ws_ptr, ws_bytes, ctypes.c_void_p(stream))
+            rc = self._lib.hificar_forward_cond(handle, c.data_ptr(), ar.data_ptr() if self.use_ar else None,
+                                                spk_id.data_ptr() if self.use_spk_id else None, ph.data_ptr() if self.use_ph else None,
+                                                lengths.data_ptr() if lengths is not None else None, out.data_ptr(),
+                                                ph_out.data_ptr() if ph_out is not None else None,
+                                                B, T, ws_ptr, ws_bytes, ctypes.c_void_p(stream))
         _native.check(rc, "hificar_forward")
-        return out
+        return (out, ph_out) if self.use_ph_loss else out
 
     def ar_synthesis(self, c, chunk_frames, lengths=None):
         """Batched autoregressive synthesis on device.

@@ -82,6 +82,13 @@ def generator_param_spec(
     ar_input=512,
     ar_hidden=256,
     ar_output=128,
+    use_spk_id=False,
+    num_spk=None,
+    spk_emb_size=32,
+    use_ph=False,
+    num_ph=None,
+    ph_emb_size=8,
+    use_ph_loss=False,
     **_ignored,
 ):
     """Ordered {state_dict key: shape} of the reference generator for these kwargs.
@@ -134,6 +141,17 @@ def generator_param_spec(
         for li in range(5):
             spec[f"ar_model.model.{2 * li}.weight"] = (dims[li + 1], dims[li])
             spec[f"ar_model.model.{2 * li}.bias"] = (dims[li + 1],)
+    # speaker / phoneme conditioning (hifigan.py:176-189), in the reference's module registration order; Embedding and Linear carry
+    # no weight norm (apply_weight_norm only touches Conv1d / ConvTranspose1d, hifigan.py:268-278)
+    if use_spk_id:
+        spec["spk_emb_mat.weight"] = (num_spk, spk_emb_size)
+        spec["spk_fc.weight"] = (in_channels, spk_emb_size)
+        spec["spk_fc.bias"] = (in_channels,)
+    if use_ph:
+        spec["ph_emb_mat.weight"] = (num_ph, ph_emb_size)
+    if use_ph_loss:
+        spec["ph_fc.weight"] = (num_ph, c_last)
+        spec["ph_fc.bias"] = (num_ph,)
     return spec
 
 

@@ -11,6 +11,7 @@
  *                                                                articulatory/models/hifigan.py:256-266
  *   hificar_finalize        model.eval().to(device)              egs/ema/voc1/local/predict_wav.py:114-115
  *   hificar_forward         HiFiGANGenerator.forward             articulatory/models/hifigan.py:198-239
+ *   hificar_forward_cond    ... with spk_id= / ph= and the (out, ph_out) return of use_ph_loss    hifigan.py:212-220, 232-237
  *   hificar_ar_loop         ar_loop (non-WSOLA branch), batched  articulatory/bin/decode.py:31-83
  *   hificar_forward_ragged  the per-utterance loop over a dataset calling .inference()  egs/ema/voc1/local/predict_wav.py:124-137,
  *   hificar_ar_loop_ragged  ... or ar_loop(), one utterance at a time                    articulatory/bin/decode.py:292-351
@@ -82,6 +83,14 @@ typedef struct hificar_config {
     int32_t ar_hidden;
     int32_t ar_output;
     int32_t precision; /* HIFICAR_PREC_* */
+    /* speaker / phoneme conditioning (hifigan.py:43-49, 176-189); all zero = off, as in every shipped YAML */
+    int32_t use_spk_id;   /* adds spk_fc(spk_emb_mat[spk_id]) to every input channel of every frame (hifigan.py:212-216) */
+    int32_t num_spk;
+    int32_t spk_emb_size;
+    int32_t use_ph;       /* appends ph_emb_mat[ph[b, t]] as ph_emb_size extra input channels (hifigan.py:217-220); in_channels counts them */
+    int32_t num_ph;
+    int32_t ph_emb_size;
+    int32_t use_ph_loss;  /* second output: phoneme logits AvgPool1d(2*hop, hop, hop/2)(ph_fc(c)) at the frame rate (hifigan.py:232-237) */
 } hificar_config;
 
 /* Build an (empty) generator for these hyper-parameters on the current HIP device. */
@@ -117,6 +126,14 @@ int hificar_forward(hificar_handle* h, const float* c, const float* ar, float* o
  * Requires ar_input <= hop*chunk_frames (the only case in which the reference's loop is well formed). */
 int hificar_ar_loop(hificar_handle* h, const float* c, float* out, int B, int T_total, int chunk_frames,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* hificar_forward with the conditioning inputs of HiFiGANGenerator.forward(c, spk_id=, ar=, ph=) (hifigan.py:198-239):
+ * spk_id: device pointer to B int32 speaker indices (use_spk_id) or NULL; ph: device pointer to (B, T) int32 phoneme indices
+ * (use_ph) or NULL; ph_out: device pointer to (B, num_ph, T) fp32 (use_ph_loss: the reference then returns (out, ph_out)) or NULL.
+ * lengths as in hificar_forward_ragged (NULL: all T).  Features c: (B, in_channels - ar_output*use_ar - ph_emb_size*use_ph, T). */
+int hificar_forward_cond(hificar_handle* h, const float* c, const float* ar, const int32_t* spk_id, const int32_t* ph,
+                         const int32_t* lengths, float* out, float* ph_out, int B, int T, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* Ragged batches: B utterances of different lengths, padded to a common T (T_total) in `c`.
  * lengths: DEVICE pointer to B int32 frame counts (0 <= lengths[b] <= T), or NULL (all T).  Utterance b is

@@ -75,6 +75,7 @@ def _cfg(params):
         use_additional_convs=True, bias=True,
         nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1},
         use_ar=False, ar_input=512, ar_hidden=256, ar_output=128, use_tanh=True,
+        use_spk_id=False, num_spk=None, spk_emb_size=32, use_ph=False, num_ph=None, ph_emb_size=8, use_ph_loss=False,
     )
     p.update({k: v for k, v in params.items() if k in p})
     assert p["nonlinear_activation"] == "LeakyReLU"
@@ -105,8 +106,9 @@ def residual_block(w, prefix, x, kernel_size, dilations, slope, use_additional_c
     return x
 
 
-def generator_forward(w, params, c, ar=None, taps=None):
-    """hifigan.py:198-239 on folded weights ``w`` (dict of tensors).  c: (B, C, T); ar: (B,1,ar_input).
+def generator_forward(w, params, c, ar=None, taps=None, spk_id=None, ph=None):
+    """hifigan.py:198-239 on folded weights ``w`` (dict of tensors).  c: (B, C, T); ar: (B,1,ar_input); spk_id: (B,) long
+    (use_spk_id); ph: (B, T) long (use_ph).  Returns the waveform, or (waveform, ph_out) when use_ph_loss.
 
     ``taps``: optional dict that receives every intermediate (for per-layer golden checks).
     """
@@ -117,6 +119,11 @@ def generator_forward(w, params, c, ar=None, taps=None):
         if taps is not None:
             taps["ar_feats"] = ar_feats
         c = torch.cat((c, ar_feats.unsqueeze(2).repeat(1, 1, c.shape[2])), dim=1)
+    if p["use_spk_id"]:  # hifigan.py:212-216: a per-utterance vector added to every frame of every input channel
+        spk = F.linear(F.embedding(spk_id, w["spk_emb_mat.weight"]), w["spk_fc.weight"], w["spk_fc.bias"])
+        c = c + spk.unsqueeze(2)
+    if p["use_ph"]:  # hifigan.py:217-220: per-frame phoneme embeddings appended as channels
+        c = torch.cat((c, F.embedding(ph, w["ph_emb_mat.weight"]).transpose(1, 2)), dim=1)
     ks = p["kernel_size"]
     c = F.conv1d(c, w["input_conv.weight"], w["input_conv.bias"], padding=(ks - 1) // 2)
     if taps is not None:
@@ -135,10 +142,15 @@ def generator_forward(w, params, c, ar=None, taps=None):
         if taps is not None:
             taps[f"stage{i}"] = c
     # output conv uses LeakyReLU() default slope 0.01 (hifigan.py:150)
-    c = F.conv1d(F.leaky_relu(c, 0.01), w["output_conv.1.weight"], w["output_conv.1.bias"], padding=(ks - 1) // 2)
+    out = F.conv1d(F.leaky_relu(c, 0.01), w["output_conv.1.weight"], w["output_conv.1.bias"], padding=(ks - 1) // 2)
     if p["use_tanh"]:
-        c = torch.tanh(c)
-    return c
+        out = torch.tanh(out)
+    if p["use_ph_loss"]:  # hifigan.py:232-237 (+ :183-189): per-sample phoneme logits, average-pooled back to the frame rate
+        hop = int(np.prod(p["upsample_scales"]))
+        ph_out = F.linear(c.transpose(1, 2), w["ph_fc.weight"], w["ph_fc.bias"]).transpose(1, 2)
+        ph_out = F.avg_pool1d(ph_out, kernel_size=hop * 2, stride=hop, padding=hop // 2)
+        return out, ph_out
+    return out
 
 
 def inference(w, params, c, mean=None, scale=None):

@@ -33,10 +33,28 @@ def test_exports_every_declared_symbol(lib):
     assert b"gfx950" in lib.hificar_version()
 
 
-def test_config_struct_matches_header_layout():
-    # 5 scalars + 8 + 8 + 1 + 4 + 4 + 16 + 2 ints + float + 6 ints = 56 x 4 bytes
-    assert ctypes.sizeof(_native.HificarConfig) == 4 * (5 + 8 + 8 + 1 + 4 + 4 + 16 + 2 + 1 + 6)
+def test_config_struct_matches_header_layout(tmp_path):
+    # 5 scalars + 8 + 8 + 1 + 4 + 4 + 16 + 2 ints + float + 6 ints + 7 conditioning ints = 63 x 4 bytes
+    assert ctypes.sizeof(_native.HificarConfig) == 4 * (5 + 8 + 8 + 1 + 4 + 4 + 16 + 2 + 1 + 6 + 7)
     assert ctypes.sizeof(_native.HificarKernelStat) == 96 + 8 + 3 * 8
+    # and against the C compiler's view of include/hificar.h: size and the offset of every field
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    fields = [f[0] for f in _native.HificarConfig._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hificar.h"\nint main(void) {\n'
+                   '  printf("%zu\\n", sizeof(hificar_config));\n' +
+                   "".join(f'  printf("%zu\\n", offsetof(hificar_config, {f}));\n' for f in fields) +
+                   '  printf("%zu\\n", sizeof(hificar_kernel_stat));\n  return 0;\n}\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [ctypes.sizeof(_native.HificarConfig)] + [getattr(_native.HificarConfig, f).offset for f in fields] + \
+           [ctypes.sizeof(_native.HificarKernelStat)]
+    assert got == want
 
 
 def test_create_macs_workspace(lib):

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import E2W_PARAMS, GOLDEN, rel_err
+from conftest import E2W_PARAMS, GOLDEN, rel_err, same_across_shapes
 from articulatory_amd.models import HiFiGANGenerator
 from articulatory_amd.utils.synth import synth_features, synth_state_dict
 from oracle import hificar_oracle as O
@@ -145,6 +145,53 @@ def test_golden_small_mri_model(prec):
     assert rel_err(y.cpu().numpy(), gold["out"]) < TOLS[prec]
 
 
+def test_golden_speaker_conditioning(prec):
+    """use_spk_id (hifigan.py:176-178, 212-216) against the real reference's output (oracle/make_golden_cond.py)."""
+    params = dict(E2W_PARAMS, channels=128, use_spk_id=True, num_spk=5, spk_emb_size=32)
+    g, w = make(params, prec, seed=4321)
+    gold = np.load(os.path.join(GOLDEN, "gold_fwd_spk.npz"))
+    c, ar, spk = (torch.from_numpy(gold[k]).cuda() for k in ("c", "ar", "spk_id"))
+    with torch.no_grad():
+        y = g(c, spk_id=spk, ar=ar)
+        y_other = g(c, spk_id=(spk + 1) % 5, ar=ar)
+    assert rel_err(y.cpu().numpy(), gold["out"]) < TOLS[prec]
+    assert rel_err(y_other.cpu().numpy(), gold["out"]) > 1e-2  # the speaker vector matters
+    with pytest.raises(RuntimeError, match="spk_id"):
+        g(c, ar=ar)
+    with pytest.raises(IndexError):
+        g(c, spk_id=spk + 5, ar=ar)
+    with pytest.raises(ValueError, match="hificar_forward_cond"):
+        g.ar_synthesis(c, 25)  # the reference's ar_loop passes no spk_id either (decode.py:72)
+
+
+def test_golden_phoneme_conditioning_and_loss_head(prec):
+    """use_ph + use_ph_loss (hifigan.py:179-189, 217-220, 232-237): waveform and frame-rate phoneme logits against the real
+    reference's pair (out, ph_out); ragged lengths leave the frames past an utterance's end untouched."""
+    params = dict(E2W_PARAMS, channels=128, in_channels=20, use_ar=False, use_ph=True, num_ph=11, ph_emb_size=8, use_ph_loss=True)
+    g, w = make(params, prec, seed=4322)
+    gold = np.load(os.path.join(GOLDEN, "gold_fwd_ph.npz"))
+    c, ph = torch.from_numpy(gold["c"]).cuda(), torch.from_numpy(gold["ph"]).cuda()
+    with torch.no_grad():
+        y, ph_out = g(c, ph=ph)
+    assert rel_err(y.cpu().numpy(), gold["out"]) < TOLS[prec]
+    assert ph_out.shape == (2, 11, 19)
+    assert rel_err(ph_out.cpu().numpy(), gold["ph_out"]) < TOLS[prec]
+    # a longer, ragged batch against the oracle (bucketed launch geometry: 45 frames run as 64)
+    B, T, lens = 3, 45, [45, 20, 33]
+    x = synth_features(B, T, 12, seed=71)
+    phs = torch.from_numpy(np.random.default_rng(72).integers(0, 11, (B, T)))
+    cc = torch.from_numpy(x).permute(0, 2, 1).contiguous()
+    with torch.no_grad():
+        y, ph_out = g(cc.cuda(), ph=phs.cuda(), lengths=lens)
+        for b, n in enumerate(lens):
+            ry, rp = O.generator_forward(w, params, cc[b:b + 1, :, :n], ph=phs[b:b + 1, :n])
+            assert rel_err(y[b:b + 1, :, :80 * n].cpu().numpy(), ry.numpy()) < TOLS[prec], b
+            assert rel_err(ph_out[b:b + 1, :, :n].cpu().numpy(), rp.numpy()) < TOLS[prec], b
+            assert float(ph_out[b, :, n:].abs().sum()) == 0.0
+    with pytest.raises(RuntimeError, match="ph="):
+        g(c)
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (1, 7), (3, 33), (8, 25), (2, 129), (5, 64)])
 def test_forward_vs_oracle_shapes(car, B, T):
     g, w = car
@@ -210,7 +257,7 @@ def test_unit_kernel_shapes(name, prec):
 
 def test_baseline_size_properties(car):
     """BASELINE config 3 at full size (batch 64, 10 s, chunk 25): properties that need no oracle run.
-    (a) utterances are independent: a batch-64 run reproduces a batch-1 run of the same utterance bit for bit
+    (a) utterances are independent: a batch-64 run reproduces a batch-1 run of the same utterance (bit for bit with HIFICAR_KSPLIT=0, to fp32 rounding otherwise)
         and duplicated utterances give duplicated waveforms;  (b) the first chunk equals forward(ar = 0);
     (c) an oracle check on a window: chunk k of utterance u equals the oracle's forward of that chunk fed
         with the GPU's own previous 512 samples."""
@@ -225,7 +272,7 @@ def test_baseline_size_properties(car):
         first = g(feats[:, :, :chunk].contiguous(), ar=torch.zeros(B, 1, 512, device="cuda:0"))
     assert y.shape == (64, 160000) and bool(torch.isfinite(y).all())
     assert torch.equal(y[0], y[63])
-    assert torch.equal(y[17], y1[0])
+    assert same_across_shapes(y[17], y1[0])  # batch 64 vs batch 1: different launch shapes
     assert torch.equal(y[:, :2000], first[:, 0])
     assert float(y.abs().max()) <= 1.0  # tanh range
     yc = y.cpu()
@@ -486,7 +533,7 @@ def test_pcm16_on_device_matches_host_writer(tmp_path):
 
 def test_ragged_batch_equals_one_at_a_time(car):
     """hificar_ar_loop_ragged: a padded batch of utterances of different lengths gives, per utterance, the waveform of
-    that utterance synthesised alone (bit for bit — same kernels, same accumulation order, zero padding at its own end),
+    that utterance synthesised alone (same_across_shapes: bit for bit in the dense conv form, zero padding at its own end),
     which in turn matches the oracle's batch-1 ``ar_loop`` (decode.py:54-83) incl. each utterance's own short tail chunk."""
     g, w = car
     lens = [260, 25, 131, 7, 200, 0, 99]
@@ -505,7 +552,7 @@ def test_ragged_batch_equals_one_at_a_time(car):
         with torch.no_grad():
             alone = g.ar_synthesis(feats[b:b + 1, :, :n].contiguous(), 25)
             ref = O.ar_loop(w, E2W_PARAMS, torch.from_numpy(x[b, :n]), 2000, 80)
-        assert torch.equal(y[b, :80 * n], alone[0]), (b, n)
+        assert same_across_shapes(y[b, :80 * n], alone[0]), (b, n)
         assert rel_err(y[b, :80 * n].cpu().numpy(), ref.numpy()) < g.tol, (b, n)
     # one chunk through hificar_forward_ragged with an AR context per utterance
     ar = torch.from_numpy(synth_features(len(lens), 512, 1, seed=8)[:, :, 0] * 0.3).reshape(len(lens), 1, 512).cuda()
@@ -515,8 +562,36 @@ def test_ragged_batch_equals_one_at_a_time(car):
         for b, n in enumerate(flens):
             if n:
                 alone = g(feats[b:b + 1, :, :n].contiguous(), ar=ar[b:b + 1])
-                assert torch.equal(yf[b, :, :80 * n], alone[0]), (b, n)
+                assert same_across_shapes(yf[b, :, :80 * n], alone[0]), (b, n)
             assert float(yf[b, :, 80 * n:].abs().sum()) == 0.0
+
+
+def test_batch_invariance_is_bitwise_without_split_k(monkeypatch, prec):
+    """HIFICAR_KSPLIT=0 (dense conv form for every launch shape): an utterance's waveform does not depend on what else is in the
+    batch — ragged batch, continuous batching and alone are bit-identical; with the default (split-K on small launches) they
+    agree to fp32 rounding (same_across_shapes)."""
+    monkeypatch.setenv("HIFICAR_KSPLIT", "0")
+    g, _ = make(dict(E2W_PARAMS), prec)
+    lens = [130, 25, 77, 7, 100, 0]
+    Tm = max(lens)
+    x = synth_features(len(lens), Tm, 13, seed=4243)
+    feats = torch.from_numpy(x).permute(0, 2, 1).contiguous().cuda()
+    with torch.no_grad():
+        y = g.ar_synthesis(feats, 25, lengths=lens)
+        yp = g.ar_synthesis_packed(feats, 25, lens, batch=2)
+        for b, n in enumerate(lens):
+            if n:
+                alone = g.ar_synthesis(feats[b:b + 1, :, :n].contiguous(), 25)
+                assert torch.equal(y[b, :80 * n], alone[0]) and torch.equal(yp[b, :80 * n], alone[0]), (b, n)
+    monkeypatch.delenv("HIFICAR_KSPLIT")
+    g2, _ = make(dict(E2W_PARAMS), prec)
+    with torch.no_grad():
+        y2 = g2.ar_synthesis(feats, 25, lengths=lens)
+        g2.profile_begin()
+        g2.ar_synthesis(feats[:1, :, :50].contiguous(), 25)
+        names = {s["name"].split("<")[0] for s in g2.profile_end()}
+    assert any(n.startswith("conv_sk_") for n in names), names  # the small launch really took the split-K form
+    assert same_across_shapes(y2, y)
 
 
 def test_ragged_forward_non_ar(prec):
@@ -531,7 +606,7 @@ def test_ragged_forward_non_ar(prec):
         y = g(feats, lengths=torch.tensor(lens))
         for b, n in enumerate(lens):
             alone = g(feats[b:b + 1, :, :n].contiguous())
-            assert torch.equal(y[b, :, :80 * n], alone[0]), (b, n)
+            assert same_across_shapes(y[b, :, :80 * n], alone[0]), (b, n)
             assert float(y[b, :, 80 * n:].abs().sum()) == 0.0
         ref = O.generator_forward(w, params, torch.from_numpy(x[1:2, :41]).permute(0, 2, 1))
     assert rel_err(y[1, :, :80 * 41].cpu().numpy(), ref[0].numpy()) < TOLS[prec]
@@ -555,12 +630,12 @@ def test_decode_dataset_ragged_batches_on_device(car, tmp_path):
                                writer=lambda p, y, sr: four.__setitem__(os.path.basename(p), y))
     assert n1 == n4 == 5 and rtf > 0 and sorted(one) == sorted(four)
     for k in one:
-        assert one[k].shape == four[k].shape and np.array_equal(one[k], four[k]), k
+        assert one[k].shape == four[k].shape and same_across_shapes(one[k], four[k]), k
 
 
 def test_packed_ar_loop_equals_one_at_a_time(car):
     """hificar_ar_loop_packed (continuous batching: 3 utterances in flight out of 9, a finished one replaced by the next):
-    every utterance's waveform is bit-identical to synthesising it alone; zero-length and single-chunk utterances included."""
+    every utterance equals synthesising it alone (same_across_shapes); zero-length and single-chunk utterances included."""
     g, w = car
     lens = [260, 131, 130, 99, 64, 26, 25, 7, 0]
     Tm = max(lens)
@@ -571,13 +646,13 @@ def test_packed_ar_loop_equals_one_at_a_time(car):
     with torch.no_grad():
         y = g.ar_synthesis_packed(feats, 25, lens, batch=3)
         y_all = g.ar_synthesis_packed(feats, 25, lens, batch=64)
-    assert y.shape == (len(lens), 80 * Tm) and torch.equal(y, y_all)
+    assert y.shape == (len(lens), 80 * Tm) and same_across_shapes(y, y_all)
     for b, n in enumerate(lens):
         assert float(y[b, 80 * n:].abs().sum()) == 0.0
         if n:
             with torch.no_grad():
                 alone = g.ar_synthesis(feats[b:b + 1, :, :n].contiguous(), 25)
-            assert torch.equal(y[b, :80 * n], alone[0]), (b, n)
+            assert same_across_shapes(y[b, :80 * n], alone[0]), (b, n)
     ref = O.ar_loop(w, E2W_PARAMS, torch.from_numpy(x[1, :131]), 2000, 80)
     assert rel_err(y[1, :80 * 131].cpu().numpy(), ref.numpy()) < g.tol
     with pytest.raises(RuntimeError):
@@ -617,8 +692,9 @@ def test_cli_mains_end_to_end_on_device(tmp_path, monkeypatch):
     for i, T in enumerate(lens):
         a = read(tmp_path / "d1" / f"u{i}_gen.wav")
         assert len(a) == 80 * T
-        assert np.array_equal(a, read(tmp_path / "d4" / f"u{i}_gen.wav"))
-        assert np.array_equal(a, read(tmp_path / "p4" / f"u{i}.wav"))
+        # batch 1 vs batch 4 launches may differ in the last fp32 bit (split-K form on small launches): at most one PCM step
+        for other in (read(tmp_path / "d4" / f"u{i}_gen.wav"), read(tmp_path / "p4" / f"u{i}.wav")):
+            assert len(other) == len(a) and int(np.abs(a.astype(np.int32) - other.astype(np.int32)).max()) <= 1
     monkeypatch.setenv("WORLD_SIZE", "2")
     for r in (0, 1):
         monkeypatch.setenv("RANK", str(r))

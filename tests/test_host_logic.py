@@ -77,9 +77,13 @@ def test_no_cpu_fallback():
     g.train()
     with pytest.raises(NotImplementedError, match="training"):
         g(torch.zeros(1, 13, 25), ar=torch.zeros(1, 1, 512))
-    for kw in ("use_spk_id", "use_ph", "use_ph_loss"):
-        with pytest.raises(NotImplementedError):
-            articulatory_amd.models.HiFiGANGenerator(**dict(E2W_PARAMS, **{kw: True}))
+    # conditioned variants construct with the reference's parameter names (hifigan.py:176-189); the ill-formed combination is refused
+    g = articulatory_amd.models.HiFiGANGenerator(**dict(E2W_PARAMS, use_spk_id=True, num_spk=4))
+    assert tuple(g.state_dict()["spk_fc.weight"].shape) == (141, 32) and tuple(g.state_dict()["spk_emb_mat.weight"].shape) == (4, 32)
+    g = articulatory_amd.models.HiFiGANGenerator(**dict(E2W_PARAMS, in_channels=149, use_ph=True, num_ph=9, use_ph_loss=True))
+    assert tuple(g.state_dict()["ph_emb_mat.weight"].shape) == (9, 8) and tuple(g.state_dict()["ph_fc.weight"].shape) == (9, 32)
+    with pytest.raises(ValueError, match="ill-formed"):
+        articulatory_amd.models.HiFiGANGenerator(**dict(E2W_PARAMS, use_spk_id=True, num_spk=4, use_ph=True, num_ph=9))
 
 
 def test_product_code_never_imports_the_oracle():

@@ -192,3 +192,22 @@ def test_saturated_synthetic_network_is_chaotic_on_cpu_too():
         out[gain] = (float(e[:, :2000].max()), float(e.max() / y64.abs().max()))
     assert out[1.3][0] < 1e-4 and out[1.3][1] > 1e-2, out
     assert out[1.0][1] < 1e-5, out
+
+
+def test_oracle_speaker_and_phoneme_conditioning_vs_reference():
+    """use_spk_id / use_ph / use_ph_loss branches (hifigan.py:176-189, 212-220, 232-237) against the real reference's outputs
+    (oracle/make_golden_cond.py)."""
+    gold = np.load(os.path.join(GOLDEN, "gold_fwd_spk.npz"))
+    params = dict(E2W_PARAMS, channels=128, use_spk_id=True, num_spk=5, spk_emb_size=32)
+    w = O.fold_weight_norm(synth_state_dict(params, seed=4321))
+    with torch.no_grad():
+        y = O.generator_forward(w, params, torch.from_numpy(gold["c"]), torch.from_numpy(gold["ar"]), spk_id=torch.from_numpy(gold["spk_id"]))
+    assert rel_err(y.numpy(), gold["out"]) < 2e-6
+    gold = np.load(os.path.join(GOLDEN, "gold_fwd_ph.npz"))
+    params = dict(E2W_PARAMS, channels=128, in_channels=20, use_ar=False, use_ph=True, num_ph=11, ph_emb_size=8, use_ph_loss=True)
+    w = O.fold_weight_norm(synth_state_dict(params, seed=4322))
+    with torch.no_grad():
+        y, ph_out = O.generator_forward(w, params, torch.from_numpy(gold["c"]), ph=torch.from_numpy(gold["ph"]))
+    assert rel_err(y.numpy(), gold["out"]) < 2e-6
+    assert ph_out.shape == gold["ph_out"].shape == (2, 11, 19)
+    assert rel_err(ph_out.numpy(), gold["ph_out"]) < 2e-6
