@@ -245,8 +245,8 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (c.n_stages < 1 || c.n_stages > HIFICAR_MAX_STAGES) return fail(HIFICAR_E_INVALID, "n_stages=%d out of range", c.n_stages);
     if (c.n_blocks < 1 || c.n_blocks > 3) return fail(HIFICAR_E_INVALID, "n_blocks=%d unsupported (1..3 residual blocks per stage)", c.n_blocks);
     if (!c.use_additional_convs) return fail(HIFICAR_E_INVALID, "use_additional_convs=false is unsupported");
-    if (c.use_ar && (c.ar_input > 1024 || c.ar_hidden > 1024 || c.ar_output > 1024 || c.ar_input < 1))
-        return fail(HIFICAR_E_INVALID, "PastFCEncoder dims must be <= 1024");
+    if (c.use_ar && (c.ar_input > 1024 || c.ar_hidden > 512 || c.ar_output > 512 || c.ar_input < 1))
+        return fail(HIFICAR_E_INVALID, "PastFCEncoder: ar_input must be <= 1024, ar_hidden / ar_output <= 512");
     if (c.use_ar && (c.ar_hidden % 4 != 0 || c.ar_output % 4 != 0))
         return fail(HIFICAR_E_INVALID, "PastFCEncoder hidden/output dims must be multiples of 4");
     if (!(c.lrelu_slope >= 0.f && c.lrelu_slope <= 1.f)) return fail(HIFICAR_E_INVALID, "negative_slope=%g outside [0, 1]", c.lrelu_slope);
@@ -267,9 +267,9 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
             h->num_cus = prop.multiProcessorCount;
     }
     h->precision = c.precision;
-    if (c.use_spk_id && (c.num_spk < 1 || c.spk_emb_size < 1)) {
+    if (c.use_spk_id && (c.num_spk < 1 || c.spk_emb_size < 1 || c.in_channels > 1024)) {
         delete h;
-        return fail(HIFICAR_E_INVALID, "use_spk_id needs num_spk and spk_emb_size");
+        return fail(HIFICAR_E_INVALID, "use_spk_id needs num_spk and spk_emb_size (and in_channels <= 1024)");
     }
     if ((c.use_ph || c.use_ph_loss) && c.num_ph < 1) {
         delete h;
@@ -1233,7 +1233,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
         const double mlp_macs = cfg.use_ar ? (double)cfg.ar_input * cfg.ar_hidden + 3.0 * cfg.ar_hidden * cfg.ar_hidden +
                                                  (double)cfg.ar_hidden * cfg.ar_output : 0.0;
         ProfScope prof(h, stream, "front_kernel", 2.0 * B * mlp_macs, 4.0 * B * (mlp_macs + (double)T * (h->cf + h->cin_pad)));
-        hipLaunchKernelGGL(front_kernel, dim3(B), dim3(512), 0, stream, fp);
+        hipLaunchKernelGGL(front_kernel, dim3(B), dim3(kFrontThreads), 0, stream, fp);
     }
     HIP_TRY(hipGetLastError());
 

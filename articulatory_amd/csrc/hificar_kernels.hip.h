@@ -501,12 +501,6 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-            // this wave's first weight fragments of the tile do not depend on the staging barrier: request them before it
-            frag_t wh, wl;
-            if (ks < nsteps) {
-                wh = wtile[(size_t)ks * 128];
-                wl = wtile[(size_t)ks * 128 + 64];
-            }
             auto x_addr = [&](int buf_off, int s, int (&ad)[2]) {
                 const int t = s >> LOG_NC, u = s & (NC16 - 1);
                 const int r0 = li + roff0 + t * tap_step;
@@ -520,36 +514,52 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                     ad[1] = base + (((SPR / 2 + 2 * u + g) ^ swz) << 4);
                 }
             };
+            const int spi = ks < nsteps ? (nsteps - ks + 3) >> 2 : 0;  // this wave's steps per item: s = ks + 4 i
             for (int c = 0; c < nchunks; ++c, ++j) {
+                // The weight fragments do not depend on the staging barrier: this item's first two steps are requested before it.
+                // Inside the item they run two steps ahead of their use in two alternating register sets (no rotation copies).
+                const frag_t* wc = wtile + (size_t)c * nsteps * 128 + (size_t)ks * 128;  // step i of this wave: wc[i * 512 (+ 64)]
+                frag_t w0h, w0l, w1h, w1l;
+                if (spi > 0) {
+                    w0h = wc[0];
+                    w0l = wc[64];
+                }
+                if (spi > 1) {
+                    w1h = wc[512];
+                    w1l = wc[512 + 64];
+                }
                 __syncthreads();  // item j is staged
                 const int buf_off = (j & 1) * buf_bytes;
-                const frag_t* wc = wtile + (size_t)c * nsteps * 128;
-                frag_t xh[MI], xl[MI];
+                frag_t x0h[MI], x0l[MI], x1h[MI], x1l[MI];
                 int ad[2];
-                if (ks < nsteps) {
+                if (spi > 0) {
                     x_addr(buf_off, ks, ad);
-                    load_x(xh, xl, ad);
+                    load_x(x0h, x0l, ad);
                 }
-                for (int s = ks; s < nsteps; s += 4) {
-                    const frag_t cwh = wh, cwl = wl;
-                    frag_t nxh[MI], nxl[MI];
-                    const bool more = s + 4 < nsteps;
-                    if (more) {  // next step of this item: fragments and weights requested before this step's MFMAs
-                        x_addr(buf_off, s + 4, ad);
-                        load_x(nxh, nxl, ad);
-                        wh = wc[(size_t)(s + 4) * 128];
-                        wl = wc[(size_t)(s + 4) * 128 + 64];
-                    } else if (c + 1 < nchunks && ks < nsteps) {  // first step of the next item (its rows are not staged yet: weights only)
-                        wh = wc[(size_t)(nsteps + ks) * 128];
-                        wl = wc[(size_t)(nsteps + ks) * 128 + 64];
+                for (int i = 0; i < spi; i += 2) {
+                    if (i + 1 < spi) {
+                        x_addr(buf_off, ks + 4 * (i + 1), ad);
+                        load_x(x1h, x1l, ad);
                     }
-                    mfma_step(xh, xl, cwh, cwl);
-                    if (more) {
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) {
-                            xh[mi] = nxh[mi];
-                            xl[mi] = nxl[mi];
+                    {
+                        const frag_t cwh = w0h, cwl = w0l;
+                        if (i + 2 < spi) {
+                            w0h = wc[(size_t)(i + 2) * 512];
+                            w0l = wc[(size_t)(i + 2) * 512 + 64];
                         }
+                        mfma_step(x0h, x0l, cwh, cwl);
+                    }
+                    if (i + 1 < spi) {
+                        if (i + 2 < spi) {
+                            x_addr(buf_off, ks + 4 * (i + 2), ad);
+                            load_x(x0h, x0l, ad);
+                        }
+                        const frag_t cwh = w1h, cwl = w1l;
+                        if (i + 3 < spi) {
+                            w1h = wc[(size_t)(i + 3) * 512];
+                            w1l = wc[(size_t)(i + 3) * 512 + 64];
+                        }
+                        mfma_step(x1h, x1l, cwh, cwl);
                     }
                 }
             }
@@ -1327,10 +1337,12 @@ struct FrontParams {
     int ph_e;
 };
 
-__global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
-    constexpr int NW = 8;  // waves = K slices
+constexpr int kFrontThreads = 1024;
+__global__ __launch_bounds__(kFrontThreads) void front_kernel(const FrontParams p) {
+    constexpr int NW = kFrontThreads / 64;  // waves = K slices: 16 slices x 16 loads in flight per lane cover a 512-input layer in two rounds
+    constexpr int NT = kFrontThreads;
     __shared__ __attribute__((aligned(16))) float act[2][1024];
-    __shared__ __attribute__((aligned(16))) float part[NW][1024];
+    __shared__ __attribute__((aligned(16))) float part[NW][512];  // layer outputs: ar_hidden, ar_output <= 512 (hificar_create)
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1342,7 +1354,7 @@ __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
             const int2 sl = p.slots[b];
             prevp = sl.y > 0 ? p.prev + (size_t)sl.x * p.prev_bstride + (size_t)p.hop * sl.y - p.ar_input : nullptr;
         }
-        for (int i = tid; i < p.ar_input; i += 512) act[0][i] = prevp ? prevp[i] : 0.f;
+        for (int i = tid; i < p.ar_input; i += NT) act[0][i] = prevp ? prevp[i] : 0.f;
         __syncthreads();
         int din = p.ar_input;
         for (int layer = 0; layer < 5; ++layer) {
@@ -1353,12 +1365,12 @@ __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
             for (int j4 = lane * 4; j4 < dout; j4 += 256) {  // dims are multiples of 4 (checked at create)
                 f32x4 s = {0.f, 0.f, 0.f, 0.f};
                 int i = i0;
-                for (; i + 8 <= i1; i += 8) {  // 8 independent 16-byte loads in flight per lane, 64 KB per CU
-                    f32x4 w[8];
+                for (; i + 16 <= i1; i += 16) {  // 16 independent 16-byte loads in flight per lane
+                    f32x4 w[16];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(wt + (size_t)(i + q) * dout + j4);
+                    for (int q = 0; q < 16; ++q) w[q] = *reinterpret_cast<const f32x4*>(wt + (size_t)(i + q) * dout + j4);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
+                    for (int q = 0; q < 16; ++q) {
                         const float xv = x[i + q];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) s[e] = fmaf(xv, w[q][e], s[e]);
@@ -1373,7 +1385,7 @@ __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
                 *reinterpret_cast<f32x4*>(&part[ks][j4]) = s;
             }
             __syncthreads();
-            for (int j = tid; j < dout; j += 512) {
+            for (int j = tid; j < dout; j += NT) {
                 float v = p.bs[layer][j];
 #pragma unroll
                 for (int q = 0; q < NW; ++q) v += part[q][j];
@@ -1387,12 +1399,13 @@ __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
     // act[cur][0:ar_output] now holds the AR features
     const float* feats = act[cur];
     const int c_ar = p.use_ar ? p.ar_output : 0;
-    if (p.spk_id) {  // per-utterance speaker vector for channels [0, cf + ar_output): part[0][ch]
+    float* spk_vec = act[cur ^ 1];  // free once the MLP is done (in_channels <= 1024 with use_spk_id, hificar_create)
+    if (p.spk_id) {  // per-utterance speaker vector for channels [0, cf + ar_output)
         const float* e = p.spk_emb + (size_t)p.spk_id[b] * p.spk_e;
-        for (int ch = tid; ch < p.cf + c_ar; ch += 512) {
+        for (int ch = tid; ch < p.cf + c_ar; ch += NT) {
             float v = p.spk_b[ch];
             for (int k = 0; k < p.spk_e; ++k) v = fmaf(p.spk_w[(size_t)ch * p.spk_e + k], e[k], v);
-            part[0][ch] = v;
+            spk_vec[ch] = v;
         }
         __syncthreads();
     }
@@ -1403,14 +1416,14 @@ __global__ __launch_bounds__(512) void front_kernel(const FrontParams p) {
         cbase = (size_t)p.slots[b].x * p.c_bstride + p.slots[b].y;
         tmax = p.valid[b];  // frames past the utterance's end may lie outside the packed tensor
     }
-    for (int idx = tid; idx < n; idx += 512) {
+    for (int idx = tid; idx < n; idx += NT) {
         const int t = idx / p.cin_pad;
         const int ch = idx - t * p.cin_pad;
         float v = 0.f;
         if (ch < p.cf) v = t < tmax ? p.c[cbase + (size_t)ch * p.c_cstride + t] : 0.f;
         else if (ch < p.cf + c_ar) v = feats[ch - p.cf];
         else if (p.ph && ch < p.cf + c_ar + p.ph_e) v = t < tmax ? p.ph_emb[(size_t)p.ph[(size_t)b * p.ph_stride + t] * p.ph_e + (ch - p.cf - c_ar)] : 0.f;
-        if (p.spk_id && ch < p.cf + c_ar && t < tmax) v += part[0][ch];
+        if (p.spk_id && ch < p.cf + c_ar && t < tmax) v += spk_vec[ch];
         if (p.xin) p.xin[(size_t)b * n + idx] = v;
         if (p.xin_s) {
             __bf16* row = reinterpret_cast<__bf16*>(p.xin_s + ((size_t)b * p.T + t) * p.cin_pad * 4);

@@ -107,7 +107,7 @@ def test_random_ar_dataset(case):
         yr = g.ar_synthesis(feats, chunk, lengths=lens)
     tag = (case, prec, chunk, lens, {k: params[k] for k in ("channels", "kernel_size", "upsample_scales", "resblock_kernel_sizes",
                                                              "resblock_dilations", "in_channels")})
-    assert same_across_shapes(yp, yr), tag
+    assert same_across_shapes(yp, yr, 5e-6 if prec == "f32" else 2e-4), tag
     for b, n in enumerate(lens):
         assert float(yp[b, hop * n:].abs().sum()) == 0.0, tag
         if n:

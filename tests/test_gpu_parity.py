@@ -23,6 +23,9 @@ NORTH_STAR_TOL = 1e-3
 # every test runs for both conv arithmetics unless HIFICAR_PRECISION narrows it
 PRECISIONS = [os.environ["HIFICAR_PRECISION"]] if os.environ.get("HIFICAR_PRECISION") else ["f32", "bf16x3"]
 TOLS = {"f32": 2e-5, "bf16x3": 2e-4}
+# same utterance, different launch shapes (split-K vs dense accumulation order): fp32 rounding for the exact arithmetic; the bf16x3
+# arithmetic re-splits every activation into hi + lo, so a last-bit change moves its own 2^-16-level rounding pattern
+XSHAPE_TOL = {"f32": 5e-6, "bf16x3": 2e-4}
 
 
 def _require_gpu():
@@ -272,7 +275,7 @@ def test_baseline_size_properties(car):
         first = g(feats[:, :, :chunk].contiguous(), ar=torch.zeros(B, 1, 512, device="cuda:0"))
     assert y.shape == (64, 160000) and bool(torch.isfinite(y).all())
     assert torch.equal(y[0], y[63])
-    assert same_across_shapes(y[17], y1[0])  # batch 64 vs batch 1: different launch shapes
+    assert same_across_shapes(y[17], y1[0], XSHAPE_TOL[g.precision])  # batch 64 vs batch 1: different launch shapes
     assert torch.equal(y[:, :2000], first[:, 0])
     assert float(y.abs().max()) <= 1.0  # tanh range
     yc = y.cpu()
@@ -552,7 +555,7 @@ def test_ragged_batch_equals_one_at_a_time(car):
         with torch.no_grad():
             alone = g.ar_synthesis(feats[b:b + 1, :, :n].contiguous(), 25)
             ref = O.ar_loop(w, E2W_PARAMS, torch.from_numpy(x[b, :n]), 2000, 80)
-        assert same_across_shapes(y[b, :80 * n], alone[0]), (b, n)
+        assert same_across_shapes(y[b, :80 * n], alone[0], XSHAPE_TOL[g.precision]), (b, n)
         assert rel_err(y[b, :80 * n].cpu().numpy(), ref.numpy()) < g.tol, (b, n)
     # one chunk through hificar_forward_ragged with an AR context per utterance
     ar = torch.from_numpy(synth_features(len(lens), 512, 1, seed=8)[:, :, 0] * 0.3).reshape(len(lens), 1, 512).cuda()
@@ -562,7 +565,7 @@ def test_ragged_batch_equals_one_at_a_time(car):
         for b, n in enumerate(flens):
             if n:
                 alone = g(feats[b:b + 1, :, :n].contiguous(), ar=ar[b:b + 1])
-                assert same_across_shapes(yf[b, :, :80 * n], alone[0]), (b, n)
+                assert same_across_shapes(yf[b, :, :80 * n], alone[0], XSHAPE_TOL[g.precision]), (b, n)
             assert float(yf[b, :, 80 * n:].abs().sum()) == 0.0
 
 
@@ -591,7 +594,7 @@ def test_batch_invariance_is_bitwise_without_split_k(monkeypatch, prec):
         g2.ar_synthesis(feats[:1, :, :50].contiguous(), 25)
         names = {s["name"].split("<")[0] for s in g2.profile_end()}
     assert any(n.startswith("conv_sk_") for n in names), names  # the small launch really took the split-K form
-    assert same_across_shapes(y2, y)
+    assert same_across_shapes(y2, y, XSHAPE_TOL[prec])
 
 
 def test_ragged_forward_non_ar(prec):
@@ -606,7 +609,7 @@ def test_ragged_forward_non_ar(prec):
         y = g(feats, lengths=torch.tensor(lens))
         for b, n in enumerate(lens):
             alone = g(feats[b:b + 1, :, :n].contiguous())
-            assert same_across_shapes(y[b, :, :80 * n], alone[0]), (b, n)
+            assert same_across_shapes(y[b, :, :80 * n], alone[0], XSHAPE_TOL[prec]), (b, n)
             assert float(y[b, :, 80 * n:].abs().sum()) == 0.0
         ref = O.generator_forward(w, params, torch.from_numpy(x[1:2, :41]).permute(0, 2, 1))
     assert rel_err(y[1, :, :80 * 41].cpu().numpy(), ref[0].numpy()) < TOLS[prec]
@@ -630,7 +633,7 @@ def test_decode_dataset_ragged_batches_on_device(car, tmp_path):
                                writer=lambda p, y, sr: four.__setitem__(os.path.basename(p), y))
     assert n1 == n4 == 5 and rtf > 0 and sorted(one) == sorted(four)
     for k in one:
-        assert one[k].shape == four[k].shape and same_across_shapes(one[k], four[k]), k
+        assert one[k].shape == four[k].shape and same_across_shapes(one[k], four[k], XSHAPE_TOL[g.precision]), k
 
 
 def test_packed_ar_loop_equals_one_at_a_time(car):
@@ -646,13 +649,13 @@ def test_packed_ar_loop_equals_one_at_a_time(car):
     with torch.no_grad():
         y = g.ar_synthesis_packed(feats, 25, lens, batch=3)
         y_all = g.ar_synthesis_packed(feats, 25, lens, batch=64)
-    assert y.shape == (len(lens), 80 * Tm) and same_across_shapes(y, y_all)
+    assert y.shape == (len(lens), 80 * Tm) and same_across_shapes(y, y_all, XSHAPE_TOL[g.precision])
     for b, n in enumerate(lens):
         assert float(y[b, 80 * n:].abs().sum()) == 0.0
         if n:
             with torch.no_grad():
                 alone = g.ar_synthesis(feats[b:b + 1, :, :n].contiguous(), 25)
-            assert same_across_shapes(y[b, :80 * n], alone[0]), (b, n)
+            assert same_across_shapes(y[b, :80 * n], alone[0], XSHAPE_TOL[g.precision]), (b, n)
     ref = O.ar_loop(w, E2W_PARAMS, torch.from_numpy(x[1, :131]), 2000, 80)
     assert rel_err(y[1, :80 * 131].cpu().numpy(), ref.numpy()) < g.tol
     with pytest.raises(RuntimeError):
