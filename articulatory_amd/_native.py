@@ -38,6 +38,14 @@ SYMBOLS = (
     "hificar_profile_begin",
     "hificar_profile_end",
     "hificar_debug_tap",
+    "hificar_set_weight_device",
+    "hificar_tape_bytes",
+    "hificar_forward_train",
+    "hificar_backward_workspace_bytes",
+    "hificar_grad_count",
+    "hificar_grad_info",
+    "hificar_grad_floats",
+    "hificar_backward",
     "hificar_destroy",
     "hificar_last_error",
     "hificar_version",
@@ -134,6 +142,22 @@ def load_library():
     lib.hificar_profile_end.restype = ctypes.c_int
     lib.hificar_debug_tap.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t]
     lib.hificar_debug_tap.restype = ctypes.c_int
+    lib.hificar_set_weight_device.argtypes = [vp, ctypes.c_char_p, vp, vp]
+    lib.hificar_set_weight_device.restype = ctypes.c_int
+    lib.hificar_tape_bytes.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.hificar_tape_bytes.restype = ctypes.c_size_t
+    lib.hificar_forward_train.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]
+    lib.hificar_forward_train.restype = ctypes.c_int
+    lib.hificar_backward_workspace_bytes.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.hificar_backward_workspace_bytes.restype = ctypes.c_size_t
+    lib.hificar_grad_count.argtypes = [vp]
+    lib.hificar_grad_count.restype = ctypes.c_int
+    lib.hificar_grad_info.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    lib.hificar_grad_info.restype = ctypes.c_int
+    lib.hificar_grad_floats.argtypes = [vp]
+    lib.hificar_grad_floats.restype = ctypes.c_int64
+    lib.hificar_backward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.hificar_backward.restype = ctypes.c_int
     lib.hificar_destroy.argtypes = [vp]
     lib.hificar_destroy.restype = None
     lib.hificar_last_error.argtypes = []

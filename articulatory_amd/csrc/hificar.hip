@@ -3,6 +3,7 @@
 // from a hificar_config, repacks folded weights into the kernels' layouts, plans the workspace and
 // enqueues the forward pass / the batched autoregressive loop on the caller's HIP stream.
 #include "hificar_kernels.hip.h"
+#include "hificar_backward.hip.h"
 
 #include "../../include/hificar.h"
 
@@ -89,6 +90,9 @@ struct hificar_handle {
     // output conv
     float* d_out_w = nullptr;
     float out_bias = 0.f;
+    float* d_out_bias = nullptr;   // training (device-resident weights): the output conv's bias is read from here
+    void* train = nullptr;         // TrainState (hificar_train.hip.inc), created by the first hificar_set_weight_device
+    void (*train_free)(hificar_handle*) = nullptr;
     // MLP
     float* d_mlp_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float* d_mlp_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -398,6 +402,7 @@ extern "C" void hificar_destroy(hificar_handle* h) {
     if (h->d_tab) (void)hipFree(h->d_tab);
     if (h->h_tab) (void)hipHostFree(h->h_tab);
     if (h->tap_scratch) (void)hipFree(h->tap_scratch);
+    if (h->train_free) h->train_free(h);
     if (h->tab_copied) (void)hipEventDestroy(h->tab_copied);
     for (auto& a : h->arenas) {
         (void)hipFree(a.d);
@@ -724,6 +729,20 @@ extern "C" double hificar_macs(const hificar_handle* h, int B, int T) {
 // ------------------------------------------------------------------------------------------------
 // Ragged batch context of one forward: utterance b has seq_len[b] frames (device array, null = all equal); the forward
 // covers frames [f0, f0 + frames) of every utterance.
+// Training tape: every activated conv input of one forward gets its own buffer (the backward pass reads them: wgrad operands and
+// LeakyReLU' masks); nothing is overwritten.  Filled by plan_tape() from a caller-provided tape buffer.
+struct Tape {
+    float* xin = nullptr;                                              // (B, T, cin_pad) assembled input rows
+    char* h0_s = nullptr;                                              // activated input-conv output
+    char* upin_s[HIFICAR_MAX_STAGES] = {};                             // activated input of upsample i (i = 0: h0_s)
+    char* u_s[HIFICAR_MAX_STAGES] = {};                                // activated upsample output
+    char* xt_s[HIFICAR_MAX_STAGES][3][HIFICAR_MAX_DILATIONS] = {};     // activated conv1 output (= conv2 input)
+    char* x_s[HIFICAR_MAX_STAGES][3][HIFICAR_MAX_DILATIONS] = {};      // activated residual stream after pair d (= next conv1 input)
+    float* mlp = nullptr;                                              // (B, 5, 1024) PastFCEncoder layer inputs
+    float* fin[3] = {nullptr, nullptr, nullptr};                       // fp32 ResBlock outputs of the LAST stage (output conv backward)
+    size_t bytes = 0;
+};
+
 // Conditioning inputs / extra output of one forward (hificar_forward_cond)
 struct Cond {
     const int32_t* spk_id = nullptr;
@@ -903,6 +922,8 @@ struct ConvIO {
     const float* res;
     float* y;
     char* ys;
+    const float* mask_src = nullptr;  // backward launches: LeakyReLU'(mask_src) scales the result before res is added
+    float mask_slope = 0.f;
 };
 
 static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows, const ConvIO* io,
@@ -974,6 +995,8 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         fill_params(mp.p[b], Lb, rows, TM, io[b].res, io[b].y, rg);
         mp.p[b].xs = io[b].xs;
         mp.p[b].ys = io[b].ys;
+        mp.p[b].mask_src = io[b].mask_src;
+        mp.p[b].mask_slope = io[b].mask_slope;
         mp.p[b].zeros = h->d_zeros;
         mp.p[b].slope_out = slope_out;
         mp.p[b].cout_real = Lb.cout_pad;
@@ -1181,7 +1204,7 @@ static bool tap_wanted(const hificar_handle* h, const std::string& name) { retur
 static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, int64_t c_cstride, const float* prev,
                         int64_t prev_bstride, float* out, int64_t out_bstride, int B, int T, const Workspace& ws,
                         hipStream_t stream, const int32_t* seq_len = nullptr, int f0 = 0, const int2* slots = nullptr, int T_valid = -1,
-                        const Cond& cond = Cond()) {
+                        const Cond& cond = Cond(), const Tape* tp = nullptr) {
     // T: frames the launches cover; T_valid (<= T, default T): frames that exist in c / out (bucketed non-AR lengths)
     const hificar_config& cfg = h->cfg;
     if (T_valid < 0) T_valid = T;
@@ -1202,8 +1225,9 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     fp.valid = seq_len;
     fp.hop = h->hop;
     const bool f32 = h->precision == HIFICAR_PREC_F32;
-    fp.xin = f32 ? ws.xin : nullptr;
+    fp.xin = f32 ? (tp ? tp->xin : ws.xin) : nullptr;
     fp.xin_s = f32 ? nullptr : reinterpret_cast<char*>(ws.xin);
+    fp.mlp_tape = tp ? tp->mlp : nullptr;
     fp.T = T;
     fp.t_valid = T_valid;
     if (cfg.use_spk_id) {
@@ -1269,8 +1293,8 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     {
         // Activations travel between layers already activated — split rows (bf16x3) or plain fp32 rows (exact fp32), the
         // "_s" buffers — and are staged by LDS-DMA; the layer's own fp32 value only where a residual / the MRF mean needs it
-        char* xin_s = reinterpret_cast<char*>(ws.xin);
-        char* h0_s = reinterpret_cast<char*>(ws.h0);
+        char* xin_s = tp ? reinterpret_cast<char*>(tp->xin) : reinterpret_cast<char*>(ws.xin);
+        char* h0_s = tp ? tp->h0_s : reinterpret_cast<char*>(ws.h0);
         char* xt_s[3] = {reinterpret_cast<char*>(ws.xt[0]), reinterpret_cast<char*>(ws.xt[1]), reinterpret_cast<char*>(ws.xt[2])};
         {   // 2. input conv (no activation in front of it: hifigan.py:221); its consumer applies LeakyReLU(slope)
             const ConvLayer* lay[1] = {&h->input_conv};
@@ -1288,6 +1312,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 mq.x1 = nbk > 1 ? fin[1] : nullptr;
                 mq.x2 = nbk > 2 ? fin[2] : nullptr;
                 mq.out = fin[0] == ws.xt[0] ? ws.x_s[0] : xt_s[0];  // a buffer none of the inputs lives in
+                if (tp) mq.out = tp->upin_s[i];
                 mq.nin = nbk;
                 mq.C = stage_pad(cfg, i);
                 mq.rows = (long long)B * rows;
@@ -1306,7 +1331,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             // kernel activates + splits its input while staging), ping-ponging between x[j] and xt[j]; no activated copies
             // are written at all.  Otherwise: activated copies ("_s") travel next to the fp32 stream.
             static const bool f32in = !getenv("HIFICAR_PAIR_F32IN") || atoi(getenv("HIFICAR_PAIR_F32IN")) != 0;  // A/B runs
-            bool all_pairs = f32in && !tap_convs1;
+            bool all_pairs = f32in && !tap_convs1 && !tp;
             for (int j = 0; j < nbk; ++j)
                 for (int d = 0; d < cfg.n_dilations[j]; ++d) {
                     const int ci = conv_index(h, i, j, d);
@@ -1314,7 +1339,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 }
             {   // LeakyReLU + ConvTranspose1d (hifigan.py:224): fp32 u (first residual) (+ activated copy: first conv input)
                 const ConvLayer* lay[1] = {&h->ups[i]};
-                const ConvIO io[1] = {{up_in, nullptr, ws.u, all_pairs ? nullptr : ws.u_s}};
+                const ConvIO io[1] = {{up_in, nullptr, ws.u, all_pairs ? nullptr : (tp ? tp->u_s[i] : ws.u_s)}};
                 if ((rc = launch_conv(h, lay, 1, B, rows, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
             }
             rows *= cfg.upsample_scales[i];
@@ -1353,10 +1378,15 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 for (int j = 0; j < nbk; ++j) fin[j] = cur_f[j];
                 continue;
             }
-            for (int j = 0; j < nbk; ++j) fin[j] = ws.x[j];
+            // fp32 residual streams; training keeps the LAST stage's (the output conv's backward needs the MRF mean) in the tape
+            float* xres[3] = {ws.x[0], ws.x[1], ws.x[2]};
+            if (tp && i + 1 == cfg.n_stages)
+                for (int j = 0; j < 3; ++j) xres[j] = tp->fin[j];
+            for (int j = 0; j < nbk; ++j) fin[j] = xres[j];
             // activated stream of each branch: where the next conv1 reads its input.  It alternates between x_s[j] and
             // xt_s[j]: a launch never writes the buffer it (or a neighbouring tile, through the halo) reads.
-            const char* cur_s[3] = {ws.u_s, ws.u_s, ws.u_s};
+            const char* u_act = tp ? tp->u_s[i] : ws.u_s;
+            const char* cur_s[3] = {u_act, u_act, u_act};
             for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
                 const ConvLayer* l1[3];
                 const ConvLayer* l2[3];
@@ -1373,15 +1403,19 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     const int ci = conv_index(h, i, j, d);
                     l1[n] = &h->convs1[ci];
                     l2[n] = &h->convs2[ci];
-                    fuse = fuse && !tap_convs1 && pair_eligible(h, *l1[n], *l2[n], B, rows);
+                    fuse = fuse && !tap_convs1 && !tp && pair_eligible(h, *l1[n], *l2[n], B, rows);
                     const bool last = d + 1 == cfg.n_dilations[j];
                     // fused pair: cur -> the other buffer.  Layer by layer: cur -> mid -> the buffer that is not mid.
                     pair_out[n] = cur_s[j] == ws.x_s[j] ? xt_s[j] : ws.x_s[j];
                     char* mid = cur_s[j] == xt_s[j] ? ws.x_s[j] : xt_s[j];
                     lbl_out[n] = mid == xt_s[j] ? ws.x_s[j] : xt_s[j];
+                    if (tp) {  // training: unique buffers, kept for the backward pass
+                        mid = tp->xt_s[i][j][d];
+                        lbl_out[n] = tp->x_s[i][j][d];
+                    }
                     io1[n] = {cur_s[j], nullptr, tap_convs1 ? h->tap_scratch + (size_t)n * tap_se : nullptr, mid};
-                    io2[n] = {mid, d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : lbl_out[n]};
-                    iop[n] = {nullptr, cur_s[j], d == 0 ? ws.u : ws.x[j], ws.x[j], last ? nullptr : pair_out[n]};
+                    io2[n] = {mid, d == 0 ? ws.u : xres[j], xres[j], last ? nullptr : lbl_out[n]};
+                    iop[n] = {nullptr, cur_s[j], d == 0 ? ws.u : xres[j], xres[j], last ? nullptr : pair_out[n]};
                     jn[n] = j;
                     ++n;
                 }
@@ -1397,7 +1431,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     if ((rc = launch_conv(h, l2, n, B, rows, io2, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                 }
                 for (int q = 0; q < n; ++q)
-                    if ((rc = tap_block(jn[q], d, ws.x[jn[q]])) != HIFICAR_OK) return rc;
+                    if ((rc = tap_block(jn[q], d, xres[jn[q]])) != HIFICAR_OK) return rc;
                 for (int q = 0; q < n; ++q) cur_s[jn[q]] = fuse ? pair_out[q] : lbl_out[q];
             }
         }
@@ -1433,6 +1467,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     op.nin = nbk;
     op.w = h->d_out_w;
     op.bias = h->out_bias;
+    op.bias_ptr = h->d_out_bias;
     op.out = out;
     op.out_bstride = out_bstride;
     op.L = rows;
@@ -1693,3 +1728,5 @@ extern "C" int hificar_pcm16(const float* x, int16_t* y, size_t n, void* stream)
     HIP_TRY(hipGetLastError());
     return HIFICAR_OK;
 }
+
+#include "hificar_train.hip.inc"

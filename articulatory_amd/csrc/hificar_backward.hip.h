@@ -1,0 +1,463 @@
+// Backward (training) kernels of the HiFi-GAN / HiFi-CAR generator on gfx950: SURVEY.md section 8 row f1, generator part.
+//
+// The reference trains with PyTorch autograd through torch.nn.Conv1d / ConvTranspose1d / Linear (articulatory/bin/train.py:241-440,
+// articulatory/models/hifigan.py:198-239).  Per conv layer y = conv(a, W) + b with a = LeakyReLU(x):
+//   data gradient    da = conv(dy, W flipped and transposed)   -> the forward conv kernels on a second weight pack, with the
+//                                                                 LeakyReLU'(a) mask and the skip gradient fused into the output pass
+//                                                                 (ConvParams::mask_src); a ConvTranspose1d's data gradient is a plain
+//                                                                 3-tap Conv1d over its phase-major "virtual channel" rows
+//   weight gradient  dW[co, ci, k] = sum_{b,t} dy[b, t, co] * a[b, t + off_k, ci]   -> wgrad_kernel (MFMA, reduction over rows)
+//   bias gradient    db[co] = sum_{b,t} dy[b, t, co]                                -> colsum_kernel
+// plus the small ends of the network (output conv + tanh, MRF mean, feature transpose, PastFCEncoder) as VALU kernels.
+// All reductions are two-stage (partials per row split, then a fixed-order sum): deterministic, no atomics.
+#pragma once
+#include "hificar_kernels.hip.h"
+
+namespace hificar {
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: P[split][tap][g][a] = sum over the split's rows of G[row, g] * A[row + off(tap, phase(g)), a]
+//   G: upstream gradient rows (nseq, L, gpitch);  A: activated layer input rows (nseq, L, apitch); rows outside [0, L) are zero.
+// One workgroup = 4 waves in a 2 x 2 grid, each wave one 32 x 32 block (v_mfma_f32_32x32x2_f32: the row axis is the MFMA's K),
+// i.e. a 64 (g) x 64 (a) tile of one tap; the rows come in chunks of 128 through LDS, the next chunk's global loads in flight in
+// registers while the current one is multiplied.
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+    const float* g;
+    const float* a;
+    float* partial;  // [nsplit][ntaps][gpad][apad], gpad = n_gblk * 32, apad = n_ablk * 32
+    int nseq, L;
+    int gpitch, apitch;
+    int n_gblk, n_ablk;
+    int ntaps;
+    int tap_step;
+    int tap_off0[kMaxPhase];
+    int nb32_per_phase;  // g blocks per phase (ConvTranspose1d: output phase r owns blocks [r * nb32_per_phase, ...))
+    int chunks_per_seq;  // ceil(L / 128)
+    int nsplit;
+    int g_per_tile;      // 32-blocks of g per workgroup tile: 2, or 1 when a 64-wide tile would straddle two phases (odd nb32_per_phase)
+};
+
+constexpr int kWgR = 128;  // rows per chunk
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float gs[kWgR][64];
+    __shared__ __attribute__((aligned(16))) float as[kWgR][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hf = lane >> 5;
+    const int gpt = p.g_per_tile;
+    const int gt_n = (p.n_gblk + gpt - 1) / gpt, at_n = (p.n_ablk + 1) >> 1;
+    int tile = blockIdx.x;
+    const int at = tile % at_n;
+    tile /= at_n;
+    const int gt = tile % gt_n;
+    const int tap = tile / gt_n;
+    const int split = blockIdx.y;
+    const int gblk = gt * gpt + (wave >> 1), ablk = at * 2 + (wave & 1);
+    const bool active = (wave >> 1) < gpt && gblk < p.n_gblk && ablk < p.n_ablk;
+    // the g blocks of a tile share one tap offset (the staged A rows are shifted by it): g_per_tile = 1 when phases are 32 wide
+    const int phase = (gt * gpt) / p.nb32_per_phase;
+    const int off = p.tap_off0[phase] + tap * p.tap_step;
+    const int nchunks = p.nseq * p.chunks_per_seq;
+    const int c_lo = (int)((long long)nchunks * split / p.nsplit), c_hi = (int)((long long)nchunks * (split + 1) / p.nsplit);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // staging: thread -> 16 float4 per operand tile of 128 rows x 64 channels (2048 float4): index q * 256 + tid
+    f32x4 gr[8], ar[8];
+    auto fetch = [&](int c) {
+        const int seq = c / p.chunks_per_seq;
+        const int t0 = (c - seq * p.chunks_per_seq) * kWgR;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = q * 256 + tid;  // float4 index: row = idx / 16, channel group = idx % 16
+            const int row = idx >> 4, c4 = (idx & 15) * 4;
+            const int tg = t0 + row, ta = tg + off;
+            f32x4 vg = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
+            const int gch = gt * gpt * 32 + c4, ach = at * 64 + c4;
+            if (tg < p.L && c4 < gpt * 32 && gch < p.gpitch) vg = *reinterpret_cast<const f32x4*>(p.g + ((size_t)seq * p.L + tg) * p.gpitch + gch);
+            if (tg < p.L && ta >= 0 && ta < p.L && ach < p.apitch) va = *reinterpret_cast<const f32x4*>(p.a + ((size_t)seq * p.L + ta) * p.apitch + ach);
+            gr[q] = vg;
+            ar[q] = va;
+        }
+    };
+    if (c_lo < c_hi) fetch(c_lo);
+    for (int c = c_lo; c < c_hi; ++c) {
+        __syncthreads();  // the previous chunk's reads are done
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = q * 256 + tid;
+            const int row = idx >> 4, c4 = (idx & 15) * 4;
+            *reinterpret_cast<f32x4*>(&gs[row][c4]) = gr[q];
+            *reinterpret_cast<f32x4*>(&as[row][c4]) = ar[q];
+        }
+        __syncthreads();
+        if (c + 1 < c_hi) fetch(c + 1);  // in flight while this chunk is multiplied
+        if (active) {
+            const int gc = (wave >> 1) * 32 + li, ac = (wave & 1) * 32 + li;
+#pragma unroll 8
+            for (int k = 0; k < kWgR; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[k + hf][gc], as[k + hf][ac], acc, 0, 0, 0);
+        }
+    }
+    if (active) {
+        const int gpad = p.n_gblk * 32, apad = p.n_ablk * 32;
+        float* dst = p.partial + (((size_t)split * p.ntaps + tap) * gpad + gblk * 32) * apad + ablk * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hf) * apad] = acc[r];
+    }
+}
+
+// dW in the reference's layout from the partials, summed over the splits in a fixed order.
+//   Conv1d          : dst[(co * cin + ci) * K + k]     g = co, a = ci, k = tap
+//   ConvTranspose1d : dst[(ci * cout + co) * K + k]    g = r * cout_pad + co (phase-major), a = ci, k = tap_k[r][tap] (< 0: no such weight)
+struct WreduceParams {
+    const float* partial;
+    float* dst;
+    int nsplit, ntaps, gpad, apad;
+    int cout, cin, K;
+    int transposed, n_phase, cout_pad;
+    int tap_k[kMaxPhase][kMaxTaps];
+    int flip;  // 0
+};
+
+__global__ __launch_bounds__(256) void wreduce_kernel(const WreduceParams p) {
+    const long long total = (long long)p.ntaps * p.gpad * p.apad;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int a = (int)(i % p.apad);
+        const long long r = i / p.apad;
+        const int g = (int)(r % p.gpad), tap = (int)(r / p.gpad);
+        if (a >= p.cin) continue;
+        int co = g, k = tap;
+        if (p.transposed) {
+            const int ph = g / p.cout_pad;
+            co = g - ph * p.cout_pad;
+            if (ph >= p.n_phase) continue;
+            k = p.tap_k[ph][tap];
+            if (k < 0) continue;
+        }
+        if (co >= p.cout) continue;
+        float s = 0.f;
+        for (int sp = 0; sp < p.nsplit; ++sp) s += p.partial[(size_t)sp * total + i];
+        const size_t d = p.transposed ? ((size_t)a * p.cout + co) * p.K + k : ((size_t)co * p.cin + a) * p.K + k;
+        p.dst[d] = s;
+    }
+}
+
+// Column sums of gradient rows (bias gradients): partial[split][ch] = sum of the split's rows of g[row, ch]
+struct ColsumParams {
+    const float* g;
+    float* partial;  // [nsplit][pitch]
+    long long rows;
+    int pitch;
+    int nsplit;
+};
+
+__global__ __launch_bounds__(256) void colsum_kernel(const ColsumParams p) {
+    __shared__ float red[4][64];
+    const int ch = blockIdx.x * 64 + (threadIdx.x & 63), rs = threadIdx.x >> 6;
+    const long long r_lo = p.rows * blockIdx.y / p.nsplit, r_hi = p.rows * (blockIdx.y + 1) / p.nsplit;
+    float s = 0.f;
+    if (ch < p.pitch)
+        for (long long r = r_lo + rs; r < r_hi; r += 4) s += p.g[(size_t)r * p.pitch + ch];
+    red[rs][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rs == 0 && ch < p.pitch) p.partial[(size_t)blockIdx.y * p.pitch + ch] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// db[co] = sum over splits (and over the phases of a ConvTranspose1d) of the column sums
+struct BreduceParams {
+    const float* partial;
+    float* dst;
+    int nsplit, pitch, cout, cout_pad, n_phase;
+};
+
+__global__ __launch_bounds__(256) void breduce_kernel(const BreduceParams p) {
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= p.cout) return;
+    float s = 0.f;
+    for (int ph = 0; ph < p.n_phase; ++ph)
+        for (int sp = 0; sp < p.nsplit; ++sp) s += p.partial[(size_t)sp * p.pitch + ph * p.cout_pad + co];
+    p.dst[co] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output conv + tanh backward (hifigan.py:146-159, 231).  Forward: s = bias + sum_k sum_c lrelu_0.01(m[t + k - pad, c]) * w[k][c],
+// out = tanh(s), m = MRF mean of the last stage.  ds = dout * (1 - out^2).
+//   outconv_bwd_data   : dm[t, c] = lrelu'(m[t, c]) * sum_k ds[t - k + pad] * w[k][c] / nin   (gradient of EACH ResBlock output)
+//   outconv_bwd_weight : partial[wg][k * C + c] = sum_t ds[t] * lrelu(m[t + k - pad, c]), partial[wg][K * C] = sum_t ds[t]
+// ------------------------------------------------------------------------------------------------
+struct OutBwdParams {
+    const float* x0;
+    const float* x1;
+    const float* x2;
+    int nin;
+    const float* w;     // [k][Cp]
+    const float* dout;  // (B, L) gradient of the waveform, row pitch dout_bstride
+    const float* out;   // (B, L) forward waveform (for tanh')
+    int64_t io_bstride;
+    float* dm;          // (B, L, Cp): gradient of each ResBlock output of the last stage (the same for all nin)
+    float* partial;     // [gridDim.x * gridDim.y][K * Cp + 1]
+    int L, Cp, K;
+    float slope;
+    int use_tanh;
+};
+
+__device__ __forceinline__ float mrf_mean_at(const OutBwdParams& p, size_t off) {
+    float v = p.x0[off];
+    if (p.nin == 2) v = (v + p.x1[off]) / 2.0f;
+    else if (p.nin == 3) v = ((v + p.x1[off]) + p.x2[off]) / 3.0f;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void outconv_bwd_data_kernel(const OutBwdParams p) {
+    // one thread = one (row, 4 channels); ds of the K neighbouring samples recomputed on the fly (K = 7 scalar loads, cached)
+    const int c4n = p.Cp >> 2;
+    const long long total = (long long)p.L * c4n;
+    const int seq = blockIdx.y;
+    const int pad = (p.K - 1) / 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i / c4n), c = (int)(i - (long long)t * c4n) * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < p.K; ++k) {
+            const int ts = t - k + pad;
+            if (ts < 0 || ts >= p.L) continue;
+            const float o = p.out[(size_t)seq * p.io_bstride + ts];
+            const float ds = p.dout[(size_t)seq * p.io_bstride + ts] * (p.use_tanh ? 1.f - o * o : 1.f);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + (size_t)k * p.Cp + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(ds, wv[e], acc[e]);
+        }
+        const size_t off = ((size_t)seq * p.L + t) * p.Cp + c;
+        f32x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float m = mrf_mean_at(p, off + e);
+            o4[e] = acc[e] * (m > 0.f ? 1.f : p.slope) / (float)p.nin;
+        }
+        *reinterpret_cast<f32x4*>(p.dm + off) = o4;
+    }
+}
+
+__global__ __launch_bounds__(256) void outconv_bwd_weight_kernel(const OutBwdParams p) {
+    // workgroup (x, seq) owns rows [x * rows_per, ...); thread = one (k, c) weight (K * Cp <= 256 * n) accumulates over the rows
+    extern __shared__ float sds[];  // ds of the workgroup's rows
+    const int seq = blockIdx.y;
+    const int rows_per = (p.L + gridDim.x - 1) / gridDim.x;
+    const int t0 = blockIdx.x * rows_per, t1 = min(t0 + rows_per, p.L);
+    const int pad = (p.K - 1) / 2;
+    for (int t = t0 + threadIdx.x; t < t1; t += 256) {
+        const float o = p.out[(size_t)seq * p.io_bstride + t];
+        sds[t - t0] = p.dout[(size_t)seq * p.io_bstride + t] * (p.use_tanh ? 1.f - o * o : 1.f);
+    }
+    __syncthreads();
+    float* dst = p.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (p.K * p.Cp + 1);
+    for (int wi = threadIdx.x; wi < p.K * p.Cp; wi += 256) {
+        const int k = wi / p.Cp, c = wi - k * p.Cp;
+        float s = 0.f;
+        for (int t = t0; t < t1; ++t) {
+            const int ta = t + k - pad;
+            if (ta < 0 || ta >= p.L) continue;
+            const float m = mrf_mean_at(p, ((size_t)seq * p.L + ta) * p.Cp + c);
+            s = fmaf(sds[t - t0], m > 0.f ? m : m * p.slope, s);
+        }
+        dst[wi] = s;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int t = t0; t < t1; ++t) s += sds[t - t0];
+        dst[p.K * p.Cp] = s;
+    }
+}
+
+// generic fixed-order sum of n partial vectors: dst[i] = sum_j partial[j * stride + i]  (+ optional (k, c) -> (c, k) transpose for the
+// output conv weight, whose reference layout is (1, C, K))
+struct VreduceParams {
+    const float* partial;
+    float* dst;
+    int n, stride, len;
+    int tr_K, tr_C, tr_Cp;  // tr_K > 0: i = k * Cp + c -> dst[c * K + k] for c < C
+};
+
+__global__ __launch_bounds__(256) void vreduce_kernel(const VreduceParams p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.len) return;
+    float s = 0.f;
+    for (int j = 0; j < p.n; ++j) s += p.partial[(size_t)j * p.stride + i];
+    if (p.tr_K > 0) {
+        const int k = i / p.tr_Cp, c = i - k * p.tr_Cp;
+        if (c < p.tr_C) p.dst[(size_t)c * p.tr_K + k] = s;
+    } else {
+        p.dst[i] = s;
+    }
+}
+
+// out = a + b + c (the three ResBlock branches' gradients with respect to the upsample output)
+__global__ __launch_bounds__(256) void add3_kernel(const float* a, const float* b, const float* c, float* out, long long n4, int nin) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(a)[i];
+        if (nin >= 2) {
+            const f32x4 w = reinterpret_cast<const f32x4*>(b)[i];
+            v = v + w;
+        }
+        if (nin >= 3) {
+            const f32x4 w = reinterpret_cast<const f32x4*>(c)[i];
+            v = v + w;
+        }
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+// Gradient of the assembled input rows -> gradient of the features (B, cf, T) and of the AR features (B, ar_out) = sum over t
+struct XinGradParams {
+    const float* dxin;  // (B, T, cin_pad)
+    float* dc;          // (B, cf, T) or null
+    float* dfeat;       // (B, ar_out) or null
+    int T, cf, ar_out, cin_pad;
+};
+
+__global__ __launch_bounds__(256) void xin_grad_kernel(const XinGradParams p) {
+    const int b = blockIdx.x;
+    const float* src = p.dxin + (size_t)b * p.T * p.cin_pad;
+    if (p.dc)
+        for (int i = threadIdx.x; i < p.cf * p.T; i += 256) {
+            const int ch = i / p.T, t = i - ch * p.T;
+            p.dc[(size_t)b * p.cf * p.T + i] = src[(size_t)t * p.cin_pad + ch];
+        }
+    if (p.dfeat)
+        for (int j = threadIdx.x; j < p.ar_out; j += 256) {
+            float s = 0.f;
+            for (int t = 0; t < p.T; ++t) s += src[(size_t)t * p.cin_pad + p.cf + j];
+            p.dfeat[(size_t)b * p.ar_out + j] = s;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PastFCEncoder backward (pytorch_layers.py:438-460): h0 = ar, h_{l+1} = lrelu_0.1(W_l h_l + b_l) for l < 4, feat = W_4 h_4 + b_4.
+//   mlp_bwd_delta : one workgroup per utterance: delta_4 = dfeat; delta_{l-1} = (W_l^T delta_l) * lrelu'(h_l); also dar = W_0^T delta_0
+//   mlp_bwd_weight: dW_l[o, i] = sum_b delta_l[b, o] * h_l[b, i];  db_l[o] = sum_b delta_l[b, o]
+// h_l (l = 0..4; h_0 = the AR context) come from the forward's tape: (B, 5, 1024) floats; deltas go to (B, 5, 512).
+// ------------------------------------------------------------------------------------------------
+struct MlpBwdParams {
+    const float* h;      // (B, 5, 1024): inputs of the five Linear layers
+    const float* dfeat;  // (B, ar_out)
+    float* delta;        // (B, 5, 512): gradient of each Linear's output
+    float* dar;          // (B, ar_input) or null
+    const float* wt[5];  // transposed weights (in, out), as the forward uses them
+    int dims[6];         // ar_input, hidden x 4, ar_output
+    float* dW[5];        // reference layout (out, in)
+    float* db[5];
+    int B;
+};
+
+__global__ __launch_bounds__(256) void mlp_bwd_delta_kernel(const MlpBwdParams p) {
+    __shared__ float d[2][512];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int cur = 0;
+    for (int j = tid; j < p.dims[5]; j += 256) {
+        const float v = p.dfeat[(size_t)b * p.dims[5] + j];
+        d[0][j] = v;
+        p.delta[((size_t)b * 5 + 4) * 512 + j] = v;
+    }
+    __syncthreads();
+    for (int l = 4; l >= 0; --l) {
+        const int din = p.dims[l], dout = p.dims[l + 1];
+        const float* wt = p.wt[l];  // (din, dout)
+        const float* hl = p.h + ((size_t)b * 5 + l) * 1024;
+        for (int i = tid; i < din; i += 256) {
+            float s = 0.f;
+            for (int o = 0; o < dout; ++o) s = fmaf(wt[(size_t)i * dout + o], d[cur][o], s);
+            if (l > 0) {
+                s *= hl[i] > 0.f ? 1.f : 0.1f;  // h_l = lrelu(pre): same sign as the pre-activation
+                d[cur ^ 1][i] = s;
+                p.delta[((size_t)b * 5 + (l - 1)) * 512 + i] = s;
+            } else if (p.dar) {
+                p.dar[(size_t)b * din + i] = s;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void mlp_bwd_weight_kernel(const MlpBwdParams p) {
+    const int l = blockIdx.y;
+    const int din = p.dims[l], dout = p.dims[l + 1];
+    const int n = din * dout;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n + dout; i += gridDim.x * 256) {
+        float s = 0.f;
+        if (i < n) {
+            const int o = i / din, ii = i - o * din;
+            for (int b = 0; b < p.B; ++b) s = fmaf(p.delta[((size_t)b * 5 + l) * 512 + o], p.h[((size_t)b * 5 + l) * 1024 + ii], s);
+            p.dW[l][i] = s;
+        } else {
+            const int o = i - n;
+            for (int b = 0; b < p.B; ++b) s += p.delta[((size_t)b * 5 + l) * 512 + o];
+            p.db[l][o] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side weight packing (training: weights live on the device and change every step).  One thread per packed fp32 element of the
+// [n_block32][chunk][tap][c16][half][lane][4] fragment layout (see pack_w32 in hificar.hip), reading the reference-layout source.
+//   mode 0  Conv1d forward            src (cout, cin, K)   w'[co][ci][k] = W[co][ci][k]
+//   mode 1  ConvTranspose1d forward   src (cin, cout, K)   phase-major virtual output channels, taps through tap_k
+//   mode 2  Conv1d data gradient      a Conv1d (cin -> its input channels): w'[co' = ci][ci' = co][k'] = W[co][ci][K - 1 - k']
+//   mode 3  ConvTranspose1d data gradient as a Conv1d over the phase-major virtual channels (r, co) of dy:
+//           w'[co' = ci][ci' = r * cout_pad + co][j] = scale * W[ci][co][r + s * (jmin + j) + pad] when that tap exists
+// ------------------------------------------------------------------------------------------------
+struct PackParams {
+    const float* src;
+    float* dst;
+    long long total;   // packed elements
+    int mode;
+    int n_blocks32, nchunk, ntaps, nc16, chunk;
+    int nb32_per_phase;
+    int cin, cout, K;            // of the SOURCE weight (reference layout)
+    int cin_pack, cout_pack;     // real (unpadded) input / output channels of the packed layer
+    int stride, pad, cout_pad, jmin;
+    float scale;
+    int tap_k[kMaxPhase][kMaxTaps];
+};
+
+__global__ __launch_bounds__(256) void pack_w32_kernel(const PackParams p) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        long long r = i;
+        const int j = (int)(r & 3);
+        r >>= 2;
+        const int lane = (int)(r & 63);
+        r >>= 6;
+        const int v = (int)(r & 1);
+        r >>= 1;
+        const int u = (int)(r % p.nc16);
+        r /= p.nc16;
+        const int t = (int)(r % p.ntaps);
+        r /= p.ntaps;
+        const int c = (int)(r % p.nchunk);
+        const int nb = (int)(r / p.nchunk);
+        float val = 0.f;
+        if (nb < p.n_blocks32) {
+            const int g = lane >> 5, n = lane & 31;
+            const int phase = nb / p.nb32_per_phase;
+            const int co = (nb % p.nb32_per_phase) * 32 + n;     // output channel of the packed layer (within its phase)
+            const int ci = c * p.chunk + u * 16 + 8 * v + 4 * g + j;  // input channel of the packed layer
+            if (co < p.cout_pack && ci < p.cin_pack) {
+                if (p.mode == 0) {
+                    val = p.src[((size_t)co * p.cin + ci) * p.K + t];
+                } else if (p.mode == 1) {
+                    const int k = p.tap_k[phase][t];
+                    if (k >= 0) val = p.src[((size_t)ci * p.cout + co) * p.K + k];
+                } else if (p.mode == 2) {
+                    val = p.src[((size_t)ci * p.cin + co) * p.K + (p.K - 1 - t)];
+                } else {
+                    const int rr = ci / p.cout_pad, cc = ci - rr * p.cout_pad;  // virtual input channel -> (phase r, real co)
+                    const int k = rr + p.stride * (p.jmin + t) + p.pad;
+                    if (rr < p.stride && cc < p.cout && k >= 0 && k < p.K) val = p.scale * p.src[((size_t)co * p.cout + cc) * p.K + k];
+                }
+            }
+        }
+        p.dst[i] = val;
+    }
+}
+
+}  // namespace hificar

@@ -39,6 +39,9 @@ struct ConvParams {
     const bf16x8* w16;  // MFMA weight fragments [n_block32][chunk][tap][c16][hi|lo or half][lane], 16 B each (bf16 pairs or fp32)
     const float* bias;  // [cout_total] (never null; zeros when the layer has no bias)
     const float* res;   // fp32 residual, same layout as y, or null
+    const float* mask_src;  // backward (dgrad) launches: rows in y's layout; the result is scaled by LeakyReLU'(mask_src) = (m > 0 ? 1 : mask_slope)
+                            // BEFORE the residual is added (dx = dx_skip + act'(x) * dgrad); null in every forward launch
+    float mask_slope;
     float* y;           // fp32 output of the layer itself (pre-activation), or null when only the activated copy is consumed
     const float* xf;    // pair kernel only: fp32 PRE-activation input rows (C floats per row); LeakyReLU(slope_in) + split are
                         // then applied while staging and xs is null (narrow stages: the producer writes no activated copy)
@@ -286,14 +289,20 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         const int split_off = ph_row * p.cout_real * 4 + (vc - ph_row * p.cout_real) * 2;
         constexpr int UB = 4;  // rows in flight per thread: LDS reads and residual loads are issued before any is used
         for (int r0 = 0; r0 < rows; r0 += rpp * UB) {
-            f32x4 v0[UB], v1[UB], q0[UB], q1[UB];
+            f32x4 v0[UB], v1[UB], q0[UB], q1[UB], m0[UB], m1[UB];
 #pragma unroll
             for (int q = 0; q < UB; ++q) {
                 const int row_l = r0 + q * rpp + rr;
                 v0[q] = v1[q] = q0[q] = q1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                m0[q] = m1[q] = f32x4{1.f, 1.f, 1.f, 1.f};
                 if (lane_on && row_l < rows) {
                     v0[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8]);
                     v1[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c8 + 4]);
+                    if (p.mask_src) {
+                        const float* mp_ = p.mask_src + (seq_base + T.t0 + row_l) * p.cout_total + vc;
+                        m0[q] = *reinterpret_cast<const f32x4*>(mp_);
+                        m1[q] = *reinterpret_cast<const f32x4*>(mp_ + 4);
+                    }
                     if constexpr (KS == 4) {  // (p0 + p1) + (p2 + p3)
                         const f32x4 a0 = *reinterpret_cast<const f32x4*>(&O[(TM + row_l) * OP + c8]);
                         const f32x4 a1 = *reinterpret_cast<const f32x4*>(&O[(TM + row_l) * OP + c8 + 4]);
@@ -317,10 +326,18 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                 if (lane_on && row_l < rows) {
                     const size_t row = seq_base + T.t0 + row_l;
                     float o[8];
+                    if (p.mask_src) {  // backward: act'(x) * (dgrad + 0) + skip gradient
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o[e] = (v0[q][e] + bv0[e]) + q0[q][e];
-                        o[4 + e] = (v1[q][e] + bv1[e]) + q1[q][e];
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = (v0[q][e] + bv0[e]) * (m0[q][e] > 0.f ? 1.f : p.mask_slope) + q0[q][e];
+                            o[4 + e] = (v1[q][e] + bv1[e]) * (m1[q][e] > 0.f ? 1.f : p.mask_slope) + q1[q][e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = (v0[q][e] + bv0[e]) + q0[q][e];
+                            o[4 + e] = (v1[q][e] + bv1[e]) + q1[q][e];
+                        }
                     }
                     if (p.y) {
                         float* yp = p.y + row * p.cout_total + vc;
@@ -1335,6 +1352,7 @@ struct FrontParams {
     int ph_stride;
     const float* ph_emb;  // (num_ph, ph_e)
     int ph_e;
+    float* mlp_tape;      // training: (B, 5, 1024) inputs of the five Linear layers (backward needs them), or null
 };
 
 constexpr int kFrontThreads = 1024;
@@ -1354,7 +1372,11 @@ __global__ __launch_bounds__(kFrontThreads) void front_kernel(const FrontParams 
             const int2 sl = p.slots[b];
             prevp = sl.y > 0 ? p.prev + (size_t)sl.x * p.prev_bstride + (size_t)p.hop * sl.y - p.ar_input : nullptr;
         }
-        for (int i = tid; i < p.ar_input; i += NT) act[0][i] = prevp ? prevp[i] : 0.f;
+        for (int i = tid; i < p.ar_input; i += NT) {
+            const float v = prevp ? prevp[i] : 0.f;
+            act[0][i] = v;
+            if (p.mlp_tape) p.mlp_tape[((size_t)b * 5) * 1024 + i] = v;
+        }
         __syncthreads();
         int din = p.ar_input;
         for (int layer = 0; layer < 5; ++layer) {
@@ -1389,7 +1411,9 @@ __global__ __launch_bounds__(kFrontThreads) void front_kernel(const FrontParams 
                 float v = p.bs[layer][j];
 #pragma unroll
                 for (int q = 0; q < NW; ++q) v += part[q][j];
-                act[cur ^ 1][j] = layer < 4 ? lrelu(v, 0.1f) : v;
+                const float a = layer < 4 ? lrelu(v, 0.1f) : v;
+                act[cur ^ 1][j] = a;
+                if (p.mlp_tape && layer < 4) p.mlp_tape[((size_t)b * 5 + layer + 1) * 1024 + j] = a;
             }
             __syncthreads();
             cur ^= 1;
@@ -1447,6 +1471,7 @@ struct OutConvParams {
     int nin;           // inputs averaged (1..3), as in ConvParams
     const float* w;    // [k][C]
     float bias;
+    const float* bias_ptr;  // training: the bias lives on the device (overrides `bias`)
     float* out;
     int64_t out_bstride;
     int L;             // samples per sequence
@@ -1504,7 +1529,7 @@ __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p)
     __syncthreads();
     const int t = t0 + tid;
     if (tid < p.TR && t < Ls) {
-        float s = p.bias;
+        float s = p.bias_ptr ? *p.bias_ptr : p.bias;
         for (int k = 0; k < p.K; ++k) {
             const float* xr = &smem[(tid + k) * P];
             const float* wk = &ws[k * p.C];

@@ -12,8 +12,8 @@ What differs is where the arithmetic runs: this module owns the parameters only.
 device pointers to ``libhificar.so`` (hand-written HIP kernels for gfx950, C ABI in
 include/hificar.h).  There is no PyTorch-operator implementation of the network in this package and
 no CPU fallback: calling ``forward`` on a CPU tensor, without a GPU, or without the built library
-raises.  Training (autograd through the generator) is scope row f1 in SURVEY.md §8 and raises
-NotImplementedError.
+raises.  Under autograd (training) ``forward`` is an autograd node whose forward AND backward run in
+libhificar (hificar_forward_train / hificar_backward); the weight-norm re-parametrisation stays in PyTorch's graph.
 """
 
 import ctypes
@@ -108,8 +108,70 @@ class _PastFCParams(torch.nn.Module):
         self.model = torch.nn.Sequential(*mods)
 
 
+class _GeneratorFunction(torch.autograd.Function):
+    """Autograd node of the native generator: forward = hificar_forward_train (keeps a tape), backward = hificar_backward.
+
+    Inputs after (module, c, ar, names) are the FOLDED parameters (w = v * g / ||v|| computed by torch on the device), so the
+    weight-norm re-parametrisation and its gradient stay in PyTorch's graph (hifigan.py:268-278) while every convolution,
+    activation and the PastFCEncoder — forward and backward — run in libhificar."""
+
+    @staticmethod
+    def forward(ctx, module, c, ar, names, *weights):
+        lib, handle = module._lib, module._handle
+        B, _, T = c.shape
+        dev = c.device
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        with torch.cuda.device(dev):
+            for name, w in zip(names, weights):
+                w = w.detach().to(torch.float32).contiguous()
+                _native.check(lib.hificar_set_weight_device(handle, name.encode(), w.data_ptr(), stream), "hificar_set_weight_device")
+            tape = torch.empty(lib.hificar_tape_bytes(handle, B, T) + 256, dtype=torch.uint8, device=dev)
+            toff = (-tape.data_ptr()) % 256
+            out = torch.empty((B, 1, T * module.hop), dtype=torch.float32, device=dev)
+            ws_ptr, ws_bytes = module._workspace(B, T)
+            rc = lib.hificar_forward_train(handle, c.data_ptr(), ar.data_ptr() if ar is not None else None, out.data_ptr(), B, T,
+                                           ws_ptr, ws_bytes, tape.data_ptr() + toff, tape.numel() - toff, stream)
+        _native.check(rc, "hificar_forward_train")
+        ctx.module, ctx.names, ctx.tape, ctx.toff, ctx.BT = module, names, tape, toff, (B, T)
+        ctx.shapes = [tuple(w.shape) for w in weights]
+        ctx.has_ar = ar is not None
+        ctx.save_for_backward(out)
+        ctx.mark_non_differentiable()
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        module = ctx.module
+        lib, handle = module._lib, module._handle
+        (out,) = ctx.saved_tensors
+        B, T = ctx.BT
+        dev = out.device
+        p = module._params
+        dout = dout.to(torch.float32).contiguous()
+        need_c, need_ar = ctx.needs_input_grad[1], ctx.has_ar and ctx.needs_input_grad[2]
+        cf = p["in_channels"] - (p["ar_output"] if module.use_ar else 0)
+        dc = torch.empty((B, cf, T), dtype=torch.float32, device=dev) if need_c else None
+        dar = torch.empty((B, 1, p["ar_input"]), dtype=torch.float32, device=dev) if need_ar else None
+        with torch.cuda.device(dev):
+            grads = torch.zeros(int(lib.hificar_grad_floats(handle)), dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.hificar_backward_workspace_bytes(handle, B, T) + 256, dtype=torch.uint8, device=dev)
+            woff = (-ws.data_ptr()) % 256
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = lib.hificar_backward(handle, dout.data_ptr(), out.data_ptr(), B, T, ctx.tape.data_ptr() + ctx.toff,
+                                      ctx.tape.numel() - ctx.toff, grads.data_ptr(), dc.data_ptr() if dc is not None else None,
+                                      dar.data_ptr() if dar is not None else None, ws.data_ptr() + woff, ws.numel() - woff, stream)
+        _native.check(rc, "hificar_backward")
+        layout = module._grad_layout()
+        gw = []
+        for name, shape in zip(ctx.names, ctx.shapes):
+            off, n = layout[name]
+            gw.append(grads[off:off + n].view(shape))
+        ctx.tape = None
+        return (None, dc, dar, None, *gw)
+
+
 class HiFiGANGenerator(torch.nn.Module):
-    """HiFiGAN generator module (MI355X-native forward)."""
+    """HiFiGAN generator module (MI355X-native forward and backward)."""
 
     def __init__(
         self,
@@ -302,6 +364,7 @@ class HiFiGANGenerator(torch.nn.Module):
             self._lib.hificar_destroy(h)
         self._handle = None
         self._workspaces = {}
+        self._grad_slots = None
 
     def __del__(self):
         try:
@@ -323,9 +386,27 @@ class HiFiGANGenerator(torch.nn.Module):
     def _device(self):
         return next(self.parameters()).device
 
+    def _param_signature(self):
+        return tuple(p._version for p in self.parameters())
+
     def _native_handle(self):
         if self._handle is not None:
-            return self._handle
+            if getattr(self, "_param_sig", None) != self._param_signature():
+                # parameters were updated in place since the weights were handed over (optimizer.step(), p.data.copy_): re-send them
+                if self.precision == "f32" and not (self.use_spk_id or self.use_ph or self.use_ph_loss):
+                    names, tensors = self._folded_parameters()
+                    dev = self._device()
+                    with torch.no_grad(), torch.cuda.device(dev):
+                        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                        for name, w in zip(names, tensors):
+                            w = w.detach().to(torch.float32).contiguous()
+                            _native.check(self._lib.hificar_set_weight_device(self._handle, name.encode(), w.data_ptr(), stream),
+                                          "hificar_set_weight_device")
+                    self._param_sig = self._param_signature()
+                    return self._handle
+                self._invalidate()
+            else:
+                return self._handle
         dev = self._device()
         if dev.type != "cuda":
             raise RuntimeError(
@@ -347,6 +428,7 @@ class HiFiGANGenerator(torch.nn.Module):
                 lib.hificar_destroy(handle)
                 raise
         self._handle = handle
+        self._param_sig = self._param_signature()
         return handle
 
     def _workspace(self, B, T):
@@ -414,11 +496,51 @@ class HiFiGANGenerator(torch.nn.Module):
         return out, taps
 
     # ------------------------------------------------------------------ forward paths
+    def _grad_layout(self):
+        """{folded parameter name: (offset, numel)} inside the flat gradient buffer hificar_backward fills."""
+        if getattr(self, "_grad_slots", None) is None:
+            n = self._lib.hificar_grad_count(self._handle)
+            if n < 0:
+                _native.check(-1, "hificar_grad_count")
+            slots = {}
+            name = ctypes.create_string_buffer(96)
+            off, cnt = ctypes.c_int64(), ctypes.c_int64()
+            for i in range(n):
+                _native.check(self._lib.hificar_grad_info(self._handle, i, name, ctypes.byref(off), ctypes.byref(cnt)), "hificar_grad_info")
+                slots[name.value.decode()] = (off.value, cnt.value)
+            self._grad_slots = slots
+        return self._grad_slots
+
+    def _folded_parameters(self):
+        """(names, tensors): every parameter in the folded form the C ABI consumes, as DIFFERENTIABLE functions of this module's
+        parameters (weight-normed convs: w = v * (g / ||v||), torch.nn.utils.weight_norm(dim=0) semantics)."""
+        names, tensors = [], []
+        for name, m in self.named_modules():
+            if isinstance(m, _ConvParams):
+                names.append(name + ".weight")
+                tensors.append(_fold(m.weight_v, m.weight_g) if m.has_weight_norm else m.weight)
+                if m.bias is not None:
+                    names.append(name + ".bias")
+                    tensors.append(m.bias)
+            elif isinstance(m, torch.nn.Linear):
+                names += [name + ".weight", name + ".bias"]
+                tensors += [m.weight, m.bias]
+        return names, tensors
+
+    def _forward_autograd(self, c, ar):
+        """Training-mode forward (train.py:276,398: y_ = generator(x, ar=ar) under autograd)."""
+        if self.use_spk_id or self.use_ph or self.use_ph_loss:
+            raise NotImplementedError("autograd through the speaker / phoneme conditioned generator is not built (SURVEY.md §8 f1)")
+        if self.precision != "f32":
+            raise RuntimeError("training runs in the exact-fp32 arithmetic: construct with precision='f32'")
+        if self._handle is None:
+            self._native_handle()
+        names, tensors = self._folded_parameters()
+        out = _GeneratorFunction.apply(self, c, ar, tuple(names), *tensors)
+        self._param_sig = self._param_signature()  # the forward above handed the current weights over
+        return out
+
     def _check_input(self, c):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError(
-                "HiFiGANGenerator.forward under autograd/training is not built (SURVEY.md §8 row f1); "
-                "call .eval() and wrap in torch.no_grad()")
         if not c.is_cuda:
             raise RuntimeError("HiFiGANGenerator.forward needs a CUDA/HIP tensor; there is no CPU fallback")
         cf = (self._params["in_channels"] - (self._params["ar_output"] if self.use_ar else 0)
@@ -454,6 +576,11 @@ class HiFiGANGenerator(torch.nn.Module):
             ar = ar.to(device=c.device, dtype=torch.float32).contiguous()
         c = c.to(torch.float32).contiguous()
         B, _, T = c.shape
+        if torch.is_grad_enabled() and (c.requires_grad or (ar is not None and ar.requires_grad)
+                                        or any(p.requires_grad for p in self.parameters())):
+            if lengths is not None:
+                raise NotImplementedError("autograd with ragged lengths is not built")
+            return self._forward_autograd(c, ar)
         if self.use_spk_id:
             if spk_id is None or spk_id.numel() != B:
                 raise RuntimeError("use_spk_id=True: forward() needs spk_id=(B,) speaker indices")

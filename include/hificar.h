@@ -185,6 +185,35 @@ typedef struct hificar_kernel_stat {
 int hificar_profile_begin(hificar_handle* h);
 int hificar_profile_end(hificar_handle* h, hificar_kernel_stat* stats, int max_stats, int* n_stats);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Training: the generator half of the reference's train step (articulatory/bin/train.py:241-440: y_ = generator(x, ar=ar) under
+ * autograd, gen_loss.backward()).  The reference has no native boundary here either (PyTorch autograd through torch.nn modules);
+ * these entry points stand in for  HiFiGANGenerator.forward  in training mode and the autograd graph behind it.
+ * Exact-fp32 arithmetic only.  The speaker / phoneme conditioned variants have no backward pass yet.
+ *
+ *   hificar_set_weight_device  one FOLDED parameter (name / layout as hificar_set_weight) from DEVICE memory, repacked on the
+ *                              device on `stream` — the weights of a model in training live on the device and change every step
+ *                              (the weight-norm fold w = v * g / ||v|| and its gradient stay with the caller's autograd).
+ *                              After the first call the handle serves fp32 layer-by-layer kernels only.
+ *   hificar_forward_train      hificar_forward that also keeps every activation the backward pass needs in `tape`
+ *                              (hificar_tape_bytes(h, B, T) bytes, 256-byte aligned, caller-owned until hificar_backward returns)
+ *   hificar_backward           gradients of one hificar_forward_train: dout (B, hop*T) gradient of the waveform, out the waveform
+ *                              the forward returned -> `grads` (hificar_grad_floats(h) floats; parameter i of hificar_grad_count(h)
+ *                              at the offset hificar_grad_info reports, in the reference's folded layout), dc (B, C, T) gradient of
+ *                              the features or NULL, dar (B, ar_input) gradient of the AR context or NULL.
+ *                              workspace: hificar_backward_workspace_bytes(h, B, T) bytes.
+ * --------------------------------------------------------------------------------------------------------------------------- */
+int hificar_set_weight_device(hificar_handle* h, const char* name, const float* data, void* stream);
+size_t hificar_tape_bytes(const hificar_handle* h, int B, int T);
+int hificar_forward_train(hificar_handle* h, const float* c, const float* ar, float* out, int B, int T, void* workspace,
+                          size_t workspace_bytes, void* tape, size_t tape_bytes, void* stream);
+size_t hificar_backward_workspace_bytes(const hificar_handle* h, int B, int T);
+int hificar_grad_count(hificar_handle* h);
+int hificar_grad_info(hificar_handle* h, int i, char* name96, int64_t* offset, int64_t* numel);
+int64_t hificar_grad_floats(hificar_handle* h);
+int hificar_backward(hificar_handle* h, const float* dout, const float* out, int B, int T, const void* tape, size_t tape_bytes,
+                     float* grads, float* dc, float* dar, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Parity aid: per-layer intermediates of the forwards that follow, copied into caller buffers in the reference's (B, C, L)
  * layout — what a forward hook on the reference's modules (articulatory/models/hifigan.py:221-231,
  * articulatory/layers/residual_block.py:217-221) returns.  Names:

@@ -228,6 +228,54 @@ def ar_loop_batched(w, params, x, batch_max_steps, hop_size):
 
 
 # --------------------------------------------------------------------------------------
+# training path: gradients (the generator half of articulatory/bin/train.py:276-440)
+# --------------------------------------------------------------------------------------
+def gradients(state_dict, params, c, ar, cot, dtype=torch.float32):
+    """d(sum(out * cot)) / d(every state_dict parameter, c, ar): the reference runs the generator under PyTorch autograd with weight
+    norm in the graph (w = v * g / ||v||, hifigan.py:268-278); the restatement differentiates ``generator_forward`` on weights folded
+    INSIDE the graph.  state_dict: reference-layout arrays (weight_g / weight_v / bias / Linear).  Returns
+    (out, {"c": .., "ar": .., state_dict key: ..})."""
+    leaves = {k: torch.as_tensor(np.asarray(v)).to(dtype).clone().requires_grad_(True) for k, v in state_dict.items()}
+    w = OrderedDict()
+    for k, v in leaves.items():
+        if k.endswith(".weight_g"):
+            continue
+        if k.endswith(".weight_v"):
+            base = k[: -len("weight_v")]
+            g = leaves[base + "weight_g"]
+            norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(g.shape)
+            w[base + "weight"] = v * (g / norm)
+        else:
+            w[k] = v
+    c = torch.as_tensor(np.asarray(c)).to(dtype).clone().requires_grad_(True)
+    ar_t = torch.as_tensor(np.asarray(ar)).to(dtype).clone().requires_grad_(True) if ar is not None else None
+    out = generator_forward(w, params, c, ar_t)
+    (out * torch.as_tensor(np.asarray(cot)).to(dtype)).sum().backward()
+    grads = {k: v.grad for k, v in leaves.items()}
+    grads["c"] = c.grad
+    if ar_t is not None:
+        grads["ar"] = ar_t.grad
+    return out.detach(), grads
+
+
+def check_packed(gold, name, arr, tol):
+    """Compare ``arr`` with a fixture entry written by oracle/make_golden_grad.py (full tensor, or sum / |.|-sum / 64 samples).
+    Returns the worst relative deviation (each relative to the entry's own scale)."""
+    flat = np.asarray(arr.detach().cpu() if hasattr(arr, "detach") else arr, dtype=np.float64).reshape(-1)
+    if name + "::full" in gold:
+        ref = gold[name + "::full"].astype(np.float64)
+        assert ref.shape == flat.shape, (name, ref.shape, flat.shape)
+        return float(np.abs(flat - ref).max() / max(np.abs(ref).max(), 1e-30))
+    idx = gold[name + "::idx"]
+    vals = gold[name + "::vals"].astype(np.float64)
+    scale = max(np.abs(vals).max(), float(gold[name + "::abssum"]) / flat.size, 1e-30)
+    e1 = float(np.abs(flat[idx] - vals).max() / scale)
+    e2 = abs(float(np.abs(flat).sum()) - float(gold[name + "::abssum"])) / max(float(gold[name + "::abssum"]), 1e-30)
+    e3 = abs(float(flat.sum()) - float(gold[name + "::sum"])) / max(float(gold[name + "::abssum"]), 1e-30)
+    return max(e1, e2, e3)
+
+
+# --------------------------------------------------------------------------------------
 # independent definition-level restatement (numpy float64, small sizes only)
 # --------------------------------------------------------------------------------------
 def _np_lrelu(x, slope):

@@ -211,3 +211,23 @@ def test_oracle_speaker_and_phoneme_conditioning_vs_reference():
     assert rel_err(y.numpy(), gold["out"]) < 2e-6
     assert ph_out.shape == gold["ph_out"].shape == (2, 11, 19)
     assert rel_err(ph_out.numpy(), gold["ph_out"]) < 2e-6
+
+
+GRAD_CASES = {
+    "small": dict(channels=128, upsample_scales=[5, 4], upsample_kernel_sizes=[10, 8]),
+    "full_linear": dict(nonlinear_activation_params={"negative_slope": 1.0}),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(GRAD_CASES))
+def test_oracle_gradients_vs_reference(tag):
+    """The training path: gradients of sum(out * cot) with respect to every parameter (weight norm in the graph) and to c / ar,
+    against the real reference under PyTorch autograd (oracle/make_golden_grad.py; its header explains the choice of cases)."""
+    gold = np.load(os.path.join(GOLDEN, f"gold_grad_{tag}.npz"))
+    params = dict(E2W_PARAMS, **GRAD_CASES[tag])
+    sd = synth_state_dict(params, seed=int(gold["seed"]))
+    out, grads = O.gradients(sd, params, gold["c"], gold["ar"], gold["cot"])
+    assert O.check_packed(gold, "out", out, 1e-5) < 1e-5
+    worst = max(O.check_packed(gold, "grad::" + k, v, 1e-4) for k, v in grads.items())
+    assert len(grads) == len(sd) + 2
+    assert worst < 2e-4, worst
