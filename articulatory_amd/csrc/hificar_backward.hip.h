@@ -36,6 +36,8 @@ struct WgradParams {
     int chunks_per_seq;  // ceil(L / 128)
     int nsplit;
     int g_per_tile;      // 32-blocks of g per workgroup tile: 2, or 1 when a 64-wide tile would straddle two phases (odd nb32_per_phase)
+    float* bias_partial; // [nsplit][gpad] column sums of G (bias gradient partials), taken from the staged G tile by the workgroups of
+                         // tap 0 / first a-tile; null: not wanted
 };
 
 constexpr int kWgR = 128;  // rows per chunk
@@ -81,6 +83,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             ar[q] = va;
         }
     };
+    const bool do_bias = p.bias_partial && at == 0 && tap == 0;
+    float bsum = 0.f;  // thread (channel tid & 63, row slice tid >> 6) of the G tile
     if (c_lo < c_hi) fetch(c_lo);
     for (int c = c_lo; c < c_hi; ++c) {
         __syncthreads();  // the previous chunk's reads are done
@@ -93,11 +97,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         }
         __syncthreads();
         if (c + 1 < c_hi) fetch(c + 1);  // in flight while this chunk is multiplied
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = tid >> 6; r < kWgR; r += 4) bsum += gs[r][tid & 63];
+        }
         if (active) {
             const int gc = (wave >> 1) * 32 + li, ac = (wave & 1) * 32 + li;
 #pragma unroll 8
             for (int k = 0; k < kWgR; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[k + hf][gc], as[k + hf][ac], acc, 0, 0, 0);
         }
+    }
+    if (do_bias) {
+        __syncthreads();
+        as[tid >> 6][tid & 63] = bsum;  // reuse the A tile as scratch
+        __syncthreads();
+        const int ch = gt * gpt * 32 + tid;
+        if (tid < gpt * 32 && ch < p.n_gblk * 32) p.bias_partial[(size_t)split * p.n_gblk * 32 + ch] = (as[0][tid] + as[1][tid]) + (as[2][tid] + as[3][tid]);
     }
     if (active) {
         const int gpad = p.n_gblk * 32, apad = p.n_ablk * 32;
