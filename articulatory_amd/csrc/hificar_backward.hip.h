@@ -36,6 +36,8 @@ struct WgradParams {
     int chunks_per_seq;  // ceil(L / 128)
     int nsplit;
     int g_per_tile;      // 32-blocks of g per workgroup tile: 2, or 1 when a 64-wide tile would straddle two phases (odd nb32_per_phase)
+    int row_split;       // 1, 2 or 4: layers narrower than the 64 x 64 workgroup tile give the spare waves a share of each chunk's rows
+                         // (summed inside the workgroup before the partial is written)
     float* bias_partial; // [nsplit][gpad] column sums of G (bias gradient partials), taken from the staged G tile by the workgroups of
                          // tap 0 / first a-tile; null: not wanted
 };
@@ -55,8 +57,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     const int gt = tile % gt_n;
     const int tap = tile / gt_n;
     const int split = blockIdx.y;
-    const int gblk = gt * gpt + (wave >> 1), ablk = at * 2 + (wave & 1);
-    const bool active = (wave >> 1) < gpt && gblk < p.n_gblk && ablk < p.n_ablk;
+    // wave -> (block of the tile, share of the rows): 4 blocks x 1 share, 2 x 2 or 1 x 4
+    const int rs = p.row_split, nblk = 4 / rs;
+    const int bi = wave % nblk, part = wave / nblk;
+    const int ab_w = p.n_ablk >= 2 ? 2 : 1;  // blocks along a inside the tile
+    const int gl = bi / ab_w, al = bi % ab_w;
+    const int gblk = gt * gpt + gl, ablk = at * 2 + al;
+    const bool active = gl < gpt && gblk < p.n_gblk && ablk < p.n_ablk;
     // the g blocks of a tile share one tap offset (the staged A rows are shifted by it): g_per_tile = 1 when phases are 32 wide
     const int phase = (gt * gpt) / p.nb32_per_phase;
     const int off = p.tap_off0[phase] + tap * p.tap_step;
@@ -102,9 +109,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             for (int r = tid >> 6; r < kWgR; r += 4) bsum += gs[r][tid & 63];
         }
         if (active) {
-            const int gc = (wave >> 1) * 32 + li, ac = (wave & 1) * 32 + li;
+            const int gc = gl * 32 + li, ac = al * 32 + li;
+            const int k0 = part * (kWgR / rs);
+            if (rs == 1) {
 #pragma unroll 8
-            for (int k = 0; k < kWgR; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[k + hf][gc], as[k + hf][ac], acc, 0, 0, 0);
+                for (int k = 0; k < kWgR; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[k + hf][gc], as[k + hf][ac], acc, 0, 0, 0);
+            } else if (rs == 2) {
+#pragma unroll 8
+                for (int k = 0; k < kWgR / 2; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[k0 + k + hf][gc], as[k0 + k + hf][ac], acc, 0, 0, 0);
+            } else {
+#pragma unroll 8
+                for (int k = 0; k < kWgR / 4; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[k0 + k + hf][gc], as[k0 + k + hf][ac], acc, 0, 0, 0);
+            }
         }
     }
     if (do_bias) {
@@ -114,7 +130,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         const int ch = gt * gpt * 32 + tid;
         if (tid < gpt * 32 && ch < p.n_gblk * 32) p.bias_partial[(size_t)split * p.n_gblk * 32 + ch] = (as[0][tid] + as[1][tid]) + (as[2][tid] + as[3][tid]);
     }
-    if (active) {
+    if (rs > 1) {  // the row shares of a block are summed in the workgroup, in the fixed order part 0 + 1 (+ 2 + 3)
+        __syncthreads();
+        float* red = &gs[0][0];  // 8192 floats; needed: (rs - 1) * nblk * 1024 <= 3072
+        if (active && part > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((part - 1) * nblk + bi) * 1024 + r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (active && part == 0) {
+            for (int q = 1; q < rs; ++q) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += red[((q - 1) * nblk + bi) * 1024 + r * 64 + lane];
+            }
+        }
+    }
+    if (active && part == 0) {
         const int gpad = p.n_gblk * 32, apad = p.n_ablk * 32;
         float* dst = p.partial + (((size_t)split * p.ntaps + tap) * gpad + gblk * 32) * apad + ablk * 32 + li;
 #pragma unroll
