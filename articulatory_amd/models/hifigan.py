@@ -161,6 +161,16 @@ class _GeneratorFunction(torch.autograd.Function):
                                       ctx.tape.numel() - ctx.toff, grads.data_ptr(), dc.data_ptr() if dc is not None else None,
                                       dar.data_ptr() if dar is not None else None, ws.data_ptr() + woff, ws.numel() - woff, stream)
         _native.check(rc, "hificar_backward")
+        if module._grad_sync is not None:
+            # data-parallel training: ONE all-reduce (RCCL over xGMI under the "nccl" backend) of the flat buffer that holds every
+            # folded parameter's gradient — the whole generator is a single 54-MB bucket.  The weight-norm chain rule that follows
+            # is linear in these gradients, so reducing them here equals reducing the (weight_g, weight_v) gradients.
+            import torch.distributed as dist
+
+            group, average = module._grad_sync
+            dist.all_reduce(grads, group=group)
+            if average:
+                grads.div_(dist.get_world_size(group))
         layout = module._grad_layout()
         gw = []
         for name, shape in zip(ctx.names, ctx.shapes):
@@ -285,6 +295,7 @@ class HiFiGANGenerator(torch.nn.Module):
         self._handle = None
         self._workspaces = {}
         self._lib = None
+        self._grad_sync = None
 
     # ------------------------------------------------------------------ parameter plumbing
     def _conv_params(self):
@@ -496,6 +507,13 @@ class HiFiGANGenerator(torch.nn.Module):
         return out, taps
 
     # ------------------------------------------------------------------ forward paths
+    def sync_gradients(self, group=None, average=True, enabled=True):
+        """Data-parallel training (the reference's DDP wrap is disabled, articulatory/bin/train.py:1790-1801): all-reduce the
+        generator's gradients across the ranks of ``group`` inside backward — one collective on the flat gradient buffer (the
+        whole generator as a single bucket), averaged like DistributedDataParallel does.  Needs an initialised process group."""
+        self._grad_sync = (group, bool(average)) if enabled else None
+        return self
+
     def _grad_layout(self):
         """{folded parameter name: (offset, numel)} inside the flat gradient buffer hificar_backward fills."""
         if getattr(self, "_grad_slots", None) is None:

@@ -139,3 +139,35 @@ def test_training_step_updates_weights_and_eval_follows():
     with torch.no_grad():
         ref = O.generator_forward(O.fold_weight_norm(sd_now), params, c.cpu(), ar.cpu())
     assert rel_err(y.numpy(), ref.numpy()) < 2e-5
+
+
+def test_gradient_all_reduce_over_rccl_world1():
+    """sync_gradients(): the backward pass all-reduces the flat gradient buffer over the "nccl" (RCCL) backend.  One GPU here, so a
+    world of one rank: the collective runs for real and must leave the gradients unchanged (averaging by 1)."""
+    import socket
+    import torch.distributed as dist
+
+    params = dict(E2W_PARAMS, channels=128, upsample_scales=[5, 4], upsample_kernel_sizes=[10, 8])
+    c = torch.from_numpy(synth_features(2, 9, 13, seed=2).transpose(0, 2, 1).copy()).cuda()
+    ar = torch.zeros(2, 1, 512, device="cuda:0")
+    cot = torch.from_numpy(uniform(4, "cot", (2, 1, 180), -1.0, 1.0)).cuda()
+
+    def grads(sync):
+        g, _ = build(params, 21)
+        if sync:
+            g.sync_gradients()
+        (g(c, ar=ar) * cot).sum().backward()
+        return {k: p.grad.clone() for k, p in g.named_parameters()}
+
+    ref = grads(False)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        got = grads(True)
+    finally:
+        dist.destroy_process_group()
+    assert sorted(got) == sorted(ref)
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
+#   tools/collect_profiles.sh <tag>        e.g. r02
+# Passes (each its own run; PMC passes use --kernel-trace only, as the pool requires):
+#   kernel stats (both arithmetics), FETCH_SIZE, WRITE_SIZE, MFMA-busy / SQ cycle counters.  Output: gpurun_out/prof_<tag>_*/
+tag=${1:-r02}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out
+export TMPDIR=/tmp
+cd /tmp
+common="--no-cpu-baseline --no-fast-leg --no-batch-sweep"
+rocprofv3 -L > $out/prof_${tag}_counters_available.txt 2>&1
+for prec in f32 bf16x3; do
+  rocprofv3 --kernel-trace --stats -f csv -d $out/prof_${tag}_${prec}_stats -- python $root/bench.py --precision $prec --steps 3 --warmup 1 $common > $out/prof_${tag}_${prec}_bench_under_rocprof.json 2> $out/prof_${tag}_${prec}_stats.log
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $ctr --kernel-trace -f csv -d $out/prof_${tag}_${prec}_$ctr -- python $root/bench.py --precision $prec --steps 1 --warmup 0 --no-roofline $common > /dev/null 2> $out/prof_${tag}_${prec}_$ctr.log
+  done
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -f csv -d $out/prof_${tag}_${prec}_mfma -- python $root/bench.py --precision $prec --steps 1 --warmup 0 --no-roofline $common > /dev/null 2> $out/prof_${tag}_${prec}_mfma.log
+done
+ls $out | grep prof_${tag}
