@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Copy rocprofv3 outputs from gpurun_out/ into profiles/ as small committed summaries.
-   python tools/summarize_profiles.py <tag> <stats_csv> <pmc_fetch_dir> <pmc_write_dir> <bench_json> [precision]"""
+"""Copy rocprofv3 outputs of tools/collect_profiles.sh from gpurun_out/ into profiles/ as small committed summaries.
+   python tools/summarize_profiles.py <tag>          (reads gpurun_out/prof_<tag>_<precision>_{stats,FETCH_SIZE,WRITE_SIZE,mfma})
+Writes per precision: profiles/<tag>_<prec>_kernel_stats.csv, _pmc_hbm.csv, _pmc_mfma.csv, _bench.json, and updates
+profiles/hbm_traffic.json (HBM bytes per launch that bench.py reports as roofline.traffic)."""
 import collections
 import csv
 import glob
@@ -10,54 +12,90 @@ import sys
 
 
 def find(path, pattern):
-    """path itself if it is a file, else the single rocprofv3 output matching pattern below it"""
-    if os.path.isfile(path):
-        return path
     hits = sorted(glob.glob(os.path.join(path, "**", pattern), recursive=True))
     assert hits, (path, pattern)
     return hits[0]
 
 
-tag, stats_csv, fdir, wdir, bench_json = sys.argv[1:6]
-prec = sys.argv[6] if len(sys.argv) > 6 else "bf16x3"
-rows = list(csv.DictReader(open(find(stats_csv, '*kernel_stats.csv'))))
-with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -f csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline  ({tag}); durations in ns\n")
-    w = csv.writer(f)
-    w.writerow(rows[0].keys())
-    for r in rows:
-        if float(r.get("Percentage", 0) or 0) >= 0.01 or "hificar" in r["Name"]:
-            w.writerow(r.values())
-res = {}
-for c, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    for row in csv.DictReader(open(find(d, "*counter_collection.csv"))):
-        if row["Counter_Name"] == c:
-            agg[row["Kernel_Name"]][0] += 1
-            agg[row["Kernel_Name"]][1] += float(row["Counter_Value"])
-    res[c] = agg
-traffic = {}
-with open(f"profiles/{tag}_pmc_hbm.csv", "w") as f:
-    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 1 --warmup 0 "
-            "--no-cpu-baseline --no-roofline\n# counter units KiB; gfx950 correction (MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of wide "
-            "coalesced reads) applied in the last column = (2*FETCH + WRITE)*1024\n")
-    f.write("Kernel,Launches,FETCH_SIZE_KiB_per_launch_raw,WRITE_SIZE_KiB_per_launch,HBM_bytes_per_launch_corrected\n")
-    for k in res["FETCH_SIZE"]:
-        n, fe = res["FETCH_SIZE"][k]
-        n2, wr = res["WRITE_SIZE"].get(k, [1, 0.0])
-        b = (2 * fe / n + wr / max(n2, 1)) * 1024
-        if "hificar" in k or "elementwise" in k:
-            f.write(f"\"{k}\",{n},{fe / n:.1f},{wr / max(n2, 1):.1f},{b:.0f}\n")
-        if "hificar" in k:
-            traffic[k.replace("void hificar::", "").replace("hificar::", "").split("(")[0].replace(", ", ",")] = round(b)
+def short(k):
+    return k.replace("void hificar::", "").replace("hificar::", "").split("(")[0].replace(", ", ",")
+
+
+def counters(path):
+    """{kernel: {counter: [n, sum]}} and {kernel: [n, total duration ns]} of one PMC pass"""
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    dur = collections.defaultdict(lambda: [0, 0.0])
+    seen = set()
+    for row in csv.DictReader(open(find(path, "*counter_collection.csv"))):
+        k = row["Kernel_Name"]
+        a = agg[k][row["Counter_Name"]]
+        a[0] += 1
+        a[1] += float(row["Counter_Value"])
+        if row["Dispatch_Id"] not in seen:
+            seen.add(row["Dispatch_Id"])
+            dur[k][0] += 1
+            dur[k][1] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    return agg, dur
+
+
+tag = sys.argv[1]
 try:
     allt = json.load(open("profiles/hbm_traffic.json"))
 except Exception:
     allt = {}
-allt[prec] = traffic
+for prec in ("f32", "bf16x3"):
+    base = f"gpurun_out/prof_{tag}_{prec}"
+    if not os.path.isdir(base + "_stats"):
+        continue
+    cmd = f"python bench.py --precision {prec} --steps 3 --warmup 1 --no-cpu-baseline --no-fast-leg --no-batch-sweep"
+    rows = list(csv.DictReader(open(find(base + "_stats", "*kernel_stats.csv"))))
+    with open(f"profiles/{tag}_{prec}_kernel_stats.csv", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -f csv -- {cmd}  ({tag}, {prec}); durations in ns\n")
+        w = csv.writer(f)
+        w.writerow(rows[0].keys())
+        for r in rows:
+            if float(r.get("Percentage", 0) or 0) >= 0.01 or "hificar" in r["Name"]:
+                w.writerow(r.values())
+    fe, _ = counters(base + "_FETCH_SIZE")
+    wr, _ = counters(base + "_WRITE_SIZE")
+    traffic = {}
+    with open(f"profiles/{tag}_{prec}_pmc_hbm.csv", "w") as f:
+        f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --precision {prec} --steps 1 "
+                "--warmup 0 --no-cpu-baseline --no-roofline --no-fast-leg --no-batch-sweep\n# counter units KiB; gfx950 correction "
+                "(MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of wide coalesced reads) applied in the last column = (2*FETCH + WRITE)*1024\n")
+        f.write("Kernel,Launches,FETCH_SIZE_KiB_per_launch_raw,WRITE_SIZE_KiB_per_launch,HBM_bytes_per_launch_corrected\n")
+        for k in fe:
+            n, v = fe[k]["FETCH_SIZE"]
+            n2, v2 = wr.get(k, {}).get("WRITE_SIZE", [1, 0.0])
+            b = (2 * v / n + v2 / max(n2, 1)) * 1024
+            if "hificar" in k:
+                f.write(f"\"{k}\",{n},{v / n:.1f},{v2 / max(n2, 1):.1f},{b:.0f}\n")
+                traffic[short(k)] = round(b)
+    allt[prec] = traffic
+    mf, dur = counters(base + "_mfma")
+    with open(f"profiles/{tag}_{prec}_pmc_mfma.csv", "w") as f:
+        f.write(f"# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace "
+                f"-- python bench.py --precision {prec} --steps 1 --warmup 0 ... ({tag}); per-launch averages.\n"
+                "# Counter values are sums over the 8 XCDs.  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 1024 SIMDs): the share of\n"
+                "# SIMD-cycles in which the matrix pipe is busy (rocprofv3's MfmaUtil expression; gfx950 has no derived-counter section,\n"
+                "# MI355X_MICROARCH.md).  SQ_VALU_MFMA_BUSY_CYCLES / 1024 equals 64 x (fp32 MFMAs per SIMD) resp. 32 x (bf16 MFMAs) exactly.\n"
+                "# gui_cycles_per_us = GRBM_GUI_ACTIVE / 8 / duration (the graphics clock the counter ticks at, in MHz).\n")
+        f.write("Kernel,Launches,avg_duration_us,GRBM_GUI_ACTIVE,SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,mfma_util,gui_cycles_per_us\n")
+        for k in sorted(mf, key=lambda k: -dur[k][1]):
+            if "hificar" not in k:
+                continue
+            c = {name: v[1] / max(v[0], 1) for name, v in mf[k].items()}
+            d_us = dur[k][1] / dur[k][0] / 1e3
+            gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+            util = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8 * 1024) if gui else 0.0
+            f.write(f"\"{k}\",{dur[k][0]},{d_us:.2f},{gui:.0f},{c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.0f},{c.get('SQ_BUSY_CYCLES', 0):.0f},"
+                    f"{c.get('SQ_WAVE_CYCLES', 0):.0f},{c.get('SQ_WAIT_INST_ANY', 0):.0f},{c.get('SQ_ACTIVE_INST_ANY', 0):.0f},{util:.4f},{gui / 8 / d_us if d_us else 0:.0f}\n")
+    bj = f"{base}_bench_under_rocprof.json"
+    if os.path.exists(bj):
+        open(f"profiles/{tag}_{prec}_bench_under_rocprof.json", "w").write(open(bj).read())
+    print(open(f"profiles/{tag}_{prec}_kernel_stats.csv").read()[:1500])
+    print(open(f"profiles/{tag}_{prec}_pmc_mfma.csv").read()[:2500])
+    print(traffic)
 allt["_comment"] = ("HBM bytes per launch from rocprofv3 PMC, (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction), "
                     "see profiles/*_pmc_hbm.csv; keyed by precision then kernel name as bench.py reports it")
 json.dump(allt, open("profiles/hbm_traffic.json", "w"), indent=1, sort_keys=True)
-open(f"profiles/{tag}_bench.json", "w").write(open(bench_json).read())
-print(open(f"profiles/{tag}_kernel_stats.csv").read()[:1800])
-print(traffic)
