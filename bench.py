@@ -79,7 +79,7 @@ def cpu_baseline(params, sd, chunk_frames, seed):
         if nt <= all_cores:
             by_threads[nt] = run(8, 5 * chunk_frames, nt)[0]
     best = max(by_threads, key=by_threads.get)
-    B, T = 64, 20 * chunk_frames  # 64 utterances x 2.5 s = 20 chunks of 25 frames each (~5 s of CPU work)
+    B, T = 64, 60 * chunk_frames  # 64 utterances x 7.5 s = 60 chunks of 25 frames each (~15 s of CPU work)
     value, dt = run(B, T, best)
     torch.set_num_threads(all_cores)
     return {
@@ -148,7 +148,8 @@ def roofline_block(stats, precision, wall_s, steps, traffic_table):
     gbs = dom["bytes"] / sec / 1e9
     peak_tf = PEAK_TFLOPS[precision]
     intensity = dom["flops"] / max(dom["bytes"], 1.0)
-    balance = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+    # machine balance of THIS arithmetic: bf16x3 spends 3 MFMAs per algorithmic MAC, so its matrix roof is peak / 3
+    balance = peak_tf / MFMA_PER_MAC[precision] * 1e12 / (PEAK_HBM_GBS * 1e9)
     bound = "mfma" if intensity >= balance else "hbm"
     traffic = (traffic_table or {}).get(precision, {}).get(dom["name"])
     alg_bytes = dom["bytes"] / dom["launches"]
