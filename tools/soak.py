@@ -18,7 +18,7 @@ for prec in ("bf16x3", "f32"):
     g = HiFiGANGenerator(**CAR_PARAMS, precision=prec)
     g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     g.remove_weight_norm(); g = g.eval().cuda()
-    for B, chunk in ((64, 25), (8, 100), (3, 25)):
+    for B, chunk in ((64, 25), (8, 100), (3, 25), (1, 25)):
         x = torch.from_numpy(synth_features(B, a.frames, 13, seed=B)).permute(0, 2, 1).contiguous().cuda()
         with torch.no_grad():
             ref = g.ar_synthesis(x, chunk).clone()
@@ -36,7 +36,8 @@ for prec in ("bf16x3", "f32"):
         ref = g.ar_synthesis_packed(x, 25, lens, batch=32).clone()
         bad = sum(int(not torch.equal(g.ar_synthesis_packed(x, 25, lens, batch=32), ref)) for _ in range(a.reps // 2))
         one = g.ar_synthesis(x[5:6, :, :lens[5]].contiguous(), 25)
-    print(f"{prec} packed 96 utterances, 32 in flight: {a.reps // 2} repeats, {bad} differing; utterance 5 == alone: "
-          f"{bool(torch.equal(ref[5, :80 * lens[5]], one[0]))}", flush=True)
-    assert bad == 0 and torch.equal(ref[5, :80 * lens[5]], one[0])
+    # utterance 5 alone is a different launch shape (split-K form on small launches): equal to rounding, bit-equal with HIFICAR_KSPLIT=0
+    close = float((ref[5, :80 * lens[5]] - one[0]).abs().max() / one[0].abs().max())
+    print(f"{prec} packed 96 utterances, 32 in flight: {a.reps // 2} repeats, {bad} differing; utterance 5 vs alone: {close:.1e}", flush=True)
+    assert bad == 0 and close < (5e-6 if prec == "f32" else 2e-4)
 print("soak ok")
