@@ -594,11 +594,6 @@ class HiFiGANGenerator(torch.nn.Module):
             ar = ar.to(device=c.device, dtype=torch.float32).contiguous()
         c = c.to(torch.float32).contiguous()
         B, _, T = c.shape
-        if torch.is_grad_enabled() and (c.requires_grad or (ar is not None and ar.requires_grad)
-                                        or any(p.requires_grad for p in self.parameters())):
-            if lengths is not None:
-                raise NotImplementedError("autograd with ragged lengths is not built")
-            return self._forward_autograd(c, ar)
         if self.use_spk_id:
             if spk_id is None or spk_id.numel() != B:
                 raise RuntimeError("use_spk_id=True: forward() needs spk_id=(B,) speaker indices")
@@ -611,6 +606,11 @@ class HiFiGANGenerator(torch.nn.Module):
             if int(ph.min()) < 0 or int(ph.max()) >= self._params["num_ph"]:
                 raise IndexError("index out of range in self")
             ph = ph.to(device=c.device, dtype=torch.int32).contiguous()
+        if torch.is_grad_enabled() and (c.requires_grad or (ar is not None and ar.requires_grad)
+                                        or any(p.requires_grad for p in self.parameters())):
+            if lengths is not None:
+                raise NotImplementedError("autograd with ragged lengths is not built")
+            return self._forward_autograd(c, ar)
         handle = self._native_handle()
         if lengths is None:
             out = torch.empty((B, 1, T * self.hop), dtype=torch.float32, device=c.device)
