@@ -362,6 +362,25 @@ def test_trained_checkpoint_scale_full_ar_loop(prec, gain, out_gain):
     assert float(e[:, -2000:].max()) < 4 * max(float(e[:, :2000].max()), 1e-7)
 
 
+@pytest.mark.parametrize("B", [1, 8])
+def test_small_batch_ar_loop_vs_oracle(car, B):
+    """BASELINE's batch 1 / 8 points (north_star: "throughput ... at batch 1/8/64"): the full 10-s, 80-step AR loop against the
+    oracle on every sample, through the split-K conv form the small launches take."""
+    g, w = car
+    x = synth_features(B, 2000, 13, seed=20260929 + 30 + B)
+    feats = torch.from_numpy(x).permute(0, 2, 1).contiguous().cuda()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        y = g.ar_synthesis(feats, 25).cpu()
+        g.profile_begin()
+        g.ar_synthesis(feats[:, :, :50].contiguous(), 25)
+        names = {s["name"].split("<")[0] for s in g.profile_end()}
+        ref = O.ar_loop_batched(w, E2W_PARAMS, torch.from_numpy(x), 2000, 80)
+    assert any(n.startswith("conv_sk_") for n in names), names
+    per_utt = (y - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)
+    assert float(per_utt.max()) < g.tol, float(per_utt.max())
+
+
 def test_nonar_baseline_size_vs_oracle_window(prec):
     """BASELINE config 2 (non-AR 12-dim, batch 8, 10 s): full-size run; oracle comparison on one utterance's
     interior window computed from a halo'd excerpt (receptive field of the whole generator < 60 frames)."""
