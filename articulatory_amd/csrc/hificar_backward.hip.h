@@ -153,6 +153,162 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// All taps from one staging: the per-tap kernels above re-read both operand tiles once per tap (16 GB of L2 / MALL traffic per backward
+// of the batch-64 step: they are bound by it, 51-54 TFLOP/s).  Here a workgroup stages a chunk of G rows and the matching A rows WITH the
+// taps' halo once (LDS-DMA, double-buffered, no staging registers) and keeps one 32 x 32 accumulator PER TAP in every wave: a K step reads
+// one G operand and one A operand per tap (row-shifted) from LDS and issues NT MFMAs.  Workgroup tile 64 (g) x 64 (a), waves 2 x 2;
+// partial layout, row shares and bias sums as above.  NT = accumulators instantiated (>= ntaps).
+struct WgradTapsParams {
+    WgradParams w;
+    const char* zeros;  // >= 16 zero bytes (rows outside the sequence)
+    int off_min;        // smallest tap offset of the layer (over all phases), halo = largest - smallest
+    int halo;
+};
+
+constexpr int kWgtR = 64;  // G rows per chunk
+
+// EXACT: the layer has exactly NT taps (no per-tap branch in the K loop: the operand reads of the next row pair are in flight while this
+// pair's MFMAs issue); otherwise ntaps < NT and the surplus taps are skipped.
+template <int NT, bool EXACT>
+__global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsParams q) {
+    extern __shared__ __attribute__((aligned(1024))) char wgt_smem[];
+    const WgradParams& p = q.w;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hf = lane >> 5;
+    const int gpt = p.g_per_tile;
+    const int gt_n = (p.n_gblk + gpt - 1) / gpt, at_n = (p.n_ablk + 1) >> 1;
+    const int at = blockIdx.x % at_n, gt = blockIdx.x / at_n;
+    const int split = blockIdx.y;
+    const int rs = p.row_split, nblk = 4 / rs;
+    const int bi = wave % nblk, part = wave / nblk;
+    const int ab_w = p.n_ablk >= 2 ? 2 : 1;
+    const int gl = bi / ab_w, al = bi % ab_w;
+    const int gblk = gt * gpt + gl, ablk = at * 2 + al;
+    const bool active = gl < gpt && gblk < p.n_gblk && ablk < p.n_ablk;
+    const int phase = (gt * gpt) / p.nb32_per_phase;
+    const int off0 = p.tap_off0[phase] - q.off_min;  // row shift of tap 0 inside the staged A tile (>= 0)
+    const int a_rows = kWgtR + q.halo;
+    const int g_bytes = kWgtR * 256, a_bytes = ((a_rows * 256 + 1023) >> 10) << 10, buf_bytes = g_bytes + a_bytes;
+    const int cps = (p.L + kWgtR - 1) / kWgtR;
+    const int nchunks = p.nseq * cps;
+    const int c_lo = (int)((long long)nchunks * split / p.nsplit), c_hi = (int)((long long)nchunks * (split + 1) / p.nsplit);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // LDS-DMA of one chunk: 1 KiB = 4 rows of 64 channels per wave-instruction, lane -> (row 4 i + lane / 16, channels 4 (lane % 16) ..)
+    auto stage = [&](int c, int b) {
+        const int seq = c / cps;
+        const int t0 = (c - seq * cps) * kWgtR;
+        char* dst = wgt_smem + b * buf_bytes;
+        const int c4 = (lane & 15) * 4;
+        for (int i = wave; i < kWgtR / 4; i += 4) {
+            const int tg = t0 + 4 * i + (lane >> 4);
+            const char* src = q.zeros;
+            const int gch = gt * gpt * 32 + c4;
+            if (tg < p.L && c4 < gpt * 32 && gch < p.gpitch) src = reinterpret_cast<const char*>(p.g + ((size_t)seq * p.L + tg) * p.gpitch + gch);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        }
+        const int ninstr = (a_rows + 3) >> 2;
+        for (int i = wave; i < ninstr; i += 4) {
+            const int r = 4 * i + (lane >> 4);
+            const int ta = t0 + q.off_min + r;
+            const char* src = q.zeros;
+            const int ach = at * 64 + c4;
+            // an A row is only ever multiplied with G rows of the same chunk: rows whose G partner lies beyond the sequence need no masking
+            // (those G rows are zero), but A rows outside [0, L) are the conv's zero padding
+            if (r < a_rows && ta >= 0 && ta < p.L && ach < p.apitch) src = reinterpret_cast<const char*>(p.a + ((size_t)seq * p.L + ta) * p.apitch + ach);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + g_bytes + i * 1024), 16, 0, 0);
+        }
+    };
+    const bool do_bias = p.bias_partial && at == 0;
+    float bsum = 0.f;
+    if (c_lo < c_hi) stage(c_lo, 0);
+    __syncthreads();  // (hipcc drains vmcnt before the barrier)
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int b = (c - c_lo) & 1;
+        if (c + 1 < c_hi) stage(c + 1, b ^ 1);  // lands while this chunk is multiplied
+        const float* gs = reinterpret_cast<const float*>(wgt_smem + b * buf_bytes);
+        const float* as = gs + g_bytes / 4;
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = tid >> 6; r < kWgtR; r += 4) bsum += gs[r * 64 + (tid & 63)];
+        }
+        if (active) {
+            const int gc = gl * 32 + li, ac = al * 32 + li;
+            const int k0 = part * (kWgtR / rs), kn = kWgtR / rs;  // kn: 64, 32 or 16 rows
+            const int tstep = p.tap_step * 64;
+            const float* gp = gs + (k0 + hf) * 64 + gc;
+            const float* ap[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ap[t] = as + (k0 + hf + off0) * 64 + ac + ((EXACT || t < p.ntaps) ? t * tstep : 0);
+            // 16 rows per trip, unrolled (row offsets are immediates of the reads); operands of the next row pair are fetched into the
+            // other register set while this pair's MFMAs issue.  The last fetch of a chunk reads two rows past it (inside the LDS
+            // allocation, never used).
+            float g0 = gp[0], g1, a0[NT], a1[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a0[t] = ap[t][0];
+            for (int kb = 0; kb < kn; kb += 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k += 4) {
+                    g1 = gp[(k + 2) * 64];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) a1[t] = ap[t][(k + 2) * 64];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (EXACT || t < p.ntaps) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, a0[t], acc[t], 0, 0, 0);
+                    g0 = gp[(k + 4) * 64];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) a0[t] = ap[t][(k + 4) * 64];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (EXACT || t < p.ntaps) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, a1[t], acc[t], 0, 0, 0);
+                }
+                gp += 16 * 64;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ap[t] += 16 * 64;
+            }
+        }
+        __syncthreads();  // next chunk landed, everyone done with this one
+    }
+    if (do_bias) {
+        float* red = reinterpret_cast<float*>(wgt_smem);
+        red[(tid >> 6) * 64 + (tid & 63)] = bsum;
+        __syncthreads();
+        const int ch = gt * gpt * 32 + tid;
+        if (tid < gpt * 32 && ch < p.n_gblk * 32) p.bias_partial[(size_t)split * p.n_gblk * 32 + ch] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+        __syncthreads();
+    }
+    const int gpad = p.n_gblk * 32, apad = p.n_ablk * 32;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t >= p.ntaps) break;
+        f32x16 v = acc[t];
+        if (rs > 1) {  // row shares of this tap summed in the workgroup, fixed order
+            float* red = reinterpret_cast<float*>(wgt_smem);
+            if (active && part > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((part - 1) * nblk + bi) * 1024 + r * 64 + lane] = v[r];
+            }
+            __syncthreads();
+            if (active && part == 0) {
+                for (int qq = 1; qq < rs; ++qq)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += red[((qq - 1) * nblk + bi) * 1024 + r * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (active && part == 0) {
+            float* dst = p.partial + (((size_t)split * p.ntaps + t) * gpad + gblk * 32) * apad + ablk * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hf) * apad] = v[r];
+        }
+    }
+}
+
 // dW in the reference's layout from the partials, summed over the splits in a fixed order.
 //   Conv1d          : dst[(co * cin + ci) * K + k]     g = co, a = ci, k = tap
 //   ConvTranspose1d : dst[(ci * cout + co) * K + k]    g = r * cout_pad + co (phase-major), a = ci, k = tap_k[r][tap] (< 0: no such weight)
@@ -167,11 +323,14 @@ struct WreduceParams {
 };
 
 __global__ __launch_bounds__(256) void wreduce_kernel(const WreduceParams p) {
-    const long long total = (long long)p.ntaps * p.gpad * p.apad;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int a = (int)(i % p.apad);
-        const long long r = i / p.apad;
-        const int g = (int)(r % p.gpad), tap = (int)(r / p.gpad);
+    // one thread: 4 consecutive a of one (tap, g); the splits in four interleaved running sums, combined in a fixed order
+    const int a4n = p.apad >> 2;
+    const int total4 = p.ntaps * p.gpad * a4n;
+    const size_t total = (size_t)total4 * 4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+        const int a = (i % a4n) * 4;
+        const int r = i / a4n;
+        const int g = r % p.gpad, tap = r / p.gpad;
         if (a >= p.cin) continue;
         int co = g, k = tap;
         if (p.transposed) {
@@ -182,10 +341,31 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreduceParams p) {
             if (k < 0) continue;
         }
         if (co >= p.cout) continue;
-        float s = 0.f;
-        for (int sp = 0; sp < p.nsplit; ++sp) s += p.partial[(size_t)sp * total + i];
-        const size_t d = p.transposed ? ((size_t)a * p.cout + co) * p.K + k : ((size_t)co * p.cin + a) * p.K + k;
-        p.dst[d] = s;
+        const float4* src = reinterpret_cast<const float4*>(p.partial) + i;
+        const size_t stride = total / 4;
+        float4 s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sp = 0;
+        for (; sp + 4 <= p.nsplit; sp += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = src[(size_t)(sp + j) * stride];
+                s[j].x += v.x, s[j].y += v.y, s[j].z += v.z, s[j].w += v.w;
+            }
+        }
+        for (int j = 0; sp < p.nsplit; ++sp, ++j) {
+            const float4 v = src[(size_t)sp * stride];
+            s[j].x += v.x, s[j].y += v.y, s[j].z += v.z, s[j].w += v.w;
+        }
+        const float o[4] = {(s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y), (s[0].z + s[1].z) + (s[2].z + s[3].z),
+                            (s[0].w + s[1].w) + (s[2].w + s[3].w)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (a + j >= p.cin) break;
+            const size_t d = p.transposed ? ((size_t)(a + j) * p.cout + co) * p.K + k : ((size_t)co * p.cin + a + j) * p.K + k;
+            p.dst[d] = o[j];
+        }
     }
 }
 
@@ -217,13 +397,32 @@ struct BreduceParams {
     int nsplit, pitch, cout, cout_pad, n_phase;
 };
 
+// 16 channels x 16 strands per workgroup: strand j sums terms j, j + 16, ... (four loads in flight), the strands are added in a fixed order
 __global__ __launch_bounds__(256) void breduce_kernel(const BreduceParams p) {
-    const int co = blockIdx.x * 256 + threadIdx.x;
-    if (co >= p.cout) return;
-    float s = 0.f;
-    for (int ph = 0; ph < p.n_phase; ++ph)
-        for (int sp = 0; sp < p.nsplit; ++sp) s += p.partial[(size_t)sp * p.pitch + ph * p.cout_pad + co];
-    p.dst[co] = s;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, jl = threadIdx.x >> 4;
+    const int co = blockIdx.x * 16 + cl;
+    const int n = p.n_phase * p.nsplit;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (co < p.cout) {
+        auto term = [&](int j) -> float {
+            if (j >= n) return 0.f;
+            const int ph = j / p.nsplit, sp = j - ph * p.nsplit;
+            return p.partial[(size_t)sp * p.pitch + ph * p.cout_pad + co];
+        };
+        for (int j = jl; j < n; j += 64) {
+            const float v0 = term(j), v1 = term(j + 16), v2 = term(j + 32), v3 = term(j + 48);
+            s0 += v0, s1 += v1, s2 += v2, s3 += v3;
+        }
+    }
+    red[jl][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (jl == 0 && co < p.cout) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += red[j][cl];
+        p.dst[co] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -324,11 +523,28 @@ struct VreduceParams {
     int tr_K, tr_C, tr_Cp;  // tr_K > 0: i = k * Cp + c -> dst[c * K + k] for c < C
 };
 
+// (16 elements x 16 strands per workgroup, like breduce_kernel)
 __global__ __launch_bounds__(256) void vreduce_kernel(const VreduceParams p) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.len) return;
+    __shared__ float red[16][17];
+    const int il = threadIdx.x & 15, jl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + il;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < p.len) {
+        const float* src = p.partial + i;
+        int j = jl;
+        for (; j + 48 < p.n; j += 64) {
+            const float v0 = src[(size_t)j * p.stride], v1 = src[(size_t)(j + 16) * p.stride], v2 = src[(size_t)(j + 32) * p.stride],
+                        v3 = src[(size_t)(j + 48) * p.stride];
+            s0 += v0, s1 += v1, s2 += v2, s3 += v3;
+        }
+        for (; j < p.n; j += 16) s0 += src[(size_t)j * p.stride];
+    }
+    red[jl][il] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (jl != 0 || i >= p.len) return;
     float s = 0.f;
-    for (int j = 0; j < p.n; ++j) s += p.partial[(size_t)j * p.stride + i];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += red[j][il];
     if (p.tr_K > 0) {
         const int k = i / p.tr_Cp, c = i - k * p.tr_Cp;
         if (c < p.tr_C) p.dst[(size_t)c * p.tr_K + k] = s;

@@ -22,6 +22,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--frames", type=int, default=25)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--profile", action="store_true")
+ap.add_argument("--torch-profile", action="store_true", help="torch.profiler table of one step (torch-side kernels around the native path)")
 a = ap.parse_args()
 params = dict(CAR_PARAMS)
 sd = synth_state_dict(params, seed=1234)
@@ -63,3 +64,28 @@ if a.profile:
     print(f"kernel time {tot:.2f} ms per step")
     for s in st[:14]:
         print(f"  {s['name']:44s} {s['launches']:4d} launches {s['total_ms']:8.3f} ms  {s['flops'] / max(s['total_ms'], 1e-9) / 1e9:7.1f} TF-alg")
+if a.torch_profile:
+    from torch.profiler import ProfilerActivity, profile
+
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=60))
+    ev = {}
+    for name, fn in (("zero_grad", lambda: opt.zero_grad(set_to_none=True)),):
+        pass
+    # wall-clock split of one step
+    def timed(fn):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, (time.perf_counter() - t) * 1e3
+
+    opt.zero_grad(set_to_none=True)
+    y, t_f = timed(lambda: g(c, ar=ar))
+    loss, t_l = timed(lambda: (y - target).abs().mean())
+    _, t_b = timed(loss.backward)
+    _, t_o = timed(opt.step)
+    print(f"serialised: forward {t_f:.2f} ms, loss {t_l:.2f} ms, backward {t_b:.2f} ms, optimizer {t_o:.2f} ms")
