@@ -39,6 +39,9 @@ SYMBOLS = (
     "hificar_profile_end",
     "hificar_debug_tap",
     "hificar_set_weight_device",
+    "hificar_set_parameters_device",
+    "hificar_raw_grad_floats",
+    "hificar_weight_norm_backward",
     "hificar_tape_bytes",
     "hificar_forward_train",
     "hificar_backward_workspace_bytes",
@@ -144,6 +147,12 @@ def load_library():
     lib.hificar_debug_tap.restype = ctypes.c_int
     lib.hificar_set_weight_device.argtypes = [vp, ctypes.c_char_p, vp, vp]
     lib.hificar_set_weight_device.restype = ctypes.c_int
+    lib.hificar_set_parameters_device.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, vp]
+    lib.hificar_set_parameters_device.restype = ctypes.c_int
+    lib.hificar_raw_grad_floats.argtypes = [vp]
+    lib.hificar_raw_grad_floats.restype = ctypes.c_int64
+    lib.hificar_weight_norm_backward.argtypes = [vp, vp, vp, vp]
+    lib.hificar_weight_norm_backward.restype = ctypes.c_int
     lib.hificar_tape_bytes.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.hificar_tape_bytes.restype = ctypes.c_size_t
     lib.hificar_forward_train.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]

@@ -682,8 +682,28 @@ struct PackParams {
     int tap_k[kMaxPhase][kMaxTaps];
 };
 
-__global__ __launch_bounds__(256) void pack_w32_kernel(const PackParams p) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+// modes 4-7: the parameters that are not conv weight packs, so that ONE batched launch re-sends every parameter
+//   mode 4  output conv weight (1, C, K) -> [k][Cp]        cin = C, cout_pad = Cp
+//   mode 5  transpose (rows = cout, cols = cin) -> (cols, rows)   (PastFCEncoder weights)
+//   mode 6  bias replicated over the phases: dst[r * cout_pad + co] = src[co], total = n_phase * cout
+//   mode 7  plain copy
+__device__ __forceinline__ void pack_w32_body(const PackParams& p, long long first, long long step) {
+    for (long long i = first; i < p.total; i += step) {
+        if (p.mode >= 4) {
+            if (p.mode == 4) {
+                const int k = (int)(i / p.cout_pad), c = (int)(i - (long long)k * p.cout_pad);
+                p.dst[i] = c < p.cin ? p.src[(size_t)c * p.K + k] : 0.f;
+            } else if (p.mode == 5) {
+                const int r = (int)(i / p.cin), c = (int)(i - (long long)r * p.cin);
+                p.dst[(size_t)c * p.cout + r] = p.src[i];
+            } else if (p.mode == 6) {
+                const int r = (int)(i / p.cout), co = (int)(i - (long long)r * p.cout);
+                p.dst[(size_t)r * p.cout_pad + co] = p.src[co];
+            } else {
+                p.dst[i] = p.src[i];
+            }
+            continue;
+        }
         long long r = i;
         const int j = (int)(r & 3);
         r >>= 2;
@@ -720,6 +740,102 @@ __global__ __launch_bounds__(256) void pack_w32_kernel(const PackParams p) {
         }
         p.dst[i] = val;
     }
+}
+
+__global__ __launch_bounds__(256) void pack_w32_kernel(const PackParams p) {
+    pack_w32_body(p, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+}
+
+// job of workgroup `wg` in a batched launch: start[j] <= wg < start[j + 1]
+__device__ __forceinline__ int find_job(const int* start, int njobs, int wg) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (start[mid] <= wg) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// every pack of the generator in one launch (the table lives in device memory; job j owns workgroups start[j] .. start[j + 1] - 1)
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackParams* jobs, const int* start, int njobs) {
+    const int j = find_job(start, njobs, blockIdx.x);
+    const int lb = blockIdx.x - start[j], nb = start[j + 1] - start[j];
+    pack_w32_body(jobs[j], (long long)lb * 256 + threadIdx.x, (long long)nb * 256);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight norm on the device (hifigan.py:268-278: torch.nn.utils.weight_norm, dim 0): w[r, :] = g[r] * v[r, :] / ||v[r, :]||.
+//   param_gather_kernel  raw parameters -> the FOLDED master copy every pack reads (plain tensors are copied), one launch
+//   wn_backward_kernel   folded gradients -> raw gradients: dg[r] = <dW[r], v[r]> / n,  dv[r] = (g / n) dW[r] - (g <dW[r], v[r]> / n^3) v[r]
+// One workgroup per row (weight norm) or per 1024 floats (copies); sums in a fixed order.
+// ------------------------------------------------------------------------------------------------
+struct ParamJob {
+    const float* v;   // weight_v, or the plain tensor
+    const float* g;   // weight_g; nullptr: copy
+    long long dst;    // float offset in the folded buffer (forward) / in the folded gradient buffer (backward: where dW lies)
+    long long dv, dg; // backward: float offsets in the raw gradient buffer (copy: dv only)
+    int rows, cols;   // weight norm: rows = dim 0, cols = the rest;  copy: cols = numel, rows = ceil(numel / 1024)
+};
+
+__device__ __forceinline__ float wg_sum256(float x, float* red) {  // all 256 threads get the total; fixed order
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void param_gather_kernel(const ParamJob* jobs, const int* start, int njobs, float* folded) {
+    __shared__ float red[4];
+    const int j = find_job(start, njobs, blockIdx.x);
+    const ParamJob q = jobs[j];
+    const int r = blockIdx.x - start[j];
+    float* dst = folded + q.dst;
+    if (!q.g) {
+        const int i = r * 1024 + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 256 < q.cols) dst[i + u * 256] = q.v[i + u * 256];
+        return;
+    }
+    const float* v = q.v + (size_t)r * q.cols;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < q.cols; c += 256) ss += v[c] * v[c];
+    ss = wg_sum256(ss, red);
+    const float sc = q.g[r] / sqrtf(ss);
+    for (int c = threadIdx.x; c < q.cols; c += 256) dst[(size_t)r * q.cols + c] = v[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void wn_backward_kernel(const ParamJob* jobs, const int* start, int njobs, const float* grads, float* raw) {
+    __shared__ float red[4];
+    const int j = find_job(start, njobs, blockIdx.x);
+    const ParamJob q = jobs[j];
+    const int r = blockIdx.x - start[j];
+    const float* dw = grads + q.dst;
+    if (!q.g) {
+        const int i = r * 1024 + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 256 < q.cols) raw[q.dv + i + u * 256] = dw[i + u * 256];
+        return;
+    }
+    const float* v = q.v + (size_t)r * q.cols;
+    dw += (size_t)r * q.cols;
+    float ss = 0.f, dot = 0.f;
+    for (int c = threadIdx.x; c < q.cols; c += 256) {
+        const float x = v[c];
+        ss += x * x;
+        dot += x * dw[c];
+    }
+    ss = wg_sum256(ss, red);
+    dot = wg_sum256(dot, red);
+    const float n = sqrtf(ss), g = q.g[r];
+    const float a = g / n, b = g * dot / (n * ss);
+    if (threadIdx.x == 0) raw[q.dg + r] = dot / n;
+    float* dv = raw + q.dv + (size_t)r * q.cols;
+    for (int c = threadIdx.x; c < q.cols; c += 256) dv[c] = a * dw[c] - b * v[c];
 }
 
 }  // namespace hificar

@@ -108,23 +108,35 @@ class _PastFCParams(torch.nn.Module):
         self.model = torch.nn.Sequential(*mods)
 
 
+def _send_parameters(module, names, tensors, stream):
+    """Hand every RAW parameter over in one call (hificar_set_parameters_device: weight norm folded and every pack refreshed on the
+    device, two launches).  Returns the tensors actually read (kept alive by the caller until the stream has consumed them)."""
+    lib, handle = module._lib, module._handle
+    held = [t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous() for t in tensors]
+    cnames = getattr(module, "_raw_cnames", None)
+    if cnames is None or cnames[0] != names:
+        arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+        cnames = module._raw_cnames = (names, arr)
+    ptrs = (ctypes.c_void_p * len(held))(*[t.data_ptr() for t in held])
+    _native.check(lib.hificar_set_parameters_device(handle, cnames[1], ptrs, len(held), stream), "hificar_set_parameters_device")
+    return held
+
+
 class _GeneratorFunction(torch.autograd.Function):
     """Autograd node of the native generator: forward = hificar_forward_train (keeps a tape), backward = hificar_backward.
 
-    Inputs after (module, c, ar, names) are the FOLDED parameters (w = v * g / ||v|| computed by torch on the device), so the
-    weight-norm re-parametrisation and its gradient stay in PyTorch's graph (hifigan.py:268-278) while every convolution,
-    activation and the PastFCEncoder — forward and backward — run in libhificar."""
+    Inputs after (module, c, ar, names) are the module's RAW parameters (weight_g / weight_v of the weight-normed convs,
+    hifigan.py:268-278; plain weights; biases): the fold w = g v / ||v||, every convolution, activation and the PastFCEncoder —
+    forward and backward, including the weight norm's chain rule — run in libhificar."""
 
     @staticmethod
-    def forward(ctx, module, c, ar, names, *weights):
+    def forward(ctx, module, c, ar, names, *params):
         lib, handle = module._lib, module._handle
         B, _, T = c.shape
         dev = c.device
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         with torch.cuda.device(dev):
-            for name, w in zip(names, weights):
-                w = w.detach().to(torch.float32).contiguous()
-                _native.check(lib.hificar_set_weight_device(handle, name.encode(), w.data_ptr(), stream), "hificar_set_weight_device")
+            held = _send_parameters(module, names, params, stream)
             tape = torch.empty(lib.hificar_tape_bytes(handle, B, T) + 256, dtype=torch.uint8, device=dev)
             toff = (-tape.data_ptr()) % 256
             out = torch.empty((B, 1, T * module.hop), dtype=torch.float32, device=dev)
@@ -133,10 +145,12 @@ class _GeneratorFunction(torch.autograd.Function):
                                            ws_ptr, ws_bytes, tape.data_ptr() + toff, tape.numel() - toff, stream)
         _native.check(rc, "hificar_forward_train")
         ctx.module, ctx.names, ctx.tape, ctx.toff, ctx.BT = module, names, tape, toff, (B, T)
-        ctx.shapes = [tuple(w.shape) for w in weights]
+        ctx.shapes = [tuple(w.shape) for w in params]
+        ctx.held = held  # the weight norm's backward reads weight_g / weight_v again
+        ctx.versions = [p._version for p in params]
+        ctx.params = params
         ctx.has_ar = ar is not None
         ctx.save_for_backward(out)
-        ctx.mark_non_differentiable()
         return out
 
     @staticmethod
@@ -147,6 +161,9 @@ class _GeneratorFunction(torch.autograd.Function):
         B, T = ctx.BT
         dev = out.device
         p = module._params
+        if any(t._version != v for t, v in zip(ctx.params, ctx.versions)):
+            raise RuntimeError("a generator parameter was modified in place between forward and backward (the weight norm's "
+                               "gradient reads weight_g / weight_v)")
         dout = dout.to(torch.float32).contiguous()
         need_c, need_ar = ctx.needs_input_grad[1], ctx.has_ar and ctx.needs_input_grad[2]
         cf = p["in_channels"] - (p["ar_output"] if module.use_ar else 0)
@@ -160,23 +177,24 @@ class _GeneratorFunction(torch.autograd.Function):
             rc = lib.hificar_backward(handle, dout.data_ptr(), out.data_ptr(), B, T, ctx.tape.data_ptr() + ctx.toff,
                                       ctx.tape.numel() - ctx.toff, grads.data_ptr(), dc.data_ptr() if dc is not None else None,
                                       dar.data_ptr() if dar is not None else None, ws.data_ptr() + woff, ws.numel() - woff, stream)
-        _native.check(rc, "hificar_backward")
+            _native.check(rc, "hificar_backward")
+            raw = torch.zeros(int(lib.hificar_raw_grad_floats(handle)), dtype=torch.float32, device=dev)
+            _native.check(lib.hificar_weight_norm_backward(handle, grads.data_ptr(), raw.data_ptr(), stream), "hificar_weight_norm_backward")
         if module._grad_sync is not None:
             # data-parallel training: ONE all-reduce (RCCL over xGMI under the "nccl" backend) of the flat buffer that holds every
-            # folded parameter's gradient — the whole generator is a single 54-MB bucket.  The weight-norm chain rule that follows
-            # is linear in these gradients, so reducing them here equals reducing the (weight_g, weight_v) gradients.
+            # parameter's gradient — the whole generator is a single 54-MB bucket.
             import torch.distributed as dist
 
             group, average = module._grad_sync
-            dist.all_reduce(grads, group=group)
+            dist.all_reduce(raw, group=group)
             if average:
-                grads.div_(dist.get_world_size(group))
-        layout = module._grad_layout()
-        gw = []
-        for name, shape in zip(ctx.names, ctx.shapes):
-            off, n = layout[name]
-            gw.append(grads[off:off + n].view(shape))
-        ctx.tape = None
+                raw.div_(dist.get_world_size(group))
+        gw, off = [], 0
+        for shape in ctx.shapes:
+            n = int(np.prod(shape))
+            gw.append(raw[off:off + n].view(shape))
+            off += (n + 3) & ~3
+        ctx.tape = ctx.held = ctx.params = None
         return (None, dc, dar, None, *gw)
 
 
@@ -405,14 +423,10 @@ class HiFiGANGenerator(torch.nn.Module):
             if getattr(self, "_param_sig", None) != self._param_signature():
                 # parameters were updated in place since the weights were handed over (optimizer.step(), p.data.copy_): re-send them
                 if self.precision == "f32" and not (self.use_spk_id or self.use_ph or self.use_ph_loss):
-                    names, tensors = self._folded_parameters()
+                    names, tensors = self._raw_parameters()
                     dev = self._device()
                     with torch.no_grad(), torch.cuda.device(dev):
-                        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-                        for name, w in zip(names, tensors):
-                            w = w.detach().to(torch.float32).contiguous()
-                            _native.check(self._lib.hificar_set_weight_device(self._handle, name.encode(), w.data_ptr(), stream),
-                                          "hificar_set_weight_device")
+                        _send_parameters(self, names, tensors, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
                     self._param_sig = self._param_signature()
                     return self._handle
                 self._invalidate()
@@ -529,21 +543,42 @@ class HiFiGANGenerator(torch.nn.Module):
             self._grad_slots = slots
         return self._grad_slots
 
-    def _folded_parameters(self):
-        """(names, tensors): every parameter in the folded form the C ABI consumes, as DIFFERENTIABLE functions of this module's
-        parameters (weight-normed convs: w = v * (g / ||v||), torch.nn.utils.weight_norm(dim=0) semantics)."""
-        names, tensors = [], []
+    def _raw_parameters(self):
+        """(names, tensors): every parameter as it sits in this module (state_dict keys: weight_g / weight_v of weight-normed convs,
+        plain weights, biases) — the form hificar_set_parameters_device consumes."""
+        cache = getattr(self, "_raw_cache", None)
+        if cache is not None:
+            cur = list(cache[2]())
+            if len(cur) == len(cache[1]) and all(t is p for t, p in zip(cache[1], cur)):
+                return cache[0], cache[1]
+
+        def current():
+            for m in mods:
+                if isinstance(m, _ConvParams):
+                    if m.has_weight_norm:
+                        yield m._parameters.get("weight_g")
+                        yield m._parameters.get("weight_v")
+                    else:
+                        yield m._parameters.get("weight")
+                    if m.bias is not None:
+                        yield m.bias
+                else:
+                    yield m.weight
+                    yield m.bias
+
+        names, mods = [], []
         for name, m in self.named_modules():
             if isinstance(m, _ConvParams):
-                names.append(name + ".weight")
-                tensors.append(_fold(m.weight_v, m.weight_g) if m.has_weight_norm else m.weight)
+                mods.append(m)
+                names += [name + ".weight_g", name + ".weight_v"] if m.has_weight_norm else [name + ".weight"]
                 if m.bias is not None:
                     names.append(name + ".bias")
-                    tensors.append(m.bias)
             elif isinstance(m, torch.nn.Linear):
+                mods.append(m)
                 names += [name + ".weight", name + ".bias"]
-                tensors += [m.weight, m.bias]
-        return names, tensors
+        tensors = list(current())
+        self._raw_cache = (tuple(names), tensors, current)
+        return self._raw_cache[0], tensors
 
     def _forward_autograd(self, c, ar):
         """Training-mode forward (train.py:276,398: y_ = generator(x, ar=ar) under autograd)."""
@@ -553,8 +588,8 @@ class HiFiGANGenerator(torch.nn.Module):
             raise RuntimeError("training runs in the exact-fp32 arithmetic: construct with precision='f32'")
         if self._handle is None:
             self._native_handle()
-        names, tensors = self._folded_parameters()
-        out = _GeneratorFunction.apply(self, c, ar, tuple(names), *tensors)
+        names, tensors = self._raw_parameters()
+        out = _GeneratorFunction.apply(self, c, ar, names, *tensors)
         self._param_sig = self._param_signature()  # the forward above handed the current weights over
         return out
 

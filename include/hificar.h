@@ -195,6 +195,13 @@ int hificar_profile_end(hificar_handle* h, hificar_kernel_stat* stats, int max_s
  *                              device on `stream` — the weights of a model in training live on the device and change every step
  *                              (the weight-norm fold w = v * g / ||v|| and its gradient stay with the caller's autograd).
  *                              After the first call the handle serves fp32 layer-by-layer kernels only.
+ *   hificar_set_parameters_device  EVERY parameter in its RAW state_dict form from device memory in one call (two launches):
+ *                              "<conv>.weight_g" + "<conv>.weight_v" for a weight-normed conv (torch.nn.utils.weight_norm, dim 0 —
+ *                              hifigan.py:268-278), "<conv>.weight" for a plain one, biases, the PastFCEncoder tensors.  The fold
+ *                              w = g v / ||v|| runs on the device into a master copy every pack is refreshed from.
+ *   hificar_weight_norm_backward  hificar_backward's folded gradients -> gradients of those raw parameters (dg, dv of the weight
+ *                              norm; the others copied): `raw_grads` holds hificar_raw_grad_floats(h) floats, one slot per entry of
+ *                              the last hificar_set_parameters_device call, in its order, each slot rounded up to 4 floats.
  *   hificar_forward_train      hificar_forward that also keeps every activation the backward pass needs in `tape`
  *                              (hificar_tape_bytes(h, B, T) bytes, 256-byte aligned, caller-owned until hificar_backward returns)
  *   hificar_backward           gradients of one hificar_forward_train: dout (B, hop*T) gradient of the waveform, out the waveform
@@ -204,6 +211,9 @@ int hificar_profile_end(hificar_handle* h, hificar_kernel_stat* stats, int max_s
  *                              workspace: hificar_backward_workspace_bytes(h, B, T) bytes.
  * --------------------------------------------------------------------------------------------------------------------------- */
 int hificar_set_weight_device(hificar_handle* h, const char* name, const float* data, void* stream);
+int hificar_set_parameters_device(hificar_handle* h, const char* const* names, const float* const* data, int n, void* stream);
+int64_t hificar_raw_grad_floats(const hificar_handle* h);
+int hificar_weight_norm_backward(hificar_handle* h, const float* grads, float* raw_grads, void* stream);
 size_t hificar_tape_bytes(const hificar_handle* h, int B, int T);
 int hificar_forward_train(hificar_handle* h, const float* c, const float* ar, float* out, int B, int T, void* workspace,
                           size_t workspace_bytes, void* tape, size_t tape_bytes, void* stream);
