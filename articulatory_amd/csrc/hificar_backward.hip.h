@@ -169,9 +169,16 @@ constexpr int kWgtR = 64;  // G rows per chunk
 
 // EXACT: the layer has exactly NT taps (no per-tap branch in the K loop: the operand reads of the next row pair are in flight while this
 // pair's MFMAs issue); otherwise ntaps < NT and the surplus taps are skipped.
+// Up to two layers of the same tap count per launch (blockIdx.z): conv2 and conv1 of a ResBlock slot have independent weight gradients,
+// and one launch with half the row splits each fills the chip with half the partial sums to write and reduce.
+struct WgradTapsPair {
+    WgradTapsParams q[2];
+};
+
 template <int NT, bool EXACT>
-__global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsParams q) {
+__global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pair) {
     extern __shared__ __attribute__((aligned(1024))) char wgt_smem[];
+    const WgradTapsParams& q = pair.q[blockIdx.z];
     const WgradParams& p = q.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hf = lane >> 5;
@@ -322,7 +329,12 @@ struct WreduceParams {
     int flip;  // 0
 };
 
-__global__ __launch_bounds__(256) void wreduce_kernel(const WreduceParams p) {
+struct WreducePair {
+    WreduceParams r[2];
+};
+
+__global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
+    const WreduceParams& p = pair.r[blockIdx.y];
     // one thread: 4 consecutive a of one (tap, g); the splits in four interleaved running sums, combined in a fixed order
     const int a4n = p.apad >> 2;
     const int total4 = p.ntaps * p.gpad * a4n;
@@ -398,7 +410,13 @@ struct BreduceParams {
 };
 
 // 16 channels x 16 strands per workgroup: strand j sums terms j, j + 16, ... (four loads in flight), the strands are added in a fixed order
-__global__ __launch_bounds__(256) void breduce_kernel(const BreduceParams p) {
+struct BreducePair {
+    BreduceParams b[2];
+};
+
+__global__ __launch_bounds__(256) void breduce_kernel(const BreducePair pair) {
+    const BreduceParams& p = pair.b[blockIdx.y];
+    if (!p.dst) return;
     __shared__ float red[16][17];
     const int cl = threadIdx.x & 15, jl = threadIdx.x >> 4;
     const int co = blockIdx.x * 16 + cl;

@@ -91,11 +91,13 @@ def test_full_model_real_slope_vs_fp64_oracle():
     assert max(e_dev.values()) < 0.1, max(e_dev.items(), key=lambda kv: kv[1])
 
 
-def test_gradients_vs_oracle_every_element():
+@pytest.mark.parametrize("weight_norm", [True, False])
+def test_gradients_vs_oracle_every_element(weight_norm):
     """Every element of every gradient against the CPU oracle's autograd (the golden fixtures hold samples of the big tensors),
-    on a configuration with odd strides, two ResBlocks of unequal depth and no ResBlock bias."""
+    on a configuration with odd strides, two ResBlocks of unequal depth and no ResBlock bias — with the weight norm folded and
+    differentiated on the device (weight_g / weight_v parameters) and with plain weights (use_weight_norm=False)."""
     params = dict(E2W_PARAMS, channels=128, upsample_scales=[3, 2], upsample_kernel_sizes=[6, 4], resblock_kernel_sizes=[5, 9],
-                  resblock_dilations=[[1, 2, 4], [3]], bias=False, in_channels=20 + 128)
+                  resblock_dilations=[[1, 2, 4], [3]], bias=False, in_channels=20 + 128, use_weight_norm=weight_norm)
     g, sd = build(params, 55)
     B, T = 2, 17
     c_np = synth_features(B, T, 20, seed=5).transpose(0, 2, 1).copy()
