@@ -22,6 +22,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--frames", type=int, default=25)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--profile", action="store_true")
+ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the default foreach implementation")
 ap.add_argument("--torch-profile", action="store_true", help="torch.profiler table of one step (torch-side kernels around the native path)")
 a = ap.parse_args()
 params = dict(CAR_PARAMS)
@@ -29,7 +30,7 @@ sd = synth_state_dict(params, seed=1234)
 g = HiFiGANGenerator(**params, precision="f32")
 g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
 g = g.train().cuda()
-opt = torch.optim.Adam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
+opt = torch.optim.Adam(g.parameters(), lr=1e-4, betas=(0.5, 0.9), fused=True if a.fused_adam else None)
 c = torch.from_numpy(synth_features(a.batch, a.frames, 13, seed=1)).permute(0, 2, 1).contiguous().cuda()
 ar = torch.zeros(a.batch, 1, 512, device="cuda")
 target = torch.rand(a.batch, 1, 80 * a.frames, device="cuda") - 0.5
