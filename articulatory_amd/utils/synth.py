@@ -191,3 +191,121 @@ def synth_features(batch: int, frames: int, dims: int, seed: int) -> np.ndarray:
     x = rng.standard_normal((batch, frames, dims)).astype(np.float32)
     x[:, :, 0] = rng.random((batch, frames)).astype(np.float32)
     return x
+
+
+# ------------------------------------------------------------------------------------------------
+# HiFiGANMultiScaleMultiPeriodDiscriminator (reference articulatory/models/hifigan.py:317-825)
+# ------------------------------------------------------------------------------------------------
+DISC_DEFAULTS = dict(
+    scales=3,
+    scale_downsample_pooling="AvgPool1d",
+    scale_downsample_pooling_params={"kernel_size": 4, "stride": 2, "padding": 2},
+    scale_discriminator_params={
+        "in_channels": 1, "out_channels": 1, "kernel_sizes": [15, 41, 5, 3], "channels": 128, "max_downsample_channels": 1024,
+        "max_groups": 16, "bias": True, "downsample_scales": [2, 2, 4, 4, 1], "nonlinear_activation": "LeakyReLU",
+        "nonlinear_activation_params": {"negative_slope": 0.1},
+    },
+    follow_official_norm=True,
+    periods=[2, 3, 5, 7, 11],
+    period_discriminator_params={
+        "in_channels": 1, "out_channels": 1, "kernel_sizes": [5, 3], "channels": 32, "downsample_scales": [3, 3, 3, 3, 1],
+        "max_downsample_channels": 1024, "bias": True, "nonlinear_activation": "LeakyReLU",
+        "nonlinear_activation_params": {"negative_slope": 0.1}, "use_weight_norm": True, "use_spectral_norm": False,
+    },
+)
+
+
+def disc_params(**kw):
+    """discriminator_params of a YAML config merged over the reference's defaults (hifigan.py:744-781)."""
+    p = {k: (dict(v) if isinstance(v, dict) else v) for k, v in DISC_DEFAULTS.items()}
+    for k, v in kw.items():
+        if k not in p:
+            raise TypeError(f"unexpected discriminator parameter {k!r}")
+        p[k] = dict(v) if isinstance(v, dict) else v
+    return p
+
+
+def scale_disc_layers(in_channels=1, out_channels=1, kernel_sizes=(15, 41, 5, 3), channels=128, max_downsample_channels=1024,
+                      max_groups=16, bias=True, downsample_scales=(2, 2, 4, 4, 1), **_ignored):
+    """Conv1d layers of one HiFiGANScaleDiscriminator (hifigan.py:549-617): dicts of cin, cout, k, stride, groups, act."""
+    assert len(kernel_sizes) == 4 and all(k % 2 == 1 for k in kernel_sizes)
+    layers = [dict(cin=in_channels, cout=channels, k=kernel_sizes[0], stride=1, groups=1, act=True, bias=bias)]
+    in_chs, out_chs, groups = channels, channels, 4
+    for s in downsample_scales:
+        layers.append(dict(cin=in_chs, cout=out_chs, k=kernel_sizes[1], stride=s, groups=groups, act=True, bias=bias))
+        in_chs = out_chs
+        out_chs = min(in_chs * 2, max_downsample_channels)
+        groups = min(groups * 4, max_groups)
+    out_chs = min(in_chs * 2, max_downsample_channels)
+    layers.append(dict(cin=in_chs, cout=out_chs, k=kernel_sizes[2], stride=1, groups=1, act=True, bias=bias))
+    layers.append(dict(cin=out_chs, cout=out_channels, k=kernel_sizes[3], stride=1, groups=1, act=False, bias=bias))
+    for L in layers:
+        L["pad"] = (L["k"] - 1) // 2
+    return layers
+
+
+def period_disc_layers(in_channels=1, out_channels=1, kernel_sizes=(5, 3), channels=32, downsample_scales=(3, 3, 3, 3, 1),
+                       max_downsample_channels=1024, bias=True, **_ignored):
+    """Conv2d (k, 1) layers of one HiFiGANPeriodDiscriminator (hifigan.py:357-389).  NB the output conv's kernel is
+    kernel_sizes[1] - 1 with padding (kernel_sizes[1] - 1) // 2 (:383-389), and every Conv2d has a bias whatever ``bias`` says."""
+    assert len(kernel_sizes) == 2 and kernel_sizes[0] % 2 == 1 and kernel_sizes[1] % 2 == 1
+    layers = []
+    in_chs, out_chs = in_channels, channels
+    for s in downsample_scales:
+        layers.append(dict(cin=in_chs, cout=out_chs, k=kernel_sizes[0], stride=s, groups=1, act=True, bias=True,
+                           pad=(kernel_sizes[0] - 1) // 2))
+        in_chs = out_chs
+        out_chs = min(out_chs * 4, max_downsample_channels)
+    layers.append(dict(cin=out_chs, cout=out_channels, k=kernel_sizes[1] - 1, stride=1, groups=1, act=False, bias=True,
+                       pad=(kernel_sizes[1] - 1) // 2))
+    return layers
+
+
+def disc_param_spec(**kw):
+    """Ordered {state_dict key: shape} of HiFiGANMultiScaleMultiPeriodDiscriminator(**kw) (checked key-for-key against the real
+    reference by tests/test_oracle_golden.py through the fixture of oracle/make_golden_disc.py).  The scale discriminators never
+    get a norm (their apply_weight_norm / apply_spectral_norm test for Conv2d on a Conv1d stack, hifigan.py:645-663): plain
+    weights.  The period discriminators are weight-normed Conv2d (bias, weight_g, weight_v)."""
+    p = disc_params(**kw)
+    spec = OrderedDict()
+    for i in range(p["scales"]):
+        layers = scale_disc_layers(**p["scale_discriminator_params"])
+        for l, L in enumerate(layers):
+            base = f"msd.discriminators.{i}.layers.{l}" + (".0" if L["act"] else "")
+            spec[base + ".weight"] = (L["cout"], L["cin"] // L["groups"], L["k"])
+            if L["bias"]:
+                spec[base + ".bias"] = (L["cout"],)
+    pp = p["period_discriminator_params"]
+    wn = pp.get("use_weight_norm", True)
+    if pp.get("use_spectral_norm", False):
+        raise NotImplementedError("spectral norm on the period discriminators is not built")
+    for i, _period in enumerate(p["periods"]):
+        layers = period_disc_layers(**pp)
+        for l, L in enumerate(layers):
+            base = f"mpd.discriminators.{i}." + (f"convs.{l}.0" if L["act"] else "output_conv")
+            spec[base + ".bias"] = (L["cout"],)
+            shape = (L["cout"], L["cin"], L["k"], 1)
+            if wn:
+                spec[base + ".weight_g"] = (L["cout"], 1, 1, 1)
+                spec[base + ".weight_v"] = shape
+            else:
+                spec[base + ".weight"] = shape
+    return spec
+
+
+def synth_disc_state_dict(discriminator_params: dict, seed: int = 4321, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """Synthetic discriminator state_dict (same recipe as synth_state_dict)."""
+    spec = disc_param_spec(**discriminator_params)
+    out = OrderedDict()
+    for name, shape in spec.items():
+        if name.endswith(".weight_v") or name.endswith(".weight"):
+            b = gain * np.sqrt(3.0 / int(np.prod(shape[1:])))
+            out[name] = uniform(seed, name, shape, -b, b)
+        elif name.endswith(".bias"):
+            out[name] = uniform(seed, name, shape, -0.05, 0.05)
+    for name, shape in spec.items():
+        if name.endswith(".weight_g"):
+            v = out[name[: -len("weight_g")] + "weight_v"].astype(np.float64)
+            norm = np.sqrt((v.reshape(v.shape[0], -1) ** 2).sum(axis=1)).reshape(shape)
+            out[name] = (norm * uniform(seed, name, shape, 0.8, 1.2).astype(np.float64)).astype(np.float32)
+    return OrderedDict((k, out[k]) for k in spec)

@@ -1,0 +1,139 @@
+"""The discriminator / GAN-loss oracle (oracle/disc_oracle.py) against golden vectors of the REAL reference
+(tests/golden/gold_disc_*.npz, written by oracle/make_golden_disc.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from articulatory_amd.utils.synth import disc_param_spec, synth_disc_state_dict, uniform
+from oracle import disc_oracle as DO
+from oracle import hificar_oracle as O
+from oracle.make_golden_disc import SMALL
+
+TOL = 2e-5
+
+
+def case_params(tag):
+    if tag == "small":
+        return SMALL
+    import yaml
+
+    # the shipped e2w_hifigan_car.yaml discriminator_params (restated: /root/reference is not available where tests run)
+    return yaml.safe_load("""
+scales: 3
+scale_downsample_pooling: "AvgPool1d"
+scale_downsample_pooling_params: {kernel_size: 4, stride: 2, padding: 2}
+scale_discriminator_params:
+    in_channels: 1
+    out_channels: 1
+    kernel_sizes: [15, 41, 5, 3]
+    channels: 128
+    max_downsample_channels: 1024
+    max_groups: 16
+    bias: true
+    downsample_scales: [4, 4, 4, 4, 1]
+    nonlinear_activation: "LeakyReLU"
+    nonlinear_activation_params: {negative_slope: 0.1}
+follow_official_norm: true
+periods: [2, 3, 5, 7, 11]
+period_discriminator_params:
+    in_channels: 1
+    out_channels: 1
+    kernel_sizes: [5, 3]
+    channels: 32
+    downsample_scales: [3, 3, 3, 3, 1]
+    max_downsample_channels: 1024
+    bias: true
+    nonlinear_activation: "LeakyReLU"
+    nonlinear_activation_params: {negative_slope: 0.1}
+    use_weight_norm: true
+""")
+
+
+def load(tag):
+    gold = np.load(os.path.join(GOLDEN, f"gold_disc_{tag}.npz"))
+    params = case_params(tag)
+    seed, B, T = int(gold["seed"]), int(gold["B"]), int(gold["T"])
+    sd = synth_disc_state_dict(params, seed=seed)
+    x = uniform(seed, "x", (B, 1, T), -0.6, 0.6)
+    xh = uniform(seed, "x_hat", (B, 1, T), -0.6, 0.6)
+    return gold, params, sd, x, xh, seed
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_state_dict_layout_matches_reference(tag):
+    gold, params, sd, *_ = load(tag)
+    spec = disc_param_spec(**params)
+    assert list(spec) == [str(k) for k in gold["keys"]]
+    assert [str(tuple(v)) for v in spec.values()] == [str(s) for s in gold["shapes"]]
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_forward_and_gradients_vs_reference(tag):
+    gold, params, sd, x, _, seed = load(tag)
+    n_layers = [int(n) for n in gold["n_layers"]]
+    cots = [[uniform(seed, f"cot.{i}.{l}", tuple(int(v) for v in gold[f"shape::{i}.{l}"]), -1.0, 1.0)
+             / np.sqrt(np.prod(gold[f"shape::{i}.{l}"][1:])) for l in range(n)] for i, n in enumerate(n_layers)]
+    outs, grads = DO.disc_gradients(sd, params, x, cots)
+    assert [len(o) for o in outs] == n_layers
+    for i, o in enumerate(outs):
+        for l, t in enumerate(o):
+            assert tuple(t.shape) == tuple(gold[f"shape::{i}.{l}"])
+            assert O.check_packed(gold, f"out::{i}.{l}", t, TOL) < TOL, (i, l)
+    bad = {k: O.check_packed(gold, "grad::" + k, g, 1e-4) for k, g in grads.items()}
+    bad = {k: v for k, v in bad.items() if v >= 1e-4}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_losses_vs_reference(tag):
+    gold, params, sd, x, xh, _ = load(tag)
+    w = DO.fold_disc_weight_norm(sd)
+    with torch.no_grad():
+        real = DO.disc_forward(w, params, torch.from_numpy(x))
+        fake = DO.disc_forward(w, params, torch.from_numpy(xh))
+
+    def close(a, key):
+        ref = float(gold[key])
+        assert abs(float(a) - ref) <= 2e-5 * max(abs(ref), 1e-3), (key, float(a), ref)
+
+    for avg in (False, True):
+        for lt in ("mse", "hinge"):
+            close(DO.gen_adv_loss(fake, avg, lt), f"loss::gen_adv::{lt}::{int(avg)}")
+            r, f = DO.dis_adv_loss(fake, real, avg, lt)
+            close(r, f"loss::dis_real::{lt}::{int(avg)}")
+            close(f, f"loss::dis_fake::{lt}::{int(avg)}")
+        for inc in (False, True):
+            close(DO.feat_match_loss(fake, real, avg, avg, inc), f"loss::feat_match::{int(avg)}::{int(inc)}")
+
+
+def test_mel_filterbank_and_spectrogram_against_float64_dft():
+    """librosa is not in this image (the reference's MelSpectrogram cannot be constructed): the restated Slaney filterbank is checked
+    for its defining properties, and the STFT path against a direct float64 DFT of the same frames."""
+    fb = DO.mel_filterbank(16000, 1024, 80, 0, 11025)  # e2w_hifigan_car.yaml:103-111 (fmax above Nyquist, as shipped)
+    assert fb.shape == (80, 513) and (fb >= 0).all()
+    peaks = fb.argmax(axis=1)
+    live = fb.sum(axis=1) > 0
+    assert live[:60].all() and (np.diff(peaks[live]) >= 0).all()
+    # slaney norm: every complete triangle has area 2 / width * width / 2 = 1 in Hz
+    df = 8000.0 / 512
+    areas = fb.sum(axis=1) * df
+    assert np.allclose(areas[5:55], 1.0, atol=0.08)
+    rng = np.random.default_rng(3)
+    y = (rng.standard_normal((2, 2000)) * 0.1).astype(np.float32)
+    kw = dict(fs=16000, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=0, fmax=11025, log_base=None)
+    got = DO.mel_spectrogram(torch.from_numpy(y), **kw).numpy()
+    # direct restatement: reflect-pad n_fft // 2, periodic hann, frames at hop, |DFT|, filterbank, log
+    pad = np.pad(y.astype(np.float64), ((0, 0), (512, 512)), mode="reflect")
+    n = np.arange(1024)
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * n / 1024)
+    frames = 1 + 2000 // 256
+    ref = np.zeros((2, 80, frames))
+    for t in range(frames):
+        seg = pad[:, t * 256 : t * 256 + 1024] * win
+        amp = np.sqrt(np.maximum(np.abs(np.fft.rfft(seg, axis=1)) ** 2, 1e-10))
+        ref[:, :, t] = np.log(np.maximum(amp @ fb.T.astype(np.float64), 1e-10))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-3  # log-mel of fp32 STFT vs float64
