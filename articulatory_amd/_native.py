@@ -42,6 +42,21 @@ SYMBOLS = (
     "hificar_set_parameters_device",
     "hificar_raw_grad_floats",
     "hificar_weight_norm_backward",
+    "hificar_disc_create",
+    "hificar_disc_destroy",
+    "hificar_disc_engine",
+    "hificar_disc_param_count",
+    "hificar_disc_param_info",
+    "hificar_disc_grad_floats",
+    "hificar_disc_raw_grad_floats",
+    "hificar_disc_set_parameters_device",
+    "hificar_disc_weight_norm_backward",
+    "hificar_disc_tape_bytes",
+    "hificar_disc_backward_workspace_bytes",
+    "hificar_disc_output_count",
+    "hificar_disc_output_info",
+    "hificar_disc_forward",
+    "hificar_disc_backward",
     "hificar_tape_bytes",
     "hificar_forward_train",
     "hificar_backward_workspace_bytes",
@@ -84,6 +99,55 @@ class HificarConfig(ctypes.Structure):
         ("num_ph", ctypes.c_int32),
         ("ph_emb_size", ctypes.c_int32),
         ("use_ph_loss", ctypes.c_int32),
+    ]
+
+
+DISC_MAX_SUBS = 8
+DISC_MAX_LAYERS = 12
+_LAY = ctypes.c_int32 * DISC_MAX_LAYERS
+
+
+class HificarDiscConfig(ctypes.Structure):
+    """hificar_disc_config (include/hificar.h)."""
+
+    _fields_ = [
+        ("n_scales", ctypes.c_int32),
+        ("pool_kernel", ctypes.c_int32),
+        ("pool_stride", ctypes.c_int32),
+        ("pool_pad", ctypes.c_int32),
+        ("s_n_layers", ctypes.c_int32),
+        ("s_cin", _LAY),
+        ("s_cout", _LAY),
+        ("s_k", _LAY),
+        ("s_stride", _LAY),
+        ("s_pad", _LAY),
+        ("s_groups", _LAY),
+        ("s_bias", ctypes.c_int32),
+        ("s_slope", ctypes.c_float),
+        ("n_periods", ctypes.c_int32),
+        ("periods", ctypes.c_int32 * DISC_MAX_SUBS),
+        ("p_n_layers", ctypes.c_int32),
+        ("p_cin", _LAY),
+        ("p_cout", _LAY),
+        ("p_k", _LAY),
+        ("p_stride", _LAY),
+        ("p_pad", _LAY),
+        ("p_slope", ctypes.c_float),
+    ]
+
+
+class HificarDiscOutput(ctypes.Structure):
+    _fields_ = [
+        ("sub", ctypes.c_int32),
+        ("layer", ctypes.c_int32),
+        ("group", ctypes.c_int32),
+        ("n_groups", ctypes.c_int32),
+        ("period", ctypes.c_int32),
+        ("offset_bytes", ctypes.c_int64),
+        ("nseq", ctypes.c_int32),
+        ("rows", ctypes.c_int32),
+        ("pitch", ctypes.c_int32),
+        ("channels", ctypes.c_int32),
     ]
 
 
@@ -153,6 +217,37 @@ def load_library():
     lib.hificar_raw_grad_floats.restype = ctypes.c_int64
     lib.hificar_weight_norm_backward.argtypes = [vp, vp, vp, vp]
     lib.hificar_weight_norm_backward.restype = ctypes.c_int
+    ci, cs, c64 = ctypes.c_int, ctypes.c_size_t, ctypes.c_int64
+    lib.hificar_disc_create.argtypes = [ctypes.POINTER(HificarDiscConfig), ctypes.POINTER(vp)]
+    lib.hificar_disc_create.restype = ci
+    lib.hificar_disc_destroy.argtypes = [vp]
+    lib.hificar_disc_destroy.restype = None
+    lib.hificar_disc_engine.argtypes = [vp]
+    lib.hificar_disc_engine.restype = vp
+    lib.hificar_disc_param_count.argtypes = [vp]
+    lib.hificar_disc_param_count.restype = ci
+    lib.hificar_disc_param_info.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(c64), ctypes.POINTER(ci), ctypes.POINTER(c64)]
+    lib.hificar_disc_param_info.restype = ci
+    lib.hificar_disc_grad_floats.argtypes = [vp]
+    lib.hificar_disc_grad_floats.restype = c64
+    lib.hificar_disc_raw_grad_floats.argtypes = [vp]
+    lib.hificar_disc_raw_grad_floats.restype = c64
+    lib.hificar_disc_set_parameters_device.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp), ci, vp]
+    lib.hificar_disc_set_parameters_device.restype = ci
+    lib.hificar_disc_weight_norm_backward.argtypes = [vp, vp, vp, vp]
+    lib.hificar_disc_weight_norm_backward.restype = ci
+    lib.hificar_disc_tape_bytes.argtypes = [vp, ci, ci]
+    lib.hificar_disc_tape_bytes.restype = cs
+    lib.hificar_disc_backward_workspace_bytes.argtypes = [vp, ci, ci]
+    lib.hificar_disc_backward_workspace_bytes.restype = cs
+    lib.hificar_disc_output_count.argtypes = [vp]
+    lib.hificar_disc_output_count.restype = ci
+    lib.hificar_disc_output_info.argtypes = [vp, ci, ci, ci, ctypes.POINTER(HificarDiscOutput)]
+    lib.hificar_disc_output_info.restype = ci
+    lib.hificar_disc_forward.argtypes = [vp, vp, ci, ci, vp, cs, vp]
+    lib.hificar_disc_forward.restype = ci
+    lib.hificar_disc_backward.argtypes = [vp, ctypes.POINTER(vp), ci, ci, vp, cs, vp, vp, vp, cs, vp]
+    lib.hificar_disc_backward.restype = ci
     lib.hificar_tape_bytes.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.hificar_tape_bytes.restype = ctypes.c_size_t
     lib.hificar_forward_train.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]

@@ -4,6 +4,7 @@
 // enqueues the forward pass / the batched autoregressive loop on the caller's HIP stream.
 #include "hificar_kernels.hip.h"
 #include "hificar_backward.hip.h"
+#include "hificar_disc_kernels.hip.h"
 
 #include "../../include/hificar.h"
 
@@ -570,6 +571,42 @@ static hipError_t set_lds_attr_f() {
 // split-K forms: (MI, NC16)
 #define HIFICAR_FOR_SK_TILES(X) X(1, 1) X(2, 1) X(4, 1) X(1, 2) X(2, 2) X(4, 2) X(1, 4) X(2, 4) X(4, 4)
 
+// Device-side state every launch needs, whatever network the handle holds (the generator, or the discriminators' engine handle):
+// the zero page of the LDS DMA, the kernels' dynamic-LDS attributes, the first schedule arena.
+static int engine_setup(hificar_handle* h) {
+    {
+        void* z = nullptr;
+        HIP_TRY(hipMalloc(&z, 256));
+        h->allocs.push_back(z);
+        HIP_TRY(hipMemset(z, 0, 256));
+        h->d_zeros = static_cast<char*>(z);
+    }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 2, 2, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 4, 1, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<4, 2, 2, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<4, 4, 1, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define HIFICAR_SET_ATTR(mi, wm, wn, nc)         \
+    HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>())); \
+    HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>()));
+    HIFICAR_FOR_ALL_TILES(HIFICAR_SET_ATTR)
+#undef HIFICAR_SET_ATTR
+#define HIFICAR_SET_ATTR_SK(mi, nc)                                                                                              \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_bf16x3_kernel<mi, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                160 * 1024));                                                                                  \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_f32_kernel<mi, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIFICAR_FOR_SK_TILES(HIFICAR_SET_ATTR_SK)
+#undef HIFICAR_SET_ATTR_SK
+    if (h->arenas.empty()) {
+        int rca = arena_add(h, 0);
+        if (rca != HIFICAR_OK) return rca;
+    }
+    return HIFICAR_OK;
+}
+
 extern "C" int hificar_finalize(hificar_handle* h) {
     if (!h) return fail(HIFICAR_E_INVALID, "hificar_finalize: null handle");
     if (h->finalized) return HIFICAR_OK;
@@ -613,36 +650,7 @@ extern "C" int hificar_finalize(hificar_handle* h) {
         if ((rc = upload(h, h->tensors.at("ph_fc.weight").data, &h->d_phfc_w)) != HIFICAR_OK) return rc;
         if ((rc = upload(h, h->tensors.at("ph_fc.bias").data, &h->d_phfc_b)) != HIFICAR_OK) return rc;
     }
-    {
-        void* z = nullptr;
-        HIP_TRY(hipMalloc(&z, 256));
-        h->allocs.push_back(z);
-        HIP_TRY(hipMemset(z, 0, 256));
-        h->d_zeros = static_cast<char*>(z);
-    }
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 2, 2, 4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 4, 1, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<4, 2, 2, 4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<4, 4, 1, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#define HIFICAR_SET_ATTR(mi, wm, wn, nc)         \
-    HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>())); \
-    HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>()));
-    HIFICAR_FOR_ALL_TILES(HIFICAR_SET_ATTR)
-#undef HIFICAR_SET_ATTR
-#define HIFICAR_SET_ATTR_SK(mi, nc)                                                                                              \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_bf16x3_kernel<mi, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                160 * 1024));                                                                                  \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_f32_kernel<mi, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIFICAR_FOR_SK_TILES(HIFICAR_SET_ATTR_SK)
-#undef HIFICAR_SET_ATTR_SK
-    if (h->arenas.empty()) {
-        int rca = arena_add(h, 0);
-        if (rca != HIFICAR_OK) return rca;
-    }
+    if ((rc = engine_setup(h)) != HIFICAR_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
     h->tensors.clear();  // host copies no longer needed
     h->finalized = true;
@@ -1730,3 +1738,4 @@ extern "C" int hificar_pcm16(const float* x, int16_t* y, size_t n, void* stream)
 }
 
 #include "hificar_train.hip.inc"
+#include "hificar_disc.hip.inc"

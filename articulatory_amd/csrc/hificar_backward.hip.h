@@ -327,6 +327,7 @@ struct WreduceParams {
     int transposed, n_phase, cout_pad;
     int tap_k[kMaxPhase][kMaxTaps];
     int flip;  // 0
+    int gemm_cin;  // > 0: GEMM form of a conv (discriminators): a = tap * gemm_cin + c -> dst[(co * gemm_cin + c) * K + tap]
 };
 
 struct WreducePair {
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
             if (k < 0) continue;
         }
         if (co >= p.cout) continue;
+        if (p.gemm_cin > 0 && a >= p.gemm_cin * p.K) continue;
         const float4* src = reinterpret_cast<const float4*>(p.partial) + i;
         const size_t stride = total / 4;
         float4 s[4];
@@ -375,7 +377,12 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (a + j >= p.cin) break;
-            const size_t d = p.transposed ? ((size_t)(a + j) * p.cout + co) * p.K + k : ((size_t)co * p.cin + a + j) * p.K + k;
+            size_t d = p.transposed ? ((size_t)(a + j) * p.cout + co) * p.K + k : ((size_t)co * p.cin + a + j) * p.K + k;
+            if (p.gemm_cin > 0) {
+                const int tap = (a + j) / p.gemm_cin, c = (a + j) - tap * p.gemm_cin;
+                if (tap >= p.K) break;
+                d = ((size_t)co * p.gemm_cin + c) * p.K + tap;
+            }
             p.dst[d] = o[j];
         }
     }
@@ -705,9 +712,11 @@ struct PackParams {
 //   mode 5  transpose (rows = cout, cols = cin) -> (cols, rows)   (PastFCEncoder weights)
 //   mode 6  bias replicated over the phases: dst[r * cout_pad + co] = src[co], total = n_phase * cout
 //   mode 7  plain copy
+//   modes 8 / 9  GEMM form of a (grouped, strided) conv and of its data gradient, src (cout_g, cin_g, k) of one group: the im2col
+//           column j = tap * cin_g + c is the packed layer's input channel (8) / output channel (9)   (hificar_disc_kernels.hip.h)
 __device__ __forceinline__ void pack_w32_body(const PackParams& p, long long first, long long step) {
     for (long long i = first; i < p.total; i += step) {
-        if (p.mode >= 4) {
+        if (p.mode >= 4 && p.mode <= 7) {
             if (p.mode == 4) {
                 const int k = (int)(i / p.cout_pad), c = (int)(i - (long long)k * p.cout_pad);
                 p.dst[i] = c < p.cin ? p.src[(size_t)c * p.K + k] : 0.f;
@@ -749,6 +758,12 @@ __device__ __forceinline__ void pack_w32_body(const PackParams& p, long long fir
                     if (k >= 0) val = p.src[((size_t)ci * p.cout + co) * p.K + k];
                 } else if (p.mode == 2) {
                     val = p.src[((size_t)ci * p.cin + co) * p.K + (p.K - 1 - t)];
+                } else if (p.mode == 8) {  // GEMM form of a conv (discriminators): input column j = tap * cin + c
+                    const int tap = ci / p.cin, c = ci - tap * p.cin;
+                    val = p.src[((size_t)co * p.cin + c) * p.K + tap];
+                } else if (p.mode == 9) {  // its data gradient: output column j = tap * cin + c, input channel = the conv's output channel
+                    const int tap = co / p.cin, c = co - tap * p.cin;
+                    val = p.src[((size_t)ci * p.cin + c) * p.K + tap];
                 } else {
                     const int rr = ci / p.cout_pad, cc = ci - rr * p.cout_pad;  // virtual input channel -> (phase r, real co)
                     const int k = rr + p.stride * (p.jmin + t) + p.pad;

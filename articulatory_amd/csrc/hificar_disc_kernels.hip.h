@@ -1,0 +1,187 @@
+// Discriminator kernels of libhificar (HiFiGANMultiScaleMultiPeriodDiscriminator, reference articulatory/models/hifigan.py:317-825):
+// every Conv1d / Conv2d (k, 1) of the discriminators runs as ONE GEMM per group on the generator's exact-fp32 conv kernels
+// (conv_f32_kernel with a single tap: A [M][Kg] x W [Kg][N]) over an im2col matrix whose rows are ALL output positions of ALL sequences
+// — the period discriminators' columns are 3..1260-row sequences (B x period of them), far too short to tile one by one.  This file holds
+// the gathers around those GEMMs; all of them are HBM-bound element-wise passes.
+//   im2col_kernel        A[m = (seq, t_out)][j = tap * cin_g + c] = in[seq][t_out * stride + tap - pad][ci0 + c]   (0 outside)
+//                        `in` = the raw signal (scale form, or period form with the reference's reflect padding) or the previous
+//                        layer's activated output (one [M][Np] buffer per group)
+//   col2im_mask_kernel   backward of im2col fused with LeakyReLU' and the loss's own gradient of that feature map:
+//                        dZ_prev[m][n] = (dY_prev[m][n] + sum_{taps} dA[(seq, t_out)][tap * cin_g + c]) * lrelu'(Y_prev[m][n])
+//   signal_grad_kernel   the same gather for layer 0: gradient of the raw signal (reflect padding folded back), accumulated over the
+//                        sub-discriminators in launch order (deterministic)
+//   avgpool_kernel / avgpool_bwd_kernel   AvgPool1d(kernel, stride, padding), count_include_pad (hifigan.py:700-738)
+#pragma once
+
+namespace hificar {
+
+struct Im2colParams {
+    const float* src;
+    float* dst;       // [M][Kg_pad]
+    long long total4; // M * Kg_pad / 4
+    int Kg, Kg_pad;
+    int L_in, L_out;  // rows per sequence
+    int kt, stride, pad, cin_g;
+    int src_mode;     // 0 raw signal, scale form: seq = b;  1 raw signal, period form: seq = (b, col);  2 previous layer
+    int T, period;    // raw signal length (unpadded); period
+    int ci0;          // first input channel of this group
+    int prev_cout_g, prev_np;
+    long long prev_gstride;  // floats between the previous layer's group buffers
+};
+
+__device__ __forceinline__ float im2col_fetch(const Im2colParams& p, int seq, int t, int c) {
+    if (t < 0 || t >= p.L_in) return 0.f;
+    if (p.src_mode == 0) return p.src[(size_t)seq * p.T + t];
+    if (p.src_mode == 1) {
+        const int b = seq / p.period, col = seq - b * p.period;
+        int idx = t * p.period + col;
+        if (idx >= p.T) idx = 2 * (p.T - 1) - idx;  // F.pad(..., "reflect") on the right (hifigan.py:404-407)
+        return p.src[(size_t)b * p.T + idx];
+    }
+    const int ca = p.ci0 + c;
+    const int g = ca / p.prev_cout_g, n = ca - g * p.prev_cout_g;
+    return p.src[(size_t)g * p.prev_gstride + ((size_t)seq * p.L_in + t) * p.prev_np + n];
+}
+
+__global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
+    const int k4 = p.Kg_pad >> 2;
+    const bool vec = p.src_mode == 2 && (p.cin_g & 3) == 0 && (p.prev_cout_g & 3) == 0 && (p.ci0 & 3) == 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total4; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / k4), j = (int)(i - (long long)m * k4) * 4;
+        const int seq = m / p.L_out, to = m - seq * p.L_out;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j < p.Kg) {
+            if (vec) {
+                const int tap = j / p.cin_g, c = j - tap * p.cin_g;
+                const int t = to * p.stride + tap - p.pad;
+                if (t >= 0 && t < p.L_in) {
+                    const int ca = p.ci0 + c;
+                    const int g = ca / p.prev_cout_g, n = ca - g * p.prev_cout_g;
+                    v = *reinterpret_cast<const f32x4*>(p.src + (size_t)g * p.prev_gstride + ((size_t)seq * p.L_in + t) * p.prev_np + n);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u;
+                    if (jj < p.Kg) {
+                        const int tap = jj / p.cin_g, c = jj - tap * p.cin_g;
+                        v[u] = im2col_fetch(p, seq, to * p.stride + tap - p.pad, c);
+                    }
+                }
+            }
+        }
+        reinterpret_cast<f32x4*>(p.dst)[i] = v;
+    }
+}
+
+// dZ of the PREVIOUS layer (one launch per previous-layer group buffer) from this layer's dA buffers.
+struct Col2imParams {
+    const float* dA;        // this layer's dA buffers: group g at dA + g * da_gstride, [M][Kg_pad]
+    long long da_gstride;
+    const float* dy;        // the loss's gradient of the previous layer's output buffer [Mp][Np] or nullptr
+    const float* y;         // the previous layer's activated output [Mp][Np]
+    float* dz;              // out [Mp][Np]
+    long long total;        // Mp * Np
+    int np, cout_g_prev, c0_prev;  // previous layer's pitch / channels per group / first channel of THIS previous-layer group
+    int L_in, L_out;        // rows per sequence of the previous layer's output (= this layer's input) / of this layer's output
+    int kt, stride, pad, cin_g, Kg_pad;
+    float slope;
+};
+
+__global__ __launch_bounds__(256) void col2im_mask_kernel(const Col2imParams p) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int mp = (int)(i / p.np), n = (int)(i - (long long)mp * p.np);
+        float r = 0.f;
+        if (n < p.cout_g_prev) {
+            const int seq = mp / p.L_in, t = mp - seq * p.L_in;
+            const int ca = p.c0_prev + n;
+            const int g = ca / p.cin_g, c = ca - g * p.cin_g;
+            const float* da = p.dA + (size_t)g * p.da_gstride;
+            float s = p.dy ? p.dy[i] : 0.f;
+            // taps with (t + pad - tap) divisible by the stride and the output position in range, ascending tap order
+            for (int tap = (t + p.pad) % p.stride; tap < p.kt; tap += p.stride) {
+                const int num = t + p.pad - tap;
+                if (num < 0) break;
+                const int to = num / p.stride;
+                if (to < p.L_out) s += da[((size_t)seq * p.L_out + to) * p.Kg_pad + tap * p.cin_g + c];
+            }
+            const float yv = p.y[i];
+            r = yv > 0.f ? s : s * p.slope;  // LeakyReLU'(x <= 0) = slope; y = 0 only where x = 0
+        }
+        p.dz[i] = r;
+    }
+}
+
+// Gradient of the raw signal from a first layer's dA ([M][Kg_pad], cin = 1): dx[b][i] (+)= sum over the positions that read sample i.
+struct SignalGradParams {
+    const float* dA;
+    float* dx;        // (B, T_sub) (scale form: the pooled signal of that scale; period form: the raw signal)
+    long long total;  // B * T
+    int T, period;    // period 0: scale form
+    int L_in, L_out, kt, stride, pad, Kg_pad;
+    int accumulate;   // 0: dx = ..., 1: dx += ...
+};
+
+__device__ __forceinline__ float signal_grad_at(const SignalGradParams& p, int seq, int t) {
+    float s = 0.f;
+    for (int tap = (t + p.pad) % p.stride; tap < p.kt; tap += p.stride) {
+        const int num = t + p.pad - tap;
+        if (num < 0) break;
+        const int to = num / p.stride;
+        if (to < p.L_out) s += p.dA[((size_t)seq * p.L_out + to) * p.Kg_pad + tap];
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void signal_grad_kernel(const SignalGradParams p) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / p.T), idx = (int)(i - (long long)b * p.T);
+        float s;
+        if (p.period == 0) {
+            s = signal_grad_at(p, b, idx);
+        } else {
+            s = signal_grad_at(p, b * p.period + idx % p.period, idx / p.period);
+            const int mir = 2 * (p.T - 1) - idx;  // the reflect-padded position that mirrors this sample, if any
+            if (mir >= p.T && mir < p.L_in * p.period) s += signal_grad_at(p, b * p.period + mir % p.period, mir / p.period);
+        }
+        p.dx[i] = p.accumulate ? p.dx[i] + s : s;
+    }
+}
+
+struct PoolParams {
+    const float* src;
+    float* dst;
+    long long total;  // B * L_dst
+    int L_src, L_dst, kernel, stride, pad;
+    int accumulate;
+};
+
+__global__ __launch_bounds__(256) void avgpool_kernel(const PoolParams p) {  // dst = AvgPool1d(src), zeros count (count_include_pad)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / p.L_dst), o = (int)(i - (long long)b * p.L_dst);
+        float s = 0.f;
+        for (int k = 0; k < p.kernel; ++k) {
+            const int t = o * p.stride + k - p.pad;
+            if (t >= 0 && t < p.L_src) s += p.src[(size_t)b * p.L_src + t];
+        }
+        p.dst[i] = s / (float)p.kernel;
+    }
+}
+
+// dst (B, L_dst = the pool's INPUT length) (+)= the pool's backward of src (B, L_src = its output length)
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const PoolParams p) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / p.L_dst), t = (int)(i - (long long)b * p.L_dst);
+        float s = 0.f;
+        for (int k = (t + p.pad) % p.stride; k < p.kernel; k += p.stride) {
+            const int num = t + p.pad - k;
+            if (num < 0) break;
+            const int o = num / p.stride;
+            if (o < p.L_src) s += p.src[(size_t)b * p.L_src + o];
+        }
+        s /= (float)p.kernel;
+        p.dst[i] = p.accumulate ? p.dst[i] + s : s;
+    }
+}
+
+}  // namespace hificar

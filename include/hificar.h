@@ -244,6 +244,74 @@ const char* hificar_last_error(void);
 /* Library / build identification, e.g. "hificar 0.1 gfx950". */
 const char* hificar_version(void);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Discriminators of the train step: HiFiGANMultiScaleMultiPeriodDiscriminator (articulatory/models/hifigan.py:741-825; the
+ * scale discriminators :503-643, the period discriminators :317-417), called at articulatory/bin/train.py:341-347 (generator
+ * step: D(fake) with the gradient flowing back into the generator's waveform, D(real) without) and :421-424 (discriminator
+ * step).  The reference has no native boundary here (torch.nn modules under autograd); these entry points stand in for
+ * `discriminator(x)` and the autograd graph behind it.  Exact fp32.
+ *
+ * Layers are described explicitly (the host side derives them from discriminator_params exactly as the reference's constructors
+ * do): s_* = the Conv1d stack of ONE scale discriminator (the last layer has no activation), p_* = the Conv2d (k, 1) stack of
+ * ONE period discriminator (last = output_conv).  Parameter names follow the reference state_dict
+ * ("msd.discriminators.0.layers.1.0.weight", "mpd.discriminators.2.convs.0.0.weight_g", ...).
+ *
+ *   hificar_disc_set_parameters_device   every RAW parameter from device memory (as hificar_set_parameters_device)
+ *   hificar_disc_forward                 x (B, 1, T) -> every layer output of every sub-discriminator, kept in `tape`
+ *                                        (hificar_disc_tape_bytes, 256-byte aligned, caller-owned); output buffer i =
+ *                                        one (sub-discriminator, layer, group): [nseq][rows][pitch] floats, `channels` valid
+ *                                        columns; scale discriminators: nseq = B, rows = time; period discriminators:
+ *                                        nseq = B * period (sequence b * period + column), rows = T' / period.  Groups of a
+ *                                        grouped conv are separate buffers (channel c of the layer = group c / channels).
+ *   hificar_disc_backward                douts[i] = gradient of output buffer i (same layout) or NULL; -> grads (folded
+ *                                        parameters, hificar_disc_grad_floats, offsets from hificar_disc_param_info) or NULL,
+ *                                        dx (B, T) or NULL
+ *   hificar_disc_weight_norm_backward    folded gradients -> raw parameter gradients (as hificar_weight_norm_backward)
+ *   hificar_disc_engine                  the engine handle, for hificar_profile_begin / hificar_profile_end
+ * --------------------------------------------------------------------------------------------------------------------------- */
+#define HIFICAR_DISC_MAX_SUBS 8
+#define HIFICAR_DISC_MAX_LAYERS 12
+typedef struct hificar_disc_config {
+    int n_scales;                 /* scale discriminators (hifigan.py:666-738), AvgPool1d between them */
+    int pool_kernel, pool_stride, pool_pad;
+    int s_n_layers;
+    int s_cin[HIFICAR_DISC_MAX_LAYERS], s_cout[HIFICAR_DISC_MAX_LAYERS], s_k[HIFICAR_DISC_MAX_LAYERS], s_stride[HIFICAR_DISC_MAX_LAYERS],
+        s_pad[HIFICAR_DISC_MAX_LAYERS], s_groups[HIFICAR_DISC_MAX_LAYERS];
+    int s_bias;
+    float s_slope;
+    int n_periods;                /* period discriminators (hifigan.py:451-500) */
+    int periods[HIFICAR_DISC_MAX_SUBS];
+    int p_n_layers;
+    int p_cin[HIFICAR_DISC_MAX_LAYERS], p_cout[HIFICAR_DISC_MAX_LAYERS], p_k[HIFICAR_DISC_MAX_LAYERS], p_stride[HIFICAR_DISC_MAX_LAYERS],
+        p_pad[HIFICAR_DISC_MAX_LAYERS];
+    float p_slope;
+} hificar_disc_config;
+
+typedef struct hificar_disc_output {
+    int sub, layer, group, n_groups;
+    int period;                   /* 0: scale discriminator */
+    int64_t offset_bytes;         /* inside the tape */
+    int nseq, rows, pitch, channels;
+} hificar_disc_output;
+
+typedef struct hificar_disc hificar_disc;
+int hificar_disc_create(const hificar_disc_config* cfg, hificar_disc** out);
+void hificar_disc_destroy(hificar_disc* d);
+hificar_handle* hificar_disc_engine(hificar_disc* d);
+int hificar_disc_param_count(const hificar_disc* d);
+int hificar_disc_param_info(const hificar_disc* d, int i, char* name96, int64_t* shape4, int* ndim, int64_t* offset);
+int64_t hificar_disc_grad_floats(const hificar_disc* d);
+int64_t hificar_disc_raw_grad_floats(const hificar_disc* d);
+int hificar_disc_set_parameters_device(hificar_disc* d, const char* const* names, const float* const* data, int n, void* stream);
+int hificar_disc_weight_norm_backward(hificar_disc* d, const float* grads, float* raw_grads, void* stream);
+size_t hificar_disc_tape_bytes(const hificar_disc* d, int B, int T);
+size_t hificar_disc_backward_workspace_bytes(const hificar_disc* d, int B, int T);
+int hificar_disc_output_count(const hificar_disc* d);
+int hificar_disc_output_info(const hificar_disc* d, int B, int T, int i, hificar_disc_output* out);
+int hificar_disc_forward(hificar_disc* d, const float* x, int B, int T, void* tape, size_t tape_bytes, void* stream);
+int hificar_disc_backward(hificar_disc* d, const float* const* douts, int B, int T, const void* tape, size_t tape_bytes, float* grads,
+                          float* dx, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

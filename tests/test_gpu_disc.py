@@ -1,0 +1,121 @@
+"""Native discriminators on a MI355X against golden vectors of the REAL reference
+(tests/golden/gold_disc_*.npz, oracle/make_golden_disc.py) and against the CPU oracle.  ``pytest -m gpu``."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from articulatory_amd import losses as NL
+from articulatory_amd.models import HiFiGANMultiScaleMultiPeriodDiscriminator
+from articulatory_amd.utils.synth import synth_disc_state_dict, uniform
+from oracle import disc_oracle as DO
+from oracle import hificar_oracle as O
+from test_disc_oracle import case_params
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def build(params, seed):
+    assert torch.cuda.is_available()
+    sd = synth_disc_state_dict(params, seed=seed)
+    d = HiFiGANMultiScaleMultiPeriodDiscriminator(**params)
+    d.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return d.to("cuda:0"), sd
+
+
+def load(tag):
+    gold = np.load(os.path.join(GOLDEN, f"gold_disc_{tag}.npz"))
+    params = case_params(tag)
+    seed, B, T = int(gold["seed"]), int(gold["B"]), int(gold["T"])
+    return gold, params, seed, uniform(seed, "x", (B, 1, T), -0.6, 0.6), uniform(seed, "x_hat", (B, 1, T), -0.6, 0.6)
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_outputs_and_gradients_vs_reference_golden(tag):
+    """Every layer output of every sub-discriminator, and d(sum(out * cot)) / d(every raw parameter, x), against the real reference."""
+    gold, params, seed, x_np, _ = load(tag)
+    d, sd = build(params, seed)
+    x = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    outs = d(x)
+    assert "libhificar.so" in open("/proc/self/maps").read()
+    n_layers = [int(n) for n in gold["n_layers"]]
+    assert [len(o) for o in outs] == n_layers
+    loss = 0.0
+    worst = 0.0
+    for i, o in enumerate(outs):
+        for l, t in enumerate(o):
+            assert tuple(t.shape) == tuple(gold[f"shape::{i}.{l}"]), (i, l, tuple(t.shape))
+            e = O.check_packed(gold, f"out::{i}.{l}", t, 2e-5)
+            worst = max(worst, e)
+            assert e < 2e-5, (i, l, e)
+            cot = uniform(seed, f"cot.{i}.{l}", tuple(t.shape), -1.0, 1.0) / np.sqrt(np.prod(t.shape[1:]))
+            loss = loss + (t * torch.from_numpy(cot.astype(np.float32)).cuda()).sum()
+    loss.backward()
+    bad = {}
+    for k, p in list(d.named_parameters()) + [("x", x)]:
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+        e = O.check_packed(gold, "grad::" + k, p.grad, TOL)
+        if e >= TOL:
+            bad[k] = e
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_losses_vs_reference_golden(tag):
+    """The reference's loss modules' values (adversarial mse / hinge, feature matching) from the engine's own buffers."""
+    gold, params, seed, x_np, xh_np = load(tag)
+    d, _ = build(params, seed)
+    with torch.no_grad():
+        real = d(torch.from_numpy(x_np).cuda(), native=True)
+        fake = d(torch.from_numpy(xh_np).cuda(), native=True)
+
+    def close(a, key):
+        ref = float(gold[key])
+        assert abs(float(a) - ref) <= 5e-5 * max(abs(ref), 1e-3), (key, float(a), ref)
+
+    for avg in (False, True):
+        for lt in ("mse", "hinge"):
+            close(NL.generator_adversarial_loss(fake, avg, lt), f"loss::gen_adv::{lt}::{int(avg)}")
+            r, f = NL.discriminator_adversarial_loss(fake, real, avg, lt)
+            close(r, f"loss::dis_real::{lt}::{int(avg)}")
+            close(f, f"loss::dis_fake::{lt}::{int(avg)}")
+        for inc in (False, True):
+            close(NL.feature_match_loss(fake, real, avg, avg, inc), f"loss::feat_match::{int(avg)}::{int(inc)}")
+
+
+def test_generator_side_gradient_through_native_losses_vs_oracle():
+    """The generator step's use (train.py:341-362): adversarial + feature-matching loss on D(fake), gradient with respect to the
+    waveform only, through the native-layout losses — against the CPU oracle's autograd."""
+    params = case_params("small")
+    d, sd = build(params, 77)
+    B, T = 2, 700
+    w = DO.fold_disc_weight_norm(sd)
+    x_np = uniform(5, "real", (B, 1, T), -0.5, 0.5)
+    xh_np = uniform(5, "fake", (B, 1, T), -0.5, 0.5)
+    xr = torch.from_numpy(xh_np).requires_grad_(True)
+    f_ref = DO.disc_forward(w, params, xr)
+    with torch.no_grad():
+        r_ref = DO.disc_forward(w, params, torch.from_numpy(x_np))
+    loss_ref = DO.gen_adv_loss(f_ref, False) + 2.0 * DO.feat_match_loss(f_ref, r_ref, False, False, False)
+    loss_ref.backward()
+    for p in d.parameters():
+        p.requires_grad_(False)
+    xh = torch.from_numpy(xh_np).cuda().requires_grad_(True)
+    fake = d(xh, native=True)
+    with torch.no_grad():
+        real = d(torch.from_numpy(x_np).cuda(), native=True)
+    loss = NL.generator_adversarial_loss(fake, False) + 2.0 * NL.feature_match_loss(fake, real, False, False, False)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-5 * abs(float(loss_ref.detach()))
+    # |a - b| (and LeakyReLU) are kinked, and with 10^5 feature elements some pair always sits within rounding distance of its kink
+    # (min |a - b| ~ 1e-8 for every input seed): such an element's sign is a coin flip between two correct fp32 implementations and
+    # moves the gradient of the ~100 samples in its receptive field by O(1 / numel).  Flip-robust check: all but a few % of the samples
+    # agree to the exact-fp32 tolerance, and the whole gradient to 1e-4 in direction.
+    g, gr = xh.grad.cpu().numpy().reshape(-1).astype(np.float64), xr.grad.numpy().reshape(-1).astype(np.float64)
+    err = np.abs(g - gr) / np.abs(gr).max()
+    assert (err < TOL).mean() > 0.9, (err < TOL).mean()
+    assert 1.0 - float(g @ gr) / float(np.linalg.norm(g) * np.linalg.norm(gr)) < 1e-4
+    assert err.max() < 5e-2
