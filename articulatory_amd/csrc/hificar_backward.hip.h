@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // one G operand and one A operand per tap (row-shifted) from LDS and issues NT MFMAs.  Workgroup tile 64 (g) x 64 (a), waves 2 x 2;
 // partial layout, row shares and bias sums as above.  NT = accumulators instantiated (>= ntaps).
 struct WgradTapsParams {
+    long long zs_g = 0, zs_a = 0, zs_partial = 0, zs_bias = 0;  // per-group strides (floats)
     WgradParams w;
     const char* zeros;  // >= 16 zero bytes (rows outside the sequence)
     int off_min;        // smallest tap offset of the layer (over all phases), halo = largest - smallest
@@ -171,14 +172,22 @@ constexpr int kWgtR = 64;  // G rows per chunk
 // pair's MFMAs issue); otherwise ntaps < NT and the surplus taps are skipped.
 // Up to two layers of the same tap count per launch (blockIdx.z): conv2 and conv1 of a ResBlock slot have independent weight gradients,
 // and one launch with half the row splits each fills the chip with half the partial sums to write and reduce.
+// A grouped conv's groups (discriminators) ride on blockIdx.z as well: entry e = blockIdx.z / zg, group z = blockIdx.z % zg, whose
+// operands / partials lie z strides further on.
 struct WgradTapsPair {
     WgradTapsParams q[2];
+    int zg;
 };
 
 template <int NT, bool EXACT>
 __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pair) {
     extern __shared__ __attribute__((aligned(1024))) char wgt_smem[];
-    const WgradTapsParams& q = pair.q[blockIdx.z];
+    const WgradTapsParams& q = pair.q[blockIdx.z / pair.zg];
+    const int zi = blockIdx.z % pair.zg;
+    const float* const g_base = q.w.g + (size_t)zi * q.zs_g;
+    const float* const a_base = q.w.a + (size_t)zi * q.zs_a;
+    float* const partial_base = q.w.partial + (size_t)zi * q.zs_partial;
+    float* const bias_base = q.w.bias_partial ? q.w.bias_partial + (size_t)zi * q.zs_bias : nullptr;
     const WgradParams& p = q.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hf = lane >> 5;
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
             const int tg = t0 + 4 * i + (lane >> 4);
             const char* src = q.zeros;
             const int gch = gt * gpt * 32 + c4;
-            if (tg < p.L && c4 < gpt * 32 && gch < p.gpitch) src = reinterpret_cast<const char*>(p.g + ((size_t)seq * p.L + tg) * p.gpitch + gch);
+            if (tg < p.L && c4 < gpt * 32 && gch < p.gpitch) src = reinterpret_cast<const char*>(g_base + ((size_t)seq * p.L + tg) * p.gpitch + gch);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
         }
@@ -226,12 +235,12 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
             const int ach = at * 64 + c4;
             // an A row is only ever multiplied with G rows of the same chunk: rows whose G partner lies beyond the sequence need no masking
             // (those G rows are zero), but A rows outside [0, L) are the conv's zero padding
-            if (r < a_rows && ta >= 0 && ta < p.L && ach < p.apitch) src = reinterpret_cast<const char*>(p.a + ((size_t)seq * p.L + ta) * p.apitch + ach);
+            if (r < a_rows && ta >= 0 && ta < p.L && ach < p.apitch) src = reinterpret_cast<const char*>(a_base + ((size_t)seq * p.L + ta) * p.apitch + ach);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + g_bytes + i * 1024), 16, 0, 0);
         }
     };
-    const bool do_bias = p.bias_partial && at == 0;
+    const bool do_bias = bias_base && at == 0;
     float bsum = 0.f;
     if (c_lo < c_hi) stage(c_lo, 0);
     __syncthreads();  // (hipcc drains vmcnt before the barrier)
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
         red[(tid >> 6) * 64 + (tid & 63)] = bsum;
         __syncthreads();
         const int ch = gt * gpt * 32 + tid;
-        if (tid < gpt * 32 && ch < p.n_gblk * 32) p.bias_partial[(size_t)split * p.n_gblk * 32 + ch] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+        if (tid < gpt * 32 && ch < p.n_gblk * 32) bias_base[(size_t)split * p.n_gblk * 32 + ch] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
         __syncthreads();
     }
     const int gpad = p.n_gblk * 32, apad = p.n_ablk * 32;
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
             __syncthreads();
         }
         if (active && part == 0) {
-            float* dst = p.partial + (((size_t)split * p.ntaps + t) * gpad + gblk * 32) * apad + ablk * 32 + li;
+            float* dst = partial_base + (((size_t)split * p.ntaps + t) * gpad + gblk * 32) * apad + ablk * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hf) * apad] = v[r];
         }
@@ -332,10 +341,15 @@ struct WreduceParams {
 
 struct WreducePair {
     WreduceParams r[2];
+    int zg;
+    long long zs_partial[2], zs_dst[2];
 };
 
 __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
-    const WreduceParams& p = pair.r[blockIdx.y];
+    const int e = blockIdx.y / pair.zg, zi = blockIdx.y % pair.zg;
+    const WreduceParams& p = pair.r[e];
+    const float* const partial_p = p.partial + (size_t)zi * pair.zs_partial[e];
+    float* const dst_p = p.dst + (size_t)zi * pair.zs_dst[e];
     // one thread: 4 consecutive a of one (tap, g); the splits in four interleaved running sums, combined in a fixed order
     const int a4n = p.apad >> 2;
     const int total4 = p.ntaps * p.gpad * a4n;
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
         }
         if (co >= p.cout) continue;
         if (p.gemm_cin > 0 && a >= p.gemm_cin * p.K) continue;
-        const float4* src = reinterpret_cast<const float4*>(p.partial) + i;
+        const float4* src = reinterpret_cast<const float4*>(partial_p) + i;
         const size_t stride = total / 4;
         float4 s[4];
 #pragma unroll
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
                 if (tap >= p.K) break;
                 d = ((size_t)co * p.gemm_cin + c) * p.K + tap;
             }
-            p.dst[d] = o[j];
+            dst_p[d] = o[j];
         }
     }
 }
@@ -419,11 +433,18 @@ struct BreduceParams {
 // 16 channels x 16 strands per workgroup: strand j sums terms j, j + 16, ... (four loads in flight), the strands are added in a fixed order
 struct BreducePair {
     BreduceParams b[2];
+    int zg;
+    long long zs_partial[2], zs_dst[2];
 };
 
 __global__ __launch_bounds__(256) void breduce_kernel(const BreducePair pair) {
-    const BreduceParams& p = pair.b[blockIdx.y];
+    BreduceParams p = pair.b[blockIdx.y / pair.zg];
     if (!p.dst) return;
+    {
+        const int e = blockIdx.y / pair.zg, zi = blockIdx.y % pair.zg;
+        p.partial += (size_t)zi * pair.zs_partial[e];
+        p.dst += (size_t)zi * pair.zs_dst[e];
+    }
     __shared__ float red[16][17];
     const int cl = threadIdx.x & 15, jl = threadIdx.x >> 4;
     const int co = blockIdx.x * 16 + cl;

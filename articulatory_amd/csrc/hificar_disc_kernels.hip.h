@@ -17,14 +17,16 @@ namespace hificar {
 
 struct Im2colParams {
     const float* src;
-    float* dst;       // [M][Kg_pad]
-    long long total4; // M * Kg_pad / 4
+    float* dst;       // group g: dst + g * dst_gstride, [M][Kg_pad]
+    long long dst_gstride;
+    long long per_group4;  // M * Kg_pad / 4
+    long long total4; // groups * M * Kg_pad / 4
     int Kg, Kg_pad;
     int L_in, L_out;  // rows per sequence
     int kt, stride, pad, cin_g;
     int src_mode;     // 0 raw signal, scale form: seq = b;  1 raw signal, period form: seq = (b, col);  2 previous layer
     int T, period;    // raw signal length (unpadded); period
-    int ci0;          // first input channel of this group
+    int ci0;          // (device side: first input channel of the group being gathered = group * cin_g)
     int prev_cout_g, prev_np;
     long long prev_gstride;  // floats between the previous layer's group buffers
 };
@@ -43,10 +45,14 @@ __device__ __forceinline__ float im2col_fetch(const Im2colParams& p, int seq, in
     return p.src[(size_t)g * p.prev_gstride + ((size_t)seq * p.L_in + t) * p.prev_np + n];
 }
 
-__global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
+__global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams q) {
+    Im2colParams p = q;
     const int k4 = p.Kg_pad >> 2;
-    const bool vec = p.src_mode == 2 && (p.cin_g & 3) == 0 && (p.prev_cout_g & 3) == 0 && (p.ci0 & 3) == 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total4; i += (long long)gridDim.x * 256) {
+    const bool vec = p.src_mode == 2 && (p.cin_g & 3) == 0 && (p.prev_cout_g & 3) == 0;
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < p.total4; i0 += (long long)gridDim.x * 256) {
+        const int grp = (int)(i0 / p.per_group4);
+        const long long i = i0 - (long long)grp * p.per_group4;
+        p.ci0 = grp * p.cin_g;
         const int m = (int)(i / k4), j = (int)(i - (long long)m * k4) * 4;
         const int seq = m / p.L_out, to = m - seq * p.L_out;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
                 }
             }
         }
-        reinterpret_cast<f32x4*>(p.dst)[i] = v;
+        reinterpret_cast<f32x4*>(p.dst + (size_t)grp * p.dst_gstride)[i] = v;
     }
 }
 
@@ -78,26 +84,31 @@ __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
 struct Col2imParams {
     const float* dA;        // this layer's dA buffers: group g at dA + g * da_gstride, [M][Kg_pad]
     long long da_gstride;
-    const float* dy;        // the loss's gradient of the previous layer's output buffer [Mp][Np] or nullptr
-    const float* y;         // the previous layer's activated output [Mp][Np]
-    float* dz;              // out [Mp][Np]
-    long long total;        // Mp * Np
-    int np, cout_g_prev, c0_prev;  // previous layer's pitch / channels per group / first channel of THIS previous-layer group
+    const float* dy[16];    // per previous-layer group: the loss's gradient of that output buffer [Mp][Np] or nullptr
+    const float* y;         // the previous layer's activated outputs: group gp at y + gp * y_gstride, [Mp][Np]
+    float* dz;              // out, same strides
+    long long y_gstride;
+    long long per_group;    // Mp * Np
+    long long total;        // groups_prev * Mp * Np
+    int np, cout_g_prev;    // previous layer's pitch / channels per group
     int L_in, L_out;        // rows per sequence of the previous layer's output (= this layer's input) / of this layer's output
     int kt, stride, pad, cin_g, Kg_pad;
     float slope;
 };
 
 __global__ __launch_bounds__(256) void col2im_mask_kernel(const Col2imParams p) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < p.total; i0 += (long long)gridDim.x * 256) {
+        const int gp = (int)(i0 / p.per_group);
+        const long long i = i0 - (long long)gp * p.per_group;
         const int mp = (int)(i / p.np), n = (int)(i - (long long)mp * p.np);
+        const float* dyg = p.dy[gp];
         float r = 0.f;
         if (n < p.cout_g_prev) {
             const int seq = mp / p.L_in, t = mp - seq * p.L_in;
-            const int ca = p.c0_prev + n;
+            const int ca = gp * p.cout_g_prev + n;
             const int g = ca / p.cin_g, c = ca - g * p.cin_g;
             const float* da = p.dA + (size_t)g * p.da_gstride;
-            float s = p.dy ? p.dy[i] : 0.f;
+            float s = dyg ? dyg[i] : 0.f;
             // taps with (t + pad - tap) divisible by the stride and the output position in range, ascending tap order
             for (int tap = (t + p.pad) % p.stride; tap < p.kt; tap += p.stride) {
                 const int num = t + p.pad - tap;
@@ -105,10 +116,10 @@ __global__ __launch_bounds__(256) void col2im_mask_kernel(const Col2imParams p) 
                 const int to = num / p.stride;
                 if (to < p.L_out) s += da[((size_t)seq * p.L_out + to) * p.Kg_pad + tap * p.cin_g + c];
             }
-            const float yv = p.y[i];
+            const float yv = p.y[(size_t)gp * p.y_gstride + i];
             r = yv > 0.f ? s : s * p.slope;  // LeakyReLU'(x <= 0) = slope; y = 0 only where x = 0
         }
-        p.dz[i] = r;
+        p.dz[(size_t)gp * p.y_gstride + i] = r;
     }
 }
 

@@ -219,12 +219,13 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         return self._handle
 
     def __del__(self):
-        if getattr(self, "_handle", None) is not None and self._lib is not None:
+        handle, lib = self.__dict__.get("_handle"), self.__dict__.get("_lib")
+        if handle is not None and lib is not None:
+            self.__dict__["_handle"] = None  # (not setattr: torch's Module.__setattr__ may be half torn down at interpreter exit)
             try:
-                self._lib.hificar_disc_destroy(self._handle)
+                lib.hificar_disc_destroy(handle)
             except Exception:
                 pass
-            self._handle = None
 
     def _output_infos(self, B, T):
         key = (B, T)
