@@ -934,8 +934,14 @@ struct ConvIO {
     float mask_slope = 0.f;
 };
 
+// Replicas of every branch at regular strides (the groups of a grouped conv): see MultiConvParams::zrep
+struct ConvRep {
+    int n = 1;
+    long long zs_x = 0, zs_w = 0, zs_y = 0, zs_b = 0;
+};
+
 static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows, const ConvIO* io,
-                              float slope_out, const Ragged& rg, hipStream_t stream) {
+                              float slope_out, const Ragged& rg, hipStream_t stream, const ConvRep& zr = ConvRep()) {
     const ConvLayer& L0 = *layers[0];
     const bool f32 = h->precision == HIFICAR_PREC_F32;  // rows are plain fp32 LeakyReLU(x) instead of split rows
     int halo_all = 0;
@@ -962,7 +968,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         if (t.KS == 4 && (h->ksplit == 0 || nsteps_min < 2)) continue;
         if (t.KS == 1 && h->ksplit == 2 && nsteps_min >= 2) continue;
         const long long tiles_per_branch = (long long)nseq * ((rows + TM - 1) / TM) * ((L0.n_blocks32 + t.WN - 1) / t.WN);
-        const long long total = tiles_per_branch * nbr;
+        const long long total = tiles_per_branch * nbr * zr.n;
         const int G = (int)std::min<long long>(total, h->num_cus);
         const int nchunks = L0.cin_pad / L0.chunk16;
         // LPT makespan estimate: max(heaviest tile, total / G), plus one light tile when the count does not divide
@@ -977,7 +983,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
                 const int steps = layers[b]->ntaps * (L0.chunk16 / 16);
                 c = (double)((steps + 3) / 4) * nchunks * slab * t.MI + 4000.0 + 600.0 * nchunks;
             }
-            total_cost += c * tiles_per_branch;
+            total_cost += c * tiles_per_branch * zr.n;
             heaviest = std::max(heaviest, c);
             lightest = std::min(lightest, c);
         }
@@ -1010,7 +1016,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         mp.p[b].cout_real = Lb.cout_pad;
         if (f32) mp.p[b].w16 = reinterpret_cast<const bf16x8*>(Lb.d_w32);
         const double pos = (double)nseq * rows;
-        flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K;
+        flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K * zr.n;
         bytes += 4.0 * (pos * Lb.cin_pad + pos * Lb.cout_total * ((io[b].res ? 1 : 0) + (io[b].y ? 1 : 0) + (io[b].ys ? 1 : 0)) +
                         (double)Lb.cin * Lb.cout * Lb.K);
     }
@@ -1019,9 +1025,14 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     mp.n_branches = nbr;
     mp.nseq_tiles = nseq * ((rows + TM - 1) / TM);
     mp.ngroups = (L0.n_blocks32 + tc.WN - 1) / tc.WN;
-    mp.total_tiles = nbr * mp.ngroups * mp.nseq_tiles;
+    mp.total_tiles = nbr * zr.n * mp.ngroups * mp.nseq_tiles;
     mp.buf_bytes = (int)buf_bytes;
     mp.trace = nullptr;
+    mp.zrep = zr.n;
+    mp.zs_x = zr.zs_x;
+    mp.zs_w = zr.zs_w;
+    mp.zs_y = zr.zs_y;
+    mp.zs_b = zr.zs_b;
     dim3 grid((unsigned)std::min(mp.total_tiles, h->num_cus), 1, 1);  // persistent: one workgroup per CU walks its tile list
     if (h->use_lpt && mp.total_tiles > (int)grid.x) {
         std::vector<double> costs((size_t)mp.total_tiles);
@@ -1029,8 +1040,9 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         std::string key = f32 ? "f" : "c";
         for (int b = 0; b < nbr; ++b) {
             key += "|" + layers[b]->name;
-            for (int i = 0; i < tpb; ++i) costs[(size_t)b * tpb + i] = layers[b]->ntaps + 1.0;  // + fixed per-tile overhead
+            for (int i = 0; i < tpb * zr.n; ++i) costs[(size_t)b * tpb * zr.n + i] = layers[b]->ntaps + 1.0;  // + fixed per-tile overhead
         }
+        if (zr.n > 1) key += "z" + std::to_string(zr.n);
         key += "|" + std::to_string(nseq) + "x" + std::to_string((rows + TM - 1) / TM) + "t" + std::to_string(TM) + "w" + std::to_string(tc.WN) +
                "k" + std::to_string(tc.KS);
         int rc2 = get_schedule(h, key, costs, (int)grid.x, stream, &mp.sched_start, &mp.sched_tiles);

@@ -96,6 +96,10 @@ struct MultiConvParams {
     // first): workgroup w walks sched_tiles[sched_start[w] .. sched_start[w+1]).  Null: round-robin w, w+G, ...
     const int* sched_start;
     const int* sched_tiles;
+    // every branch replicated zrep times (the groups of a grouped conv, hificar_disc.hip.inc): replica z reads xs + z * zs_x bytes and
+    // w16 + z * zs_w bytes, bias + z * zs_b floats, writes y / ys + z * zs_y floats.  Tiles are numbered (branch, replica)-major.
+    int zrep;
+    long long zs_x, zs_w, zs_y, zs_b;
     unsigned long long* trace;  // dev tool only (tools/conv_bench.hip, -DHIFICAR_TRACE): per-workgroup timeline
 };
 
@@ -222,12 +226,14 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     const int buf_bytes = mp.buf_bytes;
 
     struct Tile {
-        int b, ng, seq, t0;
+        int b, z, ng, seq, t0;
     };
     auto decode = [&](int tile) {
         Tile T;
-        T.b = tile / tiles_per_branch;
-        const int rem = tile - T.b * tiles_per_branch;
+        const int bz = tile / tiles_per_branch;
+        T.b = bz / mp.zrep;
+        T.z = bz - T.b * mp.zrep;
+        const int rem = tile - bz * tiles_per_branch;
         T.ng = rem / mp.nseq_tiles;
         const int m = rem - T.ng * mp.nseq_tiles;
         const int tps = mp.p[0].tiles_per_seq;
@@ -282,8 +288,11 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         const float slope_out = p.slope_out;
         const int rows = min(TM, seq_rows(p, T.seq) - T.t0);
         const int vc = vc_base + c8;
-        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + vc);
-        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(p.bias + vc + 4);
+        const float* const bias_z = p.bias + (size_t)T.z * mp.zs_b;
+        float* const y_z = p.y ? p.y + (size_t)T.z * mp.zs_y : nullptr;
+        char* const ys_z = p.ys ? p.ys + (size_t)T.z * mp.zs_y * 4 : nullptr;
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(bias_z + vc);
+        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(bias_z + vc + 4);
         // split rows: virtual channel -> (real row within the virtual row, channel); 8 | cout_real
         const int ph_row = vc / p.cout_real;
         const int split_off = ph_row * p.cout_real * 4 + (vc - ph_row * p.cout_real) * 2;
@@ -339,17 +348,17 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                             o[4 + e] = (v1[q][e] + bv1[e]) + q1[q][e];
                         }
                     }
-                    if (p.y) {
-                        float* yp = p.y + row * p.cout_total + vc;
+                    if (y_z) {
+                        float* yp = y_z + row * p.cout_total + vc;
                         *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
                         *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
                     }
-                    if (p.ys) {
+                    if (ys_z) {
                         if constexpr (F32) {
                             float a[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) a[e] = fmaxf(o[e], o[e] * slope_out);  // LeakyReLU, 0 <= slope <= 1
-                            float* orow = reinterpret_cast<float*>(p.ys) + row * (size_t)p.cout_total + vc;
+                            float* orow = reinterpret_cast<float*>(ys_z) + row * (size_t)p.cout_total + vc;
                             *reinterpret_cast<f32x4*>(orow) = f32x4{a[0], a[1], a[2], a[3]};
                             *reinterpret_cast<f32x4*>(orow + 4) = f32x4{a[4], a[5], a[6], a[7]};
                         } else {
@@ -360,7 +369,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                                 hi[e] = (__bf16)a;
                                 lo[e] = (__bf16)(a - (float)hi[e]);
                             }
-                            char* orow = p.ys + row * (size_t)p.cout_total * 4 + split_off;
+                            char* orow = ys_z + row * (size_t)p.cout_total * 4 + split_off;
                             *reinterpret_cast<bf16x8*>(orow) = hi;
                             *reinterpret_cast<bf16x8*>(orow + p.cout_real * 2) = lo;
                         }
@@ -381,6 +390,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             const size_t seq_base = (size_t)T.seq * p.L;
             const int Ls = seq_rows(p, T.seq);
             const int row_bytes = p.cin * 4;
+            const char* const xs_z = p.xs + (size_t)T.z * mp.zs_x;
             char* dst = smem_b + (jj & 1) * buf_bytes;
             const int c0b = c * CH * 2;  // byte offset of this chunk inside the hi (and lo) half of a row
             for (int i = lw; i < ninstr; i += 4) {
@@ -390,8 +400,8 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                 const int t = T.t0 + p.off_min + r;
                 const char* src = p.zeros;
                 if (r < R && t >= 0 && t < Ls) {
-                    if constexpr (F32) src = p.xs + (seq_base + t) * row_bytes + 2 * c0b + sl * 16;
-                    else src = p.xs + (seq_base + t) * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
+                    if constexpr (F32) src = xs_z + (seq_base + t) * row_bytes + 2 * c0b + sl * 16;
+                    else src = xs_z + (seq_base + t) * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
                 }
                 // aux = 2: non-temporal — an activation row is staged by one or two CUs only (+2.3 % end to end)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -435,7 +445,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     auto wstream = [&](const Tile& T) {
         const ConvParams& p = mp.p[T.b];
         const int nb = T.ng * WN + wn;
-        return reinterpret_cast<const frag_t*>(p.w16) + (size_t)(nb < p.n_blocks32 ? nb : 0) * p.ntaps * (p.cin / 16) * 128 + lane;
+        return reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(p.w16) + (size_t)T.z * mp.zs_w) + (size_t)(nb < p.n_blocks32 ? nb : 0) * p.ntaps * (p.cin / 16) * 128 + lane;
     };
     const frag_t* wp = nullptr;   // where the next tap-group of weight fragments is loaded from
     int groups_left = 0;          // tap-groups of the current tile's stream not yet requested
@@ -513,7 +523,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
             const int tap_step = p.tap_step;
             const int nsteps = p.ntaps * NC16;
-            const frag_t* wtile = reinterpret_cast<const frag_t*>(p.w16) + (size_t)nb * nchunks * nsteps * 128 + lane;
+            const frag_t* wtile = reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(p.w16) + (size_t)T.z * mp.zs_w) + (size_t)nb * nchunks * nsteps * 128 + lane;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

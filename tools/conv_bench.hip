@@ -65,6 +65,7 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
     hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice);
     MultiConvParams mp;
     memset(&mp, 0, sizeof(mp));
+    mp.zrep = 1;
     int max_halo = 0;
     double flops = 0;
     for (int b = 0; b < nbr; ++b) {
