@@ -990,7 +990,8 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         double worst = std::max(heaviest, total_cost / G);
         if (total % G != 0) worst = std::max(worst, total_cost / G + 0.5 * lightest);
         // shorter wave tiles re-read the weight stream more often per MFMA (MI = 2 measured ~10 % slower per flop)
-        if (t.MI < 4) worst *= f32 ? (t.MI == 2 ? 1.02 : 1.05) : (t.MI == 2 ? 1.10 : 1.25);
+        static const double mi1_f32 = getenv("HIFICAR_MI1") ? atof(getenv("HIFICAR_MI1")) : 1.05;
+        if (t.MI < 4) worst *= f32 ? (t.MI == 2 ? 1.02 : mi1_f32) : (t.MI == 2 ? 1.10 : 1.25);
         if (t.KS == 4) worst *= 1.05;  // near-ties go to the dense form
         if (worst < best * 0.98) {  // near-ties keep the earlier (taller) shape
             best = worst;

@@ -195,4 +195,20 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const PoolParams p) {
     }
 }
 
+// dst = src[0] + src[1] + ... in that order (n >= 0; n = 0: zeros)
+struct SumParams {
+    const float* src[9];  // HIFICAR_DISC_MAX_SUBS + 1
+    float* dst;
+    long long total;
+    int n;
+};
+
+__global__ __launch_bounds__(256) void sum_kernel(const SumParams p) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < p.n; ++k) s += p.src[k][i];
+        p.dst[i] = s;
+    }
+}
+
 }  // namespace hificar
