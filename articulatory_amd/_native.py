@@ -57,6 +57,9 @@ SYMBOLS = (
     "hificar_disc_output_info",
     "hificar_disc_forward",
     "hificar_disc_backward",
+    "hificar_disc_dout_floats",
+    "hificar_disc_loss",
+    "hificar_disc_backward_flat",
     "hificar_tape_bytes",
     "hificar_forward_train",
     "hificar_backward_workspace_bytes",
@@ -133,6 +136,18 @@ class HificarDiscConfig(ctypes.Structure):
         ("p_stride", _LAY),
         ("p_pad", _LAY),
         ("p_slope", ctypes.c_float),
+    ]
+
+
+class HificarGanLossConfig(ctypes.Structure):
+    _fields_ = [
+        ("loss_type", ctypes.c_int32),
+        ("average_by_discriminators", ctypes.c_int32),
+        ("fm_average_by_layers", ctypes.c_int32),
+        ("fm_average_by_discriminators", ctypes.c_int32),
+        ("fm_include_final_outputs", ctypes.c_int32),
+        ("lambda_adv", ctypes.c_float),
+        ("lambda_feat_match", ctypes.c_float),
     ]
 
 
@@ -248,6 +263,12 @@ def load_library():
     lib.hificar_disc_forward.restype = ci
     lib.hificar_disc_backward.argtypes = [vp, ctypes.POINTER(vp), ci, ci, vp, cs, vp, vp, vp, cs, vp]
     lib.hificar_disc_backward.restype = ci
+    lib.hificar_disc_dout_floats.argtypes = [vp, ci, ci]
+    lib.hificar_disc_dout_floats.restype = cs
+    lib.hificar_disc_loss.argtypes = [vp, ctypes.POINTER(HificarGanLossConfig), ci, vp, vp, ci, ci, vp, vp, vp]
+    lib.hificar_disc_loss.restype = ci
+    lib.hificar_disc_backward_flat.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, cs, vp, vp, vp, cs, vp]
+    lib.hificar_disc_backward_flat.restype = ci
     lib.hificar_tape_bytes.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.hificar_tape_bytes.restype = ctypes.c_size_t
     lib.hificar_forward_train.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]

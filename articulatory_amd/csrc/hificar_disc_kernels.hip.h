@@ -211,4 +211,107 @@ __global__ __launch_bounds__(256) void sum_kernel(const SumParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// GAN losses on the engine's own output buffers (articulatory/losses/adversarial_loss.py:12-123, feat_match_loss.py:12-54): every term
+// is a mean over the elements of one layer output, so one pass per output buffer gives both the term's sum and its gradient.
+//   adv_kind  0 none | 1 (a - 1)^2 | 2 a^2 | 3 -a | 4 -min(a - 1, 0) | 5 -min(-a - 1, 0)      (mse real / gen, mse fake, hinge gen, real, fake)
+//   w_fm != 0: |a - b| against the reference pass's buffer at the same offset (feature matching; b is a constant)
+// dout = w_adv * d(adv term) + w_fm * sign(a - b); partial sums per (entry, chunk) are combined in a fixed order by loss_reduce_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLossChunks = 32;
+
+struct LossEntry {
+    long long y_off;   // floats from the tape base (both passes share the layout)
+    long long d_off;   // floats from the gradient buffer's base
+    long long total;   // rows * pitch
+    int pitch, channels;
+    int adv_kind;
+    float w_adv, w_fm;   // d(total loss) / d(element) scales (lambda, averaging and 1 / numel folded in)
+    float c_adv, c_fm;   // value scales (averaging and 1 / numel; no lambda)
+};
+
+__global__ __launch_bounds__(256) void loss_kernel(const LossEntry* entries, const float* tape, const float* tape_ref, float* douts, float* partials) {
+    __shared__ float red[2][4];
+    const LossEntry e = entries[blockIdx.y];
+    const float* a = tape + e.y_off;
+    const float* b = tape_ref ? tape_ref + e.y_off : nullptr;
+    float* d = douts + e.d_off;
+    const long long n4 = e.total >> 2;
+    const long long lo = n4 * blockIdx.x / kLossChunks, hi = n4 * (blockIdx.x + 1) / kLossChunks;
+    float s_adv = 0.f, s_fm = 0.f;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const f32x4 av = reinterpret_cast<const f32x4*>(a)[i];
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (b && e.w_fm != 0.f) bv = reinterpret_cast<const f32x4*>(b)[i];
+        const int col = (int)((i * 4) % e.pitch);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (col + u >= e.channels) continue;
+            const float x = av[u];
+            float ga = 0.f;
+            switch (e.adv_kind) {
+                case 1: s_adv += (x - 1.f) * (x - 1.f); ga = 2.f * (x - 1.f); break;
+                case 2: s_adv += x * x; ga = 2.f * x; break;
+                case 3: s_adv -= x; ga = -1.f; break;
+                case 4: s_adv -= fminf(x - 1.f, 0.f); ga = x < 1.f ? -1.f : 0.f; break;
+                case 5: s_adv -= fminf(-x - 1.f, 0.f); ga = x > -1.f ? 1.f : 0.f; break;
+                default: break;
+            }
+            float gf = 0.f;
+            if (e.w_fm != 0.f) {
+                const float df = x - bv[u];
+                s_fm += fabsf(df);
+                gf = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            }
+            g[u] = e.w_adv * ga + e.w_fm * gf;
+        }
+        reinterpret_cast<f32x4*>(d)[i] = g;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s_adv += __shfl_xor(s_adv, o, 64);
+        s_fm += __shfl_xor(s_fm, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s_adv;
+        red[1][threadIdx.x >> 6] = s_fm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* out = partials + ((size_t)blockIdx.y * kLossChunks + blockIdx.x) * 2;
+        out[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        out[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// values[0] = sum_e c_adv[e] * S_adv[e], values[1] = sum_e c_fm[e] * S_fm[e], values[2] = lambda_adv * (values[0] + lambda_fm * values[1])
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const LossEntry* entries, int n, const float* partials, float* values, float lambda_adv,
+                                                          float lambda_fm) {
+    __shared__ float sa[256], sf[256];
+    float ta = 0.f, tf = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {  // (n <= 256 in practice: one entry per thread)
+        float a = 0.f, f = 0.f;
+        for (int c = 0; c < kLossChunks; ++c) {
+            a += partials[((size_t)e * kLossChunks + c) * 2];
+            f += partials[((size_t)e * kLossChunks + c) * 2 + 1];
+        }
+        ta += entries[e].c_adv * a;
+        tf += entries[e].c_fm * f;
+    }
+    sa[threadIdx.x] = ta;
+    sf[threadIdx.x] = tf;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, f = 0.f;
+        for (int i = 0; i < 256; ++i) {
+            a += sa[i];
+            f += sf[i];
+        }
+        values[0] = a;
+        values[1] = f;
+        values[2] = lambda_adv * (a + lambda_fm * f);
+    }
+}
+
 }  // namespace hificar

@@ -123,6 +123,155 @@ class _DiscFunction(torch.autograd.Function):
         return (None, dx, None, *gw)
 
 
+def _aligned(nfloats, dev):
+    """(tensor, float offset of its first 256-byte aligned element)."""
+    t = torch.empty(nfloats + 64, dtype=torch.float32, device=dev)
+    return t, ((-t.data_ptr()) % 256) // 4
+
+
+class _Pass:
+    """One native forward pass kept for the loss / backward kernels."""
+
+    def __init__(self, module, x, stream):
+        lib, handle = module._lib, module._handle
+        B, _, T = x.shape
+        self.nbytes = int(lib.hificar_disc_tape_bytes(handle, B, T))
+        self.tape, self.off = _aligned(self.nbytes // 4, x.device)
+        self.ptr = self.tape.data_ptr() + 4 * self.off
+        x = x.detach().to(torch.float32).contiguous()
+        _native.check(lib.hificar_disc_forward(handle, x.data_ptr(), B, T, self.ptr, self.nbytes, stream), "hificar_disc_forward")
+
+
+def _loss_cfg(loss_type, average_by_discriminators, fm_average_by_layers, fm_average_by_discriminators, fm_include_final_outputs,
+              lambda_adv, lambda_feat_match):
+    assert loss_type in ("mse", "hinge"), f"{loss_type} is not supported."
+    c = _native.HificarGanLossConfig()
+    c.loss_type = 0 if loss_type == "mse" else 1
+    c.average_by_discriminators = int(bool(average_by_discriminators))
+    c.fm_average_by_layers = int(bool(fm_average_by_layers))
+    c.fm_average_by_discriminators = int(bool(fm_average_by_discriminators))
+    c.fm_include_final_outputs = int(bool(fm_include_final_outputs))
+    c.lambda_adv, c.lambda_feat_match = float(lambda_adv), float(lambda_feat_match)
+    return c
+
+
+class _GeneratorLossFunction(torch.autograd.Function):
+    """Generator side of the GAN criterion in one node (train.py:341-362): D(fake), D(real) (no graph), adversarial + feature-matching
+    losses and their gradients on the engine's buffers (hificar_disc_loss), backward = the discriminators' data gradient down to the
+    waveform.  Returns (lambda_adv * (adv + lambda_feat_match * fm), adv, fm); only the first is differentiable (with respect to y_fake;
+    the discriminator's parameters get no gradient here — the reference computes and then discards them, train.py:364-372,429)."""
+
+    @staticmethod
+    def forward(ctx, module, y_fake, y_real, cfg, names, *params):
+        lib, handle = module._lib, module._handle
+        B, _, T = y_fake.shape
+        dev = y_fake.device
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _send(module, names, params, stream)
+            fake = _Pass(module, y_fake, stream)
+            real = _Pass(module, y_real, stream) if y_real is not None else None
+            douts, doff = _aligned(int(lib.hificar_disc_dout_floats(handle, B, T)), dev)
+            values = torch.empty(3, dtype=torch.float32, device=dev)
+            rc = lib.hificar_disc_loss(handle, ctypes.byref(cfg), 0, fake.ptr, real.ptr if real is not None else None, B, T, values.data_ptr(),
+                                       douts.data_ptr() + 4 * doff, stream)
+        _native.check(rc, "hificar_disc_loss")
+        ctx.module, ctx.fake, ctx.douts, ctx.doff, ctx.BT, ctx.cfg, ctx.with_fm = module, fake, douts, doff, (B, T), cfg, real is not None
+        total, adv, fm = values[2], values[0], values[1]
+        ctx.mark_non_differentiable(adv, fm)
+        return total, adv, fm
+
+    @staticmethod
+    def backward(ctx, g_total, _g_adv, _g_fm):
+        module = ctx.module
+        lib, handle = module._lib, module._handle
+        B, T = ctx.BT
+        dev = ctx.douts.device
+        if not ctx.needs_input_grad[1]:
+            return (None,) * (5 + len(ctx.needs_input_grad) - 5)
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            dx = torch.empty((B, 1, T), dtype=torch.float32, device=dev)
+            wsb = int(lib.hificar_disc_backward_workspace_bytes(handle, B, T))
+            ws, woff = _aligned(wsb // 4, dev)
+            rc = lib.hificar_disc_backward_flat(handle, ctx.douts.data_ptr() + 4 * ctx.doff, 0, int(ctx.with_fm), ctx.cfg.fm_include_final_outputs, B, T,
+                                                ctx.fake.ptr, ctx.fake.nbytes, None, dx.data_ptr(), ws.data_ptr() + 4 * woff, wsb, stream)
+        _native.check(rc, "hificar_disc_backward_flat")
+        ctx.fake = ctx.douts = None
+        return (None, dx * g_total, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+class _DiscriminatorLossFunction(torch.autograd.Function):
+    """Discriminator side (train.py:421-424): D(real), D(fake), real + fake adversarial losses, backward = both passes' parameter
+    gradients (weight norm included).  Returns (real_loss + fake_loss, real_loss, fake_loss); the first is differentiable with
+    respect to the discriminator's parameters."""
+
+    @staticmethod
+    def forward(ctx, module, y_fake, y_real, cfg, names, *params):
+        lib, handle = module._lib, module._handle
+        B, _, T = y_fake.shape
+        dev = y_fake.device
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            held = _send(module, names, params, stream)
+            passes, douts, vals = [], [], []
+            for mode, y in ((1, y_fake), (2, y_real)):
+                ps = _Pass(module, y, stream)
+                d, doff = _aligned(int(lib.hificar_disc_dout_floats(handle, B, T)), dev)
+                v = torch.empty(3, dtype=torch.float32, device=dev)
+                _native.check(lib.hificar_disc_loss(handle, ctypes.byref(cfg), mode, ps.ptr, None, B, T, v.data_ptr(), d.data_ptr() + 4 * doff, stream),
+                              "hificar_disc_loss")
+                passes.append(ps)
+                douts.append((d, doff))
+                vals.append(v)
+        ctx.module, ctx.passes, ctx.douts, ctx.BT, ctx.cfg = module, passes, douts, (B, T), cfg
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.held, ctx.params, ctx.versions = held, params, [p._version for p in params]
+        fake_loss, real_loss = vals[0][0], vals[1][0]
+        total = real_loss + fake_loss
+        ctx.mark_non_differentiable(real_loss, fake_loss)
+        return total, real_loss, fake_loss
+
+    @staticmethod
+    def backward(ctx, g_total, _g_real, _g_fake):
+        module = ctx.module
+        lib, handle = module._lib, module._handle
+        B, T = ctx.BT
+        dev = ctx.douts[0][0].device
+        if any(t._version != v for t, v in zip(ctx.params, ctx.versions)):
+            raise RuntimeError("a discriminator parameter was modified in place between forward and backward")
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            wsb = int(lib.hificar_disc_backward_workspace_bytes(handle, B, T))
+            ws, woff = _aligned(wsb // 4, dev)
+            nfold = int(lib.hificar_disc_grad_floats(handle))
+            folded = []
+            for mode, ps, (d, doff) in zip((1, 2), ctx.passes, ctx.douts):
+                g = torch.zeros(nfold, dtype=torch.float32, device=dev)
+                rc = lib.hificar_disc_backward_flat(handle, d.data_ptr() + 4 * doff, mode, 0, 0, B, T, ps.ptr, ps.nbytes, g.data_ptr(), None,
+                                                    ws.data_ptr() + 4 * woff, wsb, stream)
+                _native.check(rc, "hificar_disc_backward_flat")
+                folded.append(g)
+            grads = folded[0].add_(folded[1])
+            raw = torch.zeros(int(lib.hificar_disc_raw_grad_floats(handle)), dtype=torch.float32, device=dev)
+            _native.check(lib.hificar_disc_weight_norm_backward(handle, grads.data_ptr(), raw.data_ptr(), stream), "hificar_disc_weight_norm_backward")
+            raw.mul_(g_total)
+            if module._grad_sync is not None:
+                import torch.distributed as dist
+
+                group, average = module._grad_sync
+                dist.all_reduce(raw, group=group)
+                if average:
+                    raw.div_(dist.get_world_size(group))
+        gw, off = [], 0
+        for shape in ctx.shapes:
+            n = int(np.prod(shape))
+            gw.append(raw[off:off + n].view(shape))
+            off += (n + 3) & ~3
+        ctx.passes = ctx.douts = ctx.held = ctx.params = None
+        return (None, None, None, None, None, *gw)
+
+
 class _SubDisc(torch.nn.Module):
     pass
 
@@ -264,6 +413,34 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         _native.check(self._lib.hificar_profile_end(self._lib.hificar_disc_engine(self._handle), stats, 96, ctypes.byref(n)), "hificar_profile_end")
         return [dict(name=stats[i].name.decode(), launches=int(stats[i].launches), total_ms=float(stats[i].total_ms),
                      flops=float(stats[i].flops), bytes=float(stats[i].bytes)) for i in range(min(n.value, 96))]
+
+    # ------------------------------------------------------------------ fused GAN criterion
+    def generator_loss(self, y_fake, y_real=None, loss_type="mse", average_by_discriminators=True, lambda_adv=1.0, lambda_feat_match=0.0,
+                       fm_average_by_layers=True, fm_average_by_discriminators=True, fm_include_final_outputs=False):
+        """The generator step's adversarial part in one autograd node (train.py:341-362): GeneratorAdversarialLoss(D(y_fake)) and, when
+        y_real is given, FeatureMatchLoss(D(y_fake), D(y_real)) -> (lambda_adv * (adv + lambda_feat_match * fm), adv, fm).  Defaults as
+        the reference's loss modules (adversarial_loss.py:15-19, feat_match_loss.py:15-20)."""
+        self._check(y_fake)
+        self._native_handle()
+        cfg = _loss_cfg(loss_type, average_by_discriminators, fm_average_by_layers, fm_average_by_discriminators, fm_include_final_outputs,
+                        lambda_adv, lambda_feat_match)
+        names, tensors = self._raw_parameters()
+        return _GeneratorLossFunction.apply(self, y_fake, y_real, cfg, names, *tensors)
+
+    def discriminator_loss(self, y_fake, y_real, loss_type="mse", average_by_discriminators=True):
+        """DiscriminatorAdversarialLoss(D(y_fake), D(y_real)) in one autograd node (train.py:421-424) -> (real + fake, real, fake)."""
+        self._check(y_fake)
+        self._check(y_real)
+        self._native_handle()
+        cfg = _loss_cfg(loss_type, average_by_discriminators, True, True, False, 1.0, 0.0)
+        names, tensors = self._raw_parameters()
+        return _DiscriminatorLossFunction.apply(self, y_fake.detach(), y_real.detach(), cfg, names, *tensors)
+
+    def _check(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("HiFiGANMultiScaleMultiPeriodDiscriminator needs CUDA/HIP tensors; there is no CPU fallback")
+        if x.dim() != 3 or x.shape[1] != 1:
+            raise RuntimeError(f"Expected input of shape (B, 1, T), got {tuple(x.shape)}")
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, native=False):

@@ -294,7 +294,25 @@ typedef struct hificar_disc_output {
     int nseq, rows, pitch, channels;
 } hificar_disc_output;
 
+/* GAN criterion on the forward tapes (articulatory/losses/adversarial_loss.py:12-123, feat_match_loss.py:12-54 as combined at
+ * train.py:341-362 / :421-424).  hificar_disc_loss: mode 0 = generator side (adversarial loss of the fake pass's final outputs +
+ * feature matching against the real pass `tape_ref`, NULL: none): values = {adv, fm, lambda_adv * (adv + lambda_feat_match * fm)};
+ * mode 1 / 2 = discriminator side, fake / real pass: values = {loss, 0, loss}.  values: 3 device floats; douts:
+ * hificar_disc_dout_floats floats = d(values[2]) / d(every output buffer), consumed by hificar_disc_backward_flat. */
+typedef struct hificar_gan_loss_config {
+    int loss_type;                 /* 0 mse, 1 hinge */
+    int average_by_discriminators; /* adversarial losses */
+    int fm_average_by_layers, fm_average_by_discriminators, fm_include_final_outputs;
+    float lambda_adv, lambda_feat_match;
+} hificar_gan_loss_config;
+
 typedef struct hificar_disc hificar_disc;
+size_t hificar_disc_dout_floats(const hificar_disc* d, int B, int T);
+int hificar_disc_loss(hificar_disc* d, const hificar_gan_loss_config* cfg, int mode, const void* tape, const void* tape_ref, int B, int T,
+                      float* values3, float* douts, void* stream);
+int hificar_disc_backward_flat(hificar_disc* d, const float* douts, int mode, int with_fm, int fm_include_final_outputs, int B, int T,
+                               const void* tape, size_t tape_bytes, float* grads, float* dx, void* workspace, size_t workspace_bytes,
+                               void* stream);
 int hificar_disc_create(const hificar_disc_config* cfg, hificar_disc** out);
 void hificar_disc_destroy(hificar_disc* d);
 hificar_handle* hificar_disc_engine(hificar_disc* d);

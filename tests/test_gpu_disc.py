@@ -119,3 +119,57 @@ def test_generator_side_gradient_through_native_losses_vs_oracle():
     assert (err < TOL).mean() > 0.9, (err < TOL).mean()
     assert 1.0 - float(g @ gr) / float(np.linalg.norm(g) * np.linalg.norm(gr)) < 1e-4
     assert err.max() < 5e-2
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
+@pytest.mark.parametrize("loss_type", ["mse", "hinge"])
+def test_fused_criterion_vs_reference_values_and_unfused_gradients(tag, loss_type):
+    """generator_loss / discriminator_loss (one autograd node each: both passes, the loss kernels, the native backward) against the
+    reference's loss values (golden) and against the gradients of the same losses taken through the unfused path (native forward +
+    torch reductions on the engine's buffers) — identical forward outputs, so kinks fall on the same side and the gradients agree to
+    rounding."""
+    gold, params, seed, x_np, xh_np = load(tag)
+    d, _ = build(params, seed)
+    real = torch.from_numpy(x_np).cuda()
+
+    def close(a, key, tol=5e-5):
+        ref = float(gold[key])
+        assert abs(float(a) - ref) <= tol * max(abs(ref), 1e-3), (key, float(a), ref)
+
+    for avg in (False, True):
+        # ---- generator side
+        fake = torch.from_numpy(xh_np).cuda().requires_grad_(True)
+        total, adv, fm = d.generator_loss(fake, real, loss_type=loss_type, average_by_discriminators=avg, lambda_adv=1.5, lambda_feat_match=2.0,
+                                          fm_average_by_layers=avg, fm_average_by_discriminators=avg, fm_include_final_outputs=avg)
+        close(adv, f"loss::gen_adv::{loss_type}::{int(avg)}")
+        close(fm, f"loss::feat_match::{int(avg)}::{int(avg)}")
+        assert abs(float(total) - 1.5 * (float(adv) + 2.0 * float(fm))) < 1e-5 * abs(float(total))
+        (3.0 * total).backward()
+        fake2 = torch.from_numpy(xh_np).cuda().requires_grad_(True)
+        p_ = d(fake2, native=True)
+        with torch.no_grad():
+            p = d(real, native=True)
+        ref = 1.5 * (NL.generator_adversarial_loss(p_, avg, loss_type) + 2.0 * NL.feature_match_loss(p_, p, avg, avg, avg))
+        (gx,) = torch.autograd.grad(3.0 * ref, fake2)
+        assert rel_err_t(fake.grad, gx) < 2e-5, (avg, rel_err_t(fake.grad, gx))
+        assert all(q.grad is None for q in d.parameters())
+        # ---- discriminator side
+        tot, r, f = d.discriminator_loss(torch.from_numpy(xh_np).cuda(), real, loss_type=loss_type, average_by_discriminators=avg)
+        close(r, f"loss::dis_real::{loss_type}::{int(avg)}")
+        close(f, f"loss::dis_fake::{loss_type}::{int(avg)}")
+        d.zero_grad(set_to_none=True)
+        tot.backward()
+        got = {k: q.grad.clone() for k, q in d.named_parameters()}
+        d.zero_grad(set_to_none=True)
+        p = d(real, native=True)
+        p_ = d(torch.from_numpy(xh_np).cuda(), native=True)
+        rr, ff = NL.discriminator_adversarial_loss(p_, p, avg, loss_type)
+        (rr + ff).backward()
+        bad = {k: rel_err_t(got[k], q.grad) for k, q in d.named_parameters()}
+        bad = {k: v for k, v in bad.items() if not v < 5e-5}
+        assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
+        d.zero_grad(set_to_none=True)
+
+
+def rel_err_t(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

@@ -12,7 +12,6 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch  # noqa: E402
 
-from articulatory_amd import losses as NL  # noqa: E402
 from articulatory_amd.models import HiFiGANMultiScaleMultiPeriodDiscriminator  # noqa: E402
 from articulatory_amd.utils.synth import disc_params, synth_disc_state_dict  # noqa: E402
 
@@ -34,19 +33,15 @@ fake = torch.rand(a.batch, 1, a.samples, device="cuda") - 0.5
 
 def d_step():
     d.zero_grad(set_to_none=True)
-    p = d(real, native=True)
-    p_ = d(fake, native=True)
-    r, f = NL.discriminator_adversarial_loss(p_, p, False)
-    (r + f).backward()
+    total, _, _ = d.discriminator_loss(fake, real, average_by_discriminators=False)
+    total.backward()
 
 
 def g_step():
     x = fake.clone().requires_grad_(True)
-    p_ = d(x, native=True)
-    with torch.no_grad():
-        p = d(real, native=True)
-    loss = NL.generator_adversarial_loss(p_, False) + 2.0 * NL.feature_match_loss(p_, p, False, False, False)
-    (gx,) = torch.autograd.grad(loss, x)
+    total, _, _ = d.generator_loss(x, real, average_by_discriminators=False, lambda_adv=1.0, lambda_feat_match=2.0, fm_average_by_layers=False,
+                                   fm_average_by_discriminators=False)
+    (gx,) = torch.autograd.grad(total, x)
     return gx
 
 
