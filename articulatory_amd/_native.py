@@ -60,6 +60,10 @@ SYMBOLS = (
     "hificar_disc_dout_floats",
     "hificar_disc_loss",
     "hificar_disc_backward_flat",
+    "hificar_mel_create",
+    "hificar_mel_destroy",
+    "hificar_mel_workspace_bytes",
+    "hificar_mel_loss",
     "hificar_tape_bytes",
     "hificar_forward_train",
     "hificar_backward_workspace_bytes",
@@ -148,6 +152,17 @@ class HificarGanLossConfig(ctypes.Structure):
         ("fm_include_final_outputs", ctypes.c_int32),
         ("lambda_adv", ctypes.c_float),
         ("lambda_feat_match", ctypes.c_float),
+    ]
+
+
+class HificarMelConfig(ctypes.Structure):
+    _fields_ = [
+        ("fft_size", ctypes.c_int32),
+        ("hop_size", ctypes.c_int32),
+        ("win_length", ctypes.c_int32),
+        ("num_mels", ctypes.c_int32),
+        ("eps", ctypes.c_float),
+        ("log_base", ctypes.c_int32),
     ]
 
 
@@ -269,6 +284,14 @@ def load_library():
     lib.hificar_disc_loss.restype = ci
     lib.hificar_disc_backward_flat.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, cs, vp, vp, vp, cs, vp]
     lib.hificar_disc_backward_flat.restype = ci
+    lib.hificar_mel_create.argtypes = [ctypes.POINTER(HificarMelConfig), vp, ctypes.POINTER(vp)]
+    lib.hificar_mel_create.restype = ci
+    lib.hificar_mel_destroy.argtypes = [vp]
+    lib.hificar_mel_destroy.restype = None
+    lib.hificar_mel_workspace_bytes.argtypes = [vp, ci, ci]
+    lib.hificar_mel_workspace_bytes.restype = cs
+    lib.hificar_mel_loss.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, cs, vp]
+    lib.hificar_mel_loss.restype = ci
     lib.hificar_tape_bytes.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.hificar_tape_bytes.restype = ctypes.c_size_t
     lib.hificar_forward_train.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]

@@ -1752,3 +1752,4 @@ extern "C" int hificar_pcm16(const float* x, int16_t* y, size_t n, void* stream)
 
 #include "hificar_train.hip.inc"
 #include "hificar_disc.hip.inc"
+#include "hificar_mel.hip.inc"

@@ -315,3 +315,131 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const LossEntry* entri
 }
 
 }  // namespace hificar
+
+// ------------------------------------------------------------------------------------------------
+// Mel-spectrogram loss (articulatory/losses/mel_loss.py:16-166: torch.stft(center, hann) -> |.| -> mel filterbank -> log -> L1).  The DFT
+// and the filterbank are GEMMs on the exact-fp32 conv kernels (window folded into the DFT matrix); these are the passes around them.
+// ------------------------------------------------------------------------------------------------
+namespace hificar {
+
+struct FrameParams {
+    const float* y;   // (B, T)
+    float* A;         // [B * frames][N]
+    long long total4; // B * frames * N / 4
+    int T, N, hop, frames;
+};
+
+__device__ __forceinline__ int reflect_index(int i, int T) { return i < 0 ? -i : (i >= T ? 2 * (T - 1) - i : i); }
+
+__global__ __launch_bounds__(256) void mel_frame_kernel(const FrameParams p) {  // A[(b, f)][n] = y_padded[b][f * hop + n], reflect padding N / 2
+    const int n4 = p.N >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total4; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
+        const int b = m / p.frames, f = m - b * p.frames;
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = p.y[(size_t)b * p.T + reflect_index(f * p.hop + n + u - p.N / 2, p.T)];
+        reinterpret_cast<f32x4*>(p.A)[i] = v;
+    }
+}
+
+struct AmpParams {
+    const float* S;   // [M][2 * nfp]: re at [0, nfp), im at [nfp, 2 nfp)
+    float* amp;       // [M][nfp]
+    const float* damp;  // backward: [M][nfp]
+    float* dS;          // backward: [M][2 * nfp]
+    long long total;  // M * nfp
+    int nf, nfp;
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void mel_amp_kernel(const AmpParams p) {  // sqrt(clamp(re^2 + im^2, eps))
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / p.nfp), f = (int)(i - (long long)m * p.nfp);
+        float a = 0.f;
+        if (f < p.nf) {
+            const float re = p.S[(size_t)m * 2 * p.nfp + f], im = p.S[(size_t)m * 2 * p.nfp + p.nfp + f];
+            a = sqrtf(fmaxf(re * re + im * im, p.eps));
+        }
+        p.amp[i] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void mel_amp_bwd_kernel(const AmpParams p) {  // d|S| -> d(re, im); the clamp passes no gradient below eps
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / p.nfp), f = (int)(i - (long long)m * p.nfp);
+        float gre = 0.f, gim = 0.f;
+        if (f < p.nf) {
+            const float re = p.S[(size_t)m * 2 * p.nfp + f], im = p.S[(size_t)m * 2 * p.nfp + p.nfp + f];
+            const float pw = re * re + im * im;
+            if (pw > p.eps) {
+                const float g = p.damp[i] / sqrtf(pw);
+                gre = g * re;
+                gim = g * im;
+            }
+        }
+        p.dS[(size_t)m * 2 * p.nfp + f] = gre;
+        p.dS[(size_t)m * 2 * p.nfp + p.nfp + f] = gim;
+    }
+}
+
+struct MelLossParams {
+    const float* mel_hat;  // [M][mp]
+    const float* mel;      // [M][mp]
+    float* dmel_hat;       // [M][mp] or nullptr
+    float* partial;        // [gridDim.x]
+    long long total;       // M * mp
+    int nm, mp;
+    float eps, log_scale;  // log_base: log(x) * log_scale
+    float inv_numel;
+};
+
+__global__ __launch_bounds__(256) void mel_loss_kernel(const MelLossParams p) {  // L1 of log(clamp(mel, eps)), mean over (M, num_mels)
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % p.mp);
+        float g = 0.f;
+        if (c < p.nm) {
+            const float a = p.mel_hat[i], b = p.mel[i];
+            const float la = logf(fmaxf(a, p.eps)) * p.log_scale, lb = logf(fmaxf(b, p.eps)) * p.log_scale;
+            const float df = la - lb;
+            s += fabsf(df);
+            if (a > p.eps) g = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * p.log_scale / a * p.inv_numel;
+        }
+        if (p.dmel_hat) p.dmel_hat[i] = g;
+    }
+    s = wg_sum256(s, red);
+    if (threadIdx.x == 0) p.partial[blockIdx.x] = s * p.inv_numel;
+}
+
+struct OlaParams {
+    const float* dA;  // [B * frames][N]
+    float* dy;        // (B, T)
+    long long total;  // B * T
+    int T, N, hop, frames;
+};
+
+__device__ __forceinline__ float ola_at(const OlaParams& p, int b, int j) {  // sum over the frames that hold padded position j (offset by N / 2)
+    const int q = j + p.N / 2;
+    float s = 0.f;
+    const int f_hi = min(q / p.hop, p.frames - 1);
+    for (int f = max(0, (q - p.N + p.hop) / p.hop); f <= f_hi; ++f) {
+        const int n = q - f * p.hop;
+        if (n >= 0 && n < p.N) s += p.dA[((size_t)b * p.frames + f) * p.N + n];
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void mel_ola_kernel(const OlaParams p) {  // backward of mel_frame_kernel (reflect padding folded back)
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < p.total; i0 += (long long)gridDim.x * 256) {
+        const int b = (int)(i0 / p.T), i = (int)(i0 - (long long)b * p.T);
+        float s = ola_at(p, b, i);
+        if (i > 0 && i <= p.N / 2) s += ola_at(p, b, -i);                                   // left mirror
+        const int mr = 2 * (p.T - 1) - i;
+        if (mr >= p.T && mr < p.T + p.N / 2) s += ola_at(p, b, mr);                         // right mirror
+        p.dy[i0] = s;
+    }
+}
+
+}  // namespace hificar

@@ -54,3 +54,90 @@ def feature_match_loss(feats_hat, feats, average_by_layers=True, average_by_disc
             part = part / (j + 1)
         total = total + part
     return total / (i + 1) if average_by_discriminators else total
+
+
+# ------------------------------------------------------------------------------------------------
+# Mel-spectrogram loss (mel_loss.py:114-166) on libhificar: value and gradient in one native call
+# ------------------------------------------------------------------------------------------------
+import ctypes  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+from . import _native  # noqa: E402
+from .utils.mel import mel_filterbank  # noqa: E402
+
+
+class _MelLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, y_hat, y):
+        lib, handle = module._lib, module._handle
+        B, T = y_hat.shape[0] * y_hat.shape[1], y_hat.shape[-1]
+        dev = y_hat.device
+        yh = y_hat.detach().to(torch.float32).contiguous()
+        yr = y.detach().to(torch.float32).contiguous()
+        need = y_hat.requires_grad
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            wsb = int(lib.hificar_mel_workspace_bytes(handle, B, T))
+            ws = torch.empty(wsb // 4 + 64, dtype=torch.float32, device=dev)
+            woff = ((-ws.data_ptr()) % 256) // 4
+            value = torch.empty(1, dtype=torch.float32, device=dev)
+            dy = torch.empty_like(yh) if need else None
+            rc = lib.hificar_mel_loss(handle, yh.data_ptr(), yr.data_ptr(), B, T, value.data_ptr(), dy.data_ptr() if need else None,
+                                      ws.data_ptr() + 4 * woff, wsb, stream)
+        _native.check(rc, "hificar_mel_loss")
+        ctx.dy = dy
+        ctx.shape = y_hat.shape
+        return value[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dy = ctx.dy
+        ctx.dy = None
+        return None, (dy * g).view(ctx.shape) if dy is not None else None, None
+
+
+class MelSpectrogramLoss(torch.nn.Module):
+    """Mel-spectrogram loss, constructor arguments as the reference's (mel_loss.py:117-132).  MI355X-native (no CPU fallback)."""
+
+    def __init__(self, fs=22050, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=80, fmax=7600, center=True,
+                 normalized=False, onesided=True, eps=1e-10, log_base=10.0):
+        super().__init__()
+        if window != "hann" or not center or normalized or not onesided:
+            raise NotImplementedError("MelSpectrogramLoss: only window='hann', center=True, normalized=False, onesided=True are built")
+        if log_base not in (None, 2.0, 10.0):
+            raise ValueError(f"log_base: {log_base} is not supported.")
+        fmin = 0 if fmin is None else fmin
+        fmax = fs / 2 if fmax is None else fmax
+        self.melmat = np.ascontiguousarray(mel_filterbank(fs, fft_size, num_mels, fmin, fmax))
+        self._cfg = _native.HificarMelConfig(fft_size, hop_size, fft_size if win_length is None else win_length, num_mels, eps,
+                                             0 if log_base is None else int(log_base))
+        self._lib = self._handle = None
+
+    def _native_handle(self, dev):
+        if self._handle is None:
+            self._lib = _native.load_library()
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(dev):
+                _native.check(self._lib.hificar_mel_create(ctypes.byref(self._cfg), self.melmat.ctypes.data_as(ctypes.c_void_p), ctypes.byref(handle)),
+                              "hificar_mel_create")
+            self._handle = handle
+        return self._handle
+
+    def __del__(self):
+        handle, lib = self.__dict__.get("_handle"), self.__dict__.get("_lib")
+        if handle is not None and lib is not None:
+            self.__dict__["_handle"] = None
+            try:
+                lib.hificar_mel_destroy(handle)
+            except Exception:
+                pass
+
+    def forward(self, y_hat, y):
+        """y_hat, y: (B, 1, T) -> scalar (mel_loss.py:152-166)."""
+        if not y_hat.is_cuda:
+            raise RuntimeError("MelSpectrogramLoss needs CUDA/HIP tensors; there is no CPU fallback")
+        if y_hat.shape != y.shape or y_hat.dim() != 3:
+            raise RuntimeError(f"Expected two (B, C, T) tensors of one shape, got {tuple(y_hat.shape)} and {tuple(y.shape)}")
+        self._native_handle(y_hat.device)
+        return _MelLossFunction.apply(self, y_hat, y)

@@ -330,6 +330,22 @@ int hificar_disc_forward(hificar_disc* d, const float* x, int B, int T, void* ta
 int hificar_disc_backward(hificar_disc* d, const float* const* douts, int B, int T, const void* tape, size_t tape_bytes, float* grads,
                           float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Mel-spectrogram loss (articulatory/losses/mel_loss.py:114-166; train.py:308-311): F.l1_loss(log mel(y_hat), log mel(y)) and its
+ * gradient with respect to y_hat in one call.  melmat: (num_mels, fft_size / 2 + 1) filterbank, host memory (librosa.filters.mel in the
+ * reference, mel_loss.py:56-62).  window: hann (periodic, torch.hann_window), center = True, normalized = False, onesided = True.
+ * log_base: 0 natural, 2 or 10. */
+typedef struct hificar_mel_config {
+    int fft_size, hop_size, win_length, num_mels;
+    float eps;
+    int log_base;
+} hificar_mel_config;
+typedef struct hificar_mel hificar_mel;
+int hificar_mel_create(const hificar_mel_config* cfg, const float* melmat, hificar_mel** out);
+void hificar_mel_destroy(hificar_mel* m);
+size_t hificar_mel_workspace_bytes(const hificar_mel* m, int B, int T);
+int hificar_mel_loss(hificar_mel* m, const float* y_hat, const float* y, int B, int T, float* value, float* dy_hat, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

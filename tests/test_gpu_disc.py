@@ -173,3 +173,30 @@ def test_fused_criterion_vs_reference_values_and_unfused_gradients(tag, loss_typ
 
 def rel_err_t(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("log_base,T", [(None, 2000), (10.0, 2000), (None, 1791)])
+def test_mel_loss_vs_oracle(log_base, T):
+    """MelSpectrogramLoss (e2w_hifigan_car.yaml:100-111 parameters) value and gradient against the oracle (torch.stft on the CPU).
+    librosa is absent, so the filterbank is the restated one on both sides (parity unpinned for that matrix, oracle/disc_oracle.py)."""
+    from articulatory_amd.losses import MelSpectrogramLoss
+    from articulatory_amd.utils.mel import mel_filterbank
+
+    kw = dict(fs=16000, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=0, fmax=11025, log_base=log_base)
+    assert np.array_equal(mel_filterbank(16000, 1024, 80, 0, 11025), DO.mel_filterbank(16000, 1024, 80, 0, 11025))
+    B = 3
+    rng = np.random.default_rng(11)
+    y = (rng.standard_normal((B, 1, T)) * 0.2).astype(np.float32)
+    yh = (y + rng.standard_normal((B, 1, T)) * 0.05).astype(np.float32)
+    crit = MelSpectrogramLoss(**kw)
+    a = torch.from_numpy(yh).cuda().requires_grad_(True)
+    loss = crit(a, torch.from_numpy(y).cuda())
+    (2.0 * loss).backward()
+    ar = torch.from_numpy(yh).requires_grad_(True)
+    ref = DO.mel_loss(ar, torch.from_numpy(y), **kw)
+    (2.0 * ref).backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-4 * abs(float(ref.detach())), (float(loss), float(ref))
+    g, gr = a.grad.cpu().numpy().reshape(-1).astype(np.float64), ar.grad.numpy().reshape(-1).astype(np.float64)
+    # |.| of log-mel differences is kinked (sign flips where the two log-mels agree to rounding): direction + most elements
+    assert 1.0 - float(g @ gr) / float(np.linalg.norm(g) * np.linalg.norm(gr)) < 1e-5
+    assert (np.abs(g - gr) < 1e-3 * np.abs(gr).max()).mean() > 0.98
