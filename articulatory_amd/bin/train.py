@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""GAN training of the a2w HiFi-GAN / HiFi-CAR recipes on MI355X — the counterpart of the reference's ``articulatory-train``
+(articulatory/bin/train.py) for the path this package covers: HiFiGANGenerator + HiFiGANMultiScaleMultiPeriodDiscriminator with the mel
+(or no) auxiliary loss, adversarial + feature-matching losses, Adam / RAdam + torch LR schedulers, the reference's checkpoint layout.
+
+``Trainer.train_step`` follows ``Trainer._train_step`` (train.py:241-440) statement by statement for that path: generator forward
+(autograd through libhificar), mel loss, D(cat([ar, y_]), D(cat([ar, y])) -> adversarial + feature matching, generator update; then the
+generator forward again without a graph ("re-compute y_ which leads better quality", :389), discriminator real / fake losses,
+discriminator update.  Every network, loss and gradient runs in libhificar; PyTorch holds the parameters, the optimizers and the
+schedule.  Data parallelism: one process per GPU, ``sync_gradients`` on both networks (the reference's DDP wrap is disabled,
+train.py:1790-1801): one all-reduce per network per step over RCCL.
+
+Data: ``--audio-scp`` / ``--feats-scp`` (``utt path`` lines; audio and features as ``.npy`` — libsndfile / HDF5 readers are not in this
+image) or ``--synthetic N`` (N random utterances, for benchmarks and smoke runs).  Windows are cut as the reference's collater does
+in ``random_window`` mode (train.py:1013-1097): ``batch_max_steps`` samples, the matching frames, and the ``ar_input`` samples before
+the window (zero padded on the left) as the AR context.
+
+    python -m articulatory_amd.bin.train --config conf/e2w_hifigan_car.yaml --outdir exp/run --synthetic 256
+    python -m torch.distributed.run --nproc-per-node 8 -m articulatory_amd.bin.train --config ... --outdir ...
+"""
+import argparse
+import logging
+import os
+import time
+from collections import defaultdict
+
+import numpy as np
+import torch
+import yaml
+
+from articulatory_amd.losses import MelSpectrogramLoss
+from articulatory_amd.models import HiFiGANGenerator, HiFiGANMultiScaleMultiPeriodDiscriminator
+
+
+class WindowCollater:
+    """random_window packaging of (audio, features) pairs (train.py:1013-1035, 1071-1097 for the a2w + AR case)."""
+
+    def __init__(self, batch_max_steps, hop_size, ar_len=None, rng=None):
+        assert batch_max_steps % hop_size == 0
+        self.batch_max_steps, self.hop_size, self.ar_len = batch_max_steps, hop_size, ar_len
+        self.batch_max_frames = batch_max_steps // hop_size
+        self.rng = rng or np.random.default_rng()
+
+    def __call__(self, items):
+        """items: [(audio (T,), feats (frames, C))] -> {"x": (B, C, frames), "y": (B, 1, T), "ar": (B, 1, ar_len)}."""
+        audios, feats = zip(*items)
+        starts = np.array([self.rng.integers(0, len(c) - self.batch_max_frames + 1) for c in feats])
+        wav_starts = starts * self.hop_size
+        y = np.stack([a[s:s + self.batch_max_steps] for a, s in zip(audios, wav_starts)])
+        x = np.stack([c[s:s + self.batch_max_frames] for c, s in zip(feats, starts)])
+        batch = {"x": torch.from_numpy(x.astype(np.float32)).transpose(2, 1).contiguous(), "y": torch.from_numpy(y.astype(np.float32)).unsqueeze(1)}
+        if self.ar_len is not None:
+            ars = []
+            for a, s in zip(audios, wav_starts):
+                ar = a[max(0, s - self.ar_len):s]
+                ars.append(np.pad(ar, (self.ar_len - len(ar), 0), "constant"))
+            batch["ar"] = torch.from_numpy(np.stack(ars).astype(np.float32)).unsqueeze(1)
+        return batch
+
+
+class NpyPairs(torch.utils.data.Dataset):
+    """(audio, features) pairs from two ``utt path`` scp files of ``.npy`` arrays; utterances shorter than the window are dropped
+    (remove_short_samples, audio_mel_dataset.py of the reference)."""
+
+    def __init__(self, audio_scp, feats_scp, hop_size, min_frames):
+        def read(p):
+            with open(p) as f:
+                return dict(line.split(None, 1) for line in f.read().splitlines() if line.strip())
+
+        a, c = read(audio_scp), read(feats_scp)
+        self.items = []
+        for utt in sorted(set(a) & set(c)):
+            feats = np.load(c[utt].strip(), mmap_mode="r")
+            if feats.shape[0] >= min_frames:
+                self.items.append((a[utt].strip(), c[utt].strip()))
+        self.hop_size = hop_size
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        audio = np.load(self.items[i][0]).astype(np.float32).reshape(-1)
+        feats = np.load(self.items[i][1]).astype(np.float32)
+        n = min(len(audio) // self.hop_size, len(feats))
+        return audio[: n * self.hop_size], feats[:n]
+
+
+class SyntheticPairs(torch.utils.data.Dataset):
+    def __init__(self, n, frames, dims, hop_size, seed=0):
+        rng = np.random.default_rng(seed)
+        self.items = [((rng.standard_normal(frames * hop_size) * 0.1).astype(np.float32), rng.standard_normal((frames, dims)).astype(np.float32))
+                      for _ in range(n)]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _optimizer(kind, params, kw):
+    cls = getattr(torch.optim, kind)  # (the reference's articulatory.optimizers re-exports torch.optim + RAdam; torch has RAdam now)
+    return cls(params, **kw)
+
+
+class Trainer:
+    """The generator / discriminator / criterion / optimizer bundle of one rank."""
+
+    def __init__(self, config, device, distributed=False):
+        self.config, self.device, self.distributed = config, device, distributed
+        if config.get("generator_type", "HiFiGANGenerator") != "HiFiGANGenerator":
+            raise NotImplementedError(f"generator_type {config['generator_type']} is not built")
+        if config.get("discriminator_type", "HiFiGANMultiScaleMultiPeriodDiscriminator") != "HiFiGANMultiScaleMultiPeriodDiscriminator":
+            raise NotImplementedError(f"discriminator_type {config['discriminator_type']} is not built")
+        for flag in ("use_stft_loss", "use_subband_stft_loss", "use_inter_loss", "use_ph_loss", "use_pcd"):
+            if config.get(flag, False):
+                raise NotImplementedError(f"{flag} is not built (SURVEY.md §8 f1 covers the shipped HiFi-GAN / HiFi-CAR recipes: mel loss)")
+        gp = config["generator_params"]
+        self.use_ar = bool(gp.get("use_ar", False))
+        self.G = HiFiGANGenerator(**gp, precision="f32").to(device).train()
+        self.D = HiFiGANMultiScaleMultiPeriodDiscriminator(**config["discriminator_params"]).to(device).train()
+        self.mel = MelSpectrogramLoss(**config["mel_loss_params"]) if config.get("use_mel_loss", False) else None
+        if distributed:
+            self.G.sync_gradients()
+            self.D.sync_gradients()
+        self.optimizer = {
+            "generator": _optimizer(config.get("generator_optimizer_type", "RAdam"), self.G.parameters(), config["generator_optimizer_params"]),
+            "discriminator": _optimizer(config.get("discriminator_optimizer_type", "RAdam"), self.D.parameters(),
+                                        config["discriminator_optimizer_params"]),
+        }
+        self.scheduler = {
+            k: getattr(torch.optim.lr_scheduler, config.get(f"{k}_scheduler_type", "StepLR"))(optimizer=self.optimizer[k],
+                                                                                               **config[f"{k}_scheduler_params"])
+            for k in ("generator", "discriminator")
+        }
+        self.steps = self.epochs = 0
+        self.total_train_loss = defaultdict(float)
+
+    # ------------------------------------------------------------------ one iteration (train.py:241-440)
+    def train_step(self, batch):
+        cfg = self.config
+        x = batch["x"].to(self.device, non_blocking=True)
+        y = batch["y"].to(self.device, non_blocking=True)
+        ar = batch["ar"].to(self.device, non_blocking=True) if self.use_ar else None
+        log = {}
+        adv_on = self.steps > cfg["discriminator_train_start_steps"]
+        ga = cfg.get("generator_adv_loss_params", {})
+        da = cfg.get("discriminator_adv_loss_params", {})
+        fm = cfg.get("feat_match_loss_params", {})
+        #######################
+        #      Generator      #
+        #######################
+        if self.steps > cfg.get("generator_train_start_steps", 0):
+            y_ = self.G(x, ar=ar)
+            gen_loss = 0.0
+            if self.mel is not None:
+                mel_loss = self.mel(y_, y)
+                gen_loss = gen_loss + mel_loss
+                log["train/mel_loss"] = mel_loss.detach()
+            gen_loss = gen_loss * cfg.get("lambda_aux", 1.0)
+            if adv_on:
+                disc_y = torch.cat([ar, y], dim=2) if self.use_ar else y
+                disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
+                use_fm = cfg.get("use_feat_match_loss", False)
+                total, adv, fml = self.D.generator_loss(
+                    disc_y_, disc_y if use_fm else None, loss_type=ga.get("loss_type", "mse"),
+                    average_by_discriminators=ga.get("average_by_discriminators", True), lambda_adv=cfg["lambda_adv"],
+                    lambda_feat_match=cfg.get("lambda_feat_match", 0.0) if use_fm else 0.0,
+                    fm_average_by_layers=fm.get("average_by_layers", True), fm_average_by_discriminators=fm.get("average_by_discriminators", True),
+                    fm_include_final_outputs=fm.get("include_final_outputs", False))
+                gen_loss = gen_loss + total
+                log["train/adversarial_loss"] = adv
+                if use_fm:
+                    log["train/feature_matching_loss"] = fml
+            log["train/generator_loss"] = gen_loss.detach()
+            self.optimizer["generator"].zero_grad(set_to_none=True)
+            gen_loss.backward()
+            if cfg.get("generator_grad_norm", -1) > 0:
+                torch.nn.utils.clip_grad_norm_(self.G.parameters(), cfg["generator_grad_norm"])
+            self.optimizer["generator"].step()
+            self.scheduler["generator"].step()
+        #######################
+        #    Discriminator    #
+        #######################
+        if adv_on:
+            with torch.no_grad():
+                y_ = self.G(x, ar=ar)  # re-compute y_ (train.py:389-400): a training-mode forward without a graph
+            disc_y = torch.cat([ar, y], dim=2) if self.use_ar else y
+            disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
+            dis_loss, real_loss, fake_loss = self.D.discriminator_loss(disc_y_, disc_y, loss_type=da.get("loss_type", "mse"),
+                                                                       average_by_discriminators=da.get("average_by_discriminators", True))
+            log.update({"train/real_loss": real_loss, "train/fake_loss": fake_loss, "train/discriminator_loss": dis_loss.detach()})
+            self.optimizer["discriminator"].zero_grad(set_to_none=True)
+            dis_loss.backward()
+            if cfg.get("discriminator_grad_norm", -1) > 0:
+                torch.nn.utils.clip_grad_norm_(self.D.parameters(), cfg["discriminator_grad_norm"])
+            self.optimizer["discriminator"].step()
+            self.scheduler["discriminator"].step()
+        self.steps += 1
+        return log
+
+    # ------------------------------------------------------------------ checkpoints (train.py:140-238)
+    def save_checkpoint(self, path):
+        state = {
+            "optimizer": {k: v.state_dict() for k, v in self.optimizer.items()},
+            "scheduler": {k: v.state_dict() for k, v in self.scheduler.items()},
+            "steps": self.steps,
+            "epochs": self.epochs,
+            "model": {"generator": self.G.state_dict(), "discriminator": self.D.state_dict()},
+        }
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        torch.save(state, path)
+
+    def load_checkpoint(self, path, load_only_params=False):
+        state = torch.load(path, map_location="cpu")
+        self.G.load_state_dict(state["model"]["generator"])
+        self.D.load_state_dict(state["model"]["discriminator"])
+        if not load_only_params:
+            self.steps, self.epochs = state["steps"], state["epochs"]
+            for k in ("generator", "discriminator"):
+                self.optimizer[k].load_state_dict(state["optimizer"][k])
+                self.scheduler[k].load_state_dict(state["scheduler"][k])
+
+
+def hop_of(config):
+    return int(np.prod(config["generator_params"]["upsample_scales"]))
+
+
+def feature_dims(config):
+    gp = config["generator_params"]
+    return gp["in_channels"] - (gp.get("ar_output", 0) if gp.get("use_ar", False) else 0)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--outdir", required=True)
+    ap.add_argument("--audio-scp")
+    ap.add_argument("--feats-scp")
+    ap.add_argument("--synthetic", type=int, default=0, help="train on this many random utterances instead of a dataset")
+    ap.add_argument("--resume", default="")
+    ap.add_argument("--max-steps", type=int, default=None, help="override train_max_steps")
+    ap.add_argument("--verbose", type=int, default=1)
+    a = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO if a.verbose else logging.WARN, format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    with open(a.config) as f:
+        config = yaml.safe_load(f)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("articulatory_amd.bin.train needs a MI355X: the networks only exist as HIP kernels")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        torch.distributed.init_process_group("nccl")  # RCCL
+    config["distributed"] = world > 1
+    hop = hop_of(config)
+    frames = config["batch_max_steps"] // hop
+    gp = config["generator_params"]
+    ar_len = gp.get("ar_input") if gp.get("use_ar", False) else None
+    if a.synthetic:
+        data = SyntheticPairs(a.synthetic, 4 * frames, feature_dims(config), hop, seed=rank)
+    else:
+        if not (a.audio_scp and a.feats_scp):
+            raise SystemExit("give --audio-scp and --feats-scp, or --synthetic N")
+        data = NpyPairs(a.audio_scp, a.feats_scp, hop, frames)
+    sampler = torch.utils.data.distributed.DistributedSampler(data, world, rank, shuffle=True) if world > 1 else None
+    loader = torch.utils.data.DataLoader(data, batch_size=config["batch_size"], shuffle=sampler is None, sampler=sampler, drop_last=True,
+                                         collate_fn=WindowCollater(config["batch_max_steps"], hop, ar_len, np.random.default_rng(1234 + rank)),
+                                         num_workers=config.get("num_workers", 0), pin_memory=config.get("pin_memory", False))
+    if len(loader) == 0:
+        raise SystemExit(f"fewer utterances ({len(data)}) than one batch ({config['batch_size']})")
+    trainer = Trainer(config, device, distributed=world > 1)
+    if a.resume:
+        trainer.load_checkpoint(a.resume)
+        logging.info(f"Successfully resumed from {a.resume}.")
+    max_steps = a.max_steps if a.max_steps is not None else config["train_max_steps"]
+    t0, n0 = time.time(), trainer.steps
+    while trainer.steps < max_steps:
+        if sampler is not None:
+            sampler.set_epoch(trainer.epochs)
+        for batch in loader:
+            log = trainer.train_step(batch)
+            for k, v in log.items():
+                trainer.total_train_loss[k] += float(v)
+            if trainer.steps % config.get("log_interval_steps", 100) == 0 and rank == 0:
+                n = config.get("log_interval_steps", 100)
+                logging.info(f"(Steps: {trainer.steps}) " + ", ".join(f"{k} = {v / n:.4f}" for k, v in sorted(trainer.total_train_loss.items()))
+                             + f", {(time.time() - t0) / max(trainer.steps - n0, 1) * 1e3:.1f} ms/step")
+                trainer.total_train_loss = defaultdict(float)
+            if trainer.steps % config.get("save_interval_steps", 10 ** 9) == 0 and rank == 0:
+                trainer.save_checkpoint(os.path.join(a.outdir, f"checkpoint-{trainer.steps}steps.pkl"))
+            if trainer.steps >= max_steps:
+                break
+        trainer.epochs += 1
+    if rank == 0:
+        trainer.save_checkpoint(os.path.join(a.outdir, f"checkpoint-{trainer.steps}steps.pkl"))
+        logging.info(f"Finished training: {trainer.steps} steps, {(time.time() - t0) / max(trainer.steps - n0, 1) * 1e3:.1f} ms/step.")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

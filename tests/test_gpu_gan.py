@@ -1,0 +1,110 @@
+"""The GAN training iteration (articulatory_amd/bin/train.py::Trainer.train_step, counterpart of the reference's Trainer._train_step,
+articulatory/bin/train.py:241-440) on a MI355X: every logged loss of the first iteration against the CPU oracle's restatement of the same
+step, the updates it makes, and the checkpoint layout.  ``pytest -m gpu``."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import E2W_PARAMS
+from articulatory_amd.bin.train import SyntheticPairs, Trainer, WindowCollater
+from articulatory_amd.utils.synth import synth_disc_state_dict, synth_state_dict
+from oracle import disc_oracle as DO
+from oracle import hificar_oracle as O
+from oracle.make_golden_disc import SMALL
+
+pytestmark = pytest.mark.gpu
+
+
+def make_config(use_ar=True):
+    gp = dict(E2W_PARAMS, channels=128, upsample_scales=[5, 4], upsample_kernel_sizes=[10, 8], use_ar=use_ar)
+    if not use_ar:
+        gp["in_channels"] = 13
+    adam = {"lr": 2.0e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}
+    sched = {"gamma": 0.5, "milestones": [100, 200]}
+    return dict(
+        generator_type="HiFiGANGenerator", generator_params=gp, discriminator_type="HiFiGANMultiScaleMultiPeriodDiscriminator",
+        discriminator_params=SMALL, use_stft_loss=False, use_mel_loss=True,
+        mel_loss_params=dict(fs=16000, fft_size=256, hop_size=64, win_length=None, window="hann", num_mels=20, fmin=0, fmax=8000, log_base=None),
+        generator_adv_loss_params={"average_by_discriminators": False}, discriminator_adv_loss_params={"average_by_discriminators": False},
+        use_feat_match_loss=True, feat_match_loss_params={"average_by_discriminators": False, "average_by_layers": False, "include_final_outputs": False},
+        lambda_aux=45.0, lambda_adv=1.0, lambda_feat_match=2.0, batch_size=4, batch_max_steps=400,
+        generator_optimizer_type="Adam", generator_optimizer_params=adam, generator_scheduler_type="MultiStepLR", generator_scheduler_params=sched,
+        generator_grad_norm=-1, discriminator_optimizer_type="Adam", discriminator_optimizer_params=adam, discriminator_scheduler_type="MultiStepLR",
+        discriminator_scheduler_params=sched, discriminator_grad_norm=10.0, discriminator_train_start_steps=0, distributed=False)
+
+
+def build(config):
+    assert torch.cuda.is_available()
+    t = Trainer(config, torch.device("cuda:0"))
+    gsd = synth_state_dict(config["generator_params"], seed=31)
+    dsd = synth_disc_state_dict(config["discriminator_params"], seed=32)
+    t.G.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()})
+    t.D.load_state_dict({k: torch.from_numpy(v) for k, v in dsd.items()})
+    data = SyntheticPairs(4, 60, 13, 20, seed=3)
+    ar_len = 512 if config["generator_params"]["use_ar"] else None
+    batch = WindowCollater(400, 20, ar_len, np.random.default_rng(5))([data[i] for i in range(4)])
+    return t, gsd, dsd, batch
+
+
+@pytest.mark.parametrize("use_ar", [True, False])
+def test_first_iteration_losses_vs_oracle(use_ar):
+    config = make_config(use_ar)
+    t, gsd, dsd, batch = build(config)
+    t.steps = 1  # past discriminator_train_start_steps: generator AND discriminator parts
+    log = {k: float(v) for k, v in t.train_step(batch).items()}
+    assert "libhificar.so" in open("/proc/self/maps").read()
+    # ---- the same iteration on the CPU oracle (train.py:262-424 for this configuration)
+    x, y = batch["x"], batch["y"]
+    ar = batch.get("ar")
+    gp = config["generator_params"]
+    with torch.no_grad():
+        gw = O.fold_weight_norm(gsd)
+        y_ = O.generator_forward(gw, gp, x, ar)
+        mel = DO.mel_loss(y_, y, **config["mel_loss_params"])
+        dw = DO.fold_disc_weight_norm(dsd)
+        dy = torch.cat([ar, y], 2) if use_ar else y
+        dy_ = torch.cat([ar, y_], 2) if use_ar else y_
+        p_, p = DO.disc_forward(dw, SMALL, dy_), DO.disc_forward(dw, SMALL, dy)
+        adv = DO.gen_adv_loss(p_, False)
+        fm = DO.feat_match_loss(p_, p, False, False, False)
+        gen = 45.0 * mel + 1.0 * (adv + 2.0 * fm)
+    ref = {"train/mel_loss": float(mel), "train/adversarial_loss": float(adv), "train/feature_matching_loss": float(fm), "train/generator_loss": float(gen)}
+    for k, v in ref.items():
+        assert abs(log[k] - v) < 1e-4 * max(abs(v), 1e-3), (k, log[k], v)
+    # the discriminator part runs on the UPDATED generator (train.py:389): finite, and the real loss is that of the untouched D
+    with torch.no_grad():
+        real = DO.dis_adv_loss(p_, p, False)[0]
+    assert abs(log["train/real_loss"] - float(real)) < 1e-4 * abs(float(real))
+    assert np.isfinite(log["train/fake_loss"]) and abs(log["train/discriminator_loss"] - log["train/real_loss"] - log["train/fake_loss"]) < 1e-5
+    assert t.steps == 2
+
+
+def test_training_moves_both_networks_and_checkpoint_roundtrip(tmp_path):
+    config = make_config(True)
+    t, gsd, dsd, batch = build(config)
+    t.steps = 1
+    first = {k: float(v) for k, v in t.train_step(batch).items()}
+    for _ in range(24):
+        log = t.train_step(batch)
+    last = {k: float(v) for k, v in log.items()}
+    assert all(np.isfinite(v) for v in last.values())
+    assert last["train/mel_loss"] < first["train/mel_loss"]              # the generator fits the batch
+    assert last["train/discriminator_loss"] < first["train/discriminator_loss"]
+    g_now, d_now = t.G.state_dict(), t.D.state_dict()
+    assert any(not np.allclose(g_now[k].cpu().numpy(), v) for k, v in gsd.items())
+    assert any(not np.allclose(d_now[k].cpu().numpy(), v) for k, v in dsd.items())
+    path = os.path.join(tmp_path, "checkpoint-26steps.pkl")
+    t.save_checkpoint(path)
+    state = torch.load(path, map_location="cpu")
+    assert sorted(state) == ["epochs", "model", "optimizer", "scheduler", "steps"]               # train.py:147-176
+    assert sorted(state["model"]) == ["discriminator", "generator"] and list(state["model"]["generator"]) == list(gsd)
+    assert list(state["model"]["discriminator"]) == list(dsd)
+    t2 = Trainer(config, torch.device("cuda:0"))
+    t2.load_checkpoint(path)
+    assert t2.steps == t.steps
+    a = {k: float(v) for k, v in t.train_step(batch).items()}
+    b = {k: float(v) for k, v in t2.train_step(batch).items()}
+    for k in a:
+        assert abs(a[k] - b[k]) <= 1e-5 * max(abs(a[k]), 1e-3), (k, a[k], b[k])  # resumed run = uninterrupted run

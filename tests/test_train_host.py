@@ -1,0 +1,69 @@
+"""Host logic of the training counterpart (articulatory_amd/bin/train.py) that needs no GPU: the random-window collater (reference
+articulatory/bin/train.py:1013-1035, 1071-1097), the .npy pair dataset, loud failure without a GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from articulatory_amd.bin import train as T
+
+
+def test_window_collater_cuts_matching_windows_and_ar_context():
+    hop, frames_w, ar_len = 20, 5, 64
+    rng = np.random.default_rng(0)
+    items = []
+    for n in (9, 30, 5):
+        feats = np.arange(n * 3, dtype=np.float32).reshape(n, 3) + 1000 * n
+        audio = np.arange(n * hop, dtype=np.float32) + 1
+        items.append((audio, feats))
+    col = T.WindowCollater(frames_w * hop, hop, ar_len, np.random.default_rng(7))
+    seen_pad = seen_full = False
+    for _ in range(50):
+        b = col(items)
+        assert b["x"].shape == (3, 3, frames_w) and b["y"].shape == (3, 1, frames_w * hop) and b["ar"].shape == (3, 1, ar_len)
+        for i, (audio, feats) in enumerate(items):
+            y = b["y"][i, 0].numpy()
+            s = int(y[0]) - 1                      # audio[k] = k + 1
+            assert s % hop == 0 and np.array_equal(y, audio[s:s + frames_w * hop])
+            assert np.array_equal(b["x"][i].numpy().T, feats[s // hop:s // hop + frames_w])   # the frames under the window
+            ar = b["ar"][i, 0].numpy()
+            k = min(s, ar_len)                     # samples before the window, zero padded on the left (train.py:1084-1095)
+            assert np.array_equal(ar[ar_len - k:], audio[s - k:s]) and not ar[:ar_len - k].any()
+            seen_pad |= k < ar_len
+            seen_full |= k == ar_len
+    assert seen_pad and seen_full
+    assert col([items[2]])["y"][0, 0, 0] == 1      # an utterance exactly one window long: the only start is 0
+
+
+def test_npy_pairs_drops_short_utterances_and_aligns_lengths(tmp_path):
+    hop = 10
+    a_lines, c_lines = [], []
+    for utt, frames, extra in (("a", 12, 7), ("b", 3, 0), ("c", 20, -15)):
+        np.save(tmp_path / f"{utt}-feats.npy", np.zeros((frames, 4), np.float32))
+        np.save(tmp_path / f"{utt}-wave.npy", np.zeros(frames * hop + extra, np.float32))
+        a_lines.append(f"{utt} {tmp_path / (utt + '-wave.npy')}")
+        c_lines.append(f"{utt} {tmp_path / (utt + '-feats.npy')}")
+    (tmp_path / "wav.scp").write_text("\n".join(a_lines) + "\n")
+    (tmp_path / "feats.scp").write_text("\n".join(c_lines) + "\n")
+    ds = T.NpyPairs(str(tmp_path / "wav.scp"), str(tmp_path / "feats.scp"), hop, min_frames=5)
+    assert len(ds) == 2                                                   # "b" is shorter than a window
+    for audio, feats in (ds[0], ds[1]):
+        assert len(audio) == len(feats) * hop                             # trimmed to whole frames both ways
+    assert len(ds[1][1]) == 18                                            # "c": 185 samples -> 18 frames
+
+
+def test_trainer_rejects_unbuilt_options_before_touching_the_gpu():
+    base = dict(generator_params={}, discriminator_params={})
+    with pytest.raises(NotImplementedError, match="use_stft_loss"):
+        T.Trainer(dict(base, use_stft_loss=True), torch.device("cpu"))
+    with pytest.raises(NotImplementedError, match="generator_type"):
+        T.Trainer(dict(base, generator_type="ParallelWaveGANGenerator"), torch.device("cpu"))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
+def test_main_fails_loudly_without_a_gpu(tmp_path):
+    cfg = tmp_path / "c.yaml"
+    cfg.write_text("batch_size: 2\n")
+    with pytest.raises(SystemExit, match="MI355X"):
+        T.main(["--config", str(cfg), "--outdir", str(tmp_path), "--synthetic", "4"])
