@@ -144,6 +144,7 @@ class Trainer:
         ar = batch["ar"].to(self.device, non_blocking=True) if self.use_ar else None
         log = {}
         adv_on = self.steps > cfg["discriminator_train_start_steps"]
+        disc_y = (torch.cat([ar, y], dim=2) if self.use_ar else y) if adv_on else None  # train.py:340-346 (the same tensor in both parts)
         ga = cfg.get("generator_adv_loss_params", {})
         da = cfg.get("discriminator_adv_loss_params", {})
         fm = cfg.get("feat_match_loss_params", {})
@@ -159,7 +160,6 @@ class Trainer:
                 log["train/mel_loss"] = mel_loss.detach()
             gen_loss = gen_loss * cfg.get("lambda_aux", 1.0)
             if adv_on:
-                disc_y = torch.cat([ar, y], dim=2) if self.use_ar else y
                 disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
                 use_fm = cfg.get("use_feat_match_loss", False)
                 total, adv, fml = self.D.generator_loss(
@@ -185,7 +185,6 @@ class Trainer:
         if adv_on:
             with torch.no_grad():
                 y_ = self.G(x, ar=ar)  # re-compute y_ (train.py:389-400): a training-mode forward without a graph
-            disc_y = torch.cat([ar, y], dim=2) if self.use_ar else y
             disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
             dis_loss, real_loss, fake_loss = self.D.discriminator_loss(disc_y_, disc_y, loss_type=da.get("loss_type", "mse"),
                                                                        average_by_discriminators=da.get("average_by_discriminators", True))

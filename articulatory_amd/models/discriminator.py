@@ -170,7 +170,7 @@ class _GeneratorLossFunction(torch.autograd.Function):
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             _send(module, names, params, stream)
             fake = _Pass(module, y_fake, stream)
-            real = _Pass(module, y_real, stream) if y_real is not None else None
+            real = module._real_pass(y_real, params, stream) if y_real is not None else None
             douts, doff = _aligned(int(lib.hificar_disc_dout_floats(handle, B, T)), dev)
             values = torch.empty(3, dtype=torch.float32, device=dev)
             rc = lib.hificar_disc_loss(handle, ctypes.byref(cfg), 0, fake.ptr, real.ptr if real is not None else None, B, T, values.data_ptr(),
@@ -216,7 +216,7 @@ class _DiscriminatorLossFunction(torch.autograd.Function):
             held = _send(module, names, params, stream)
             passes, douts, vals = [], [], []
             for mode, y in ((1, y_fake), (2, y_real)):
-                ps = _Pass(module, y, stream)
+                ps = _Pass(module, y, stream) if mode == 1 else module._real_pass(y, params, stream)
                 d, doff = _aligned(int(lib.hificar_disc_dout_floats(handle, B, T)), dev)
                 v = torch.empty(3, dtype=torch.float32, device=dev)
                 _native.check(lib.hificar_disc_loss(handle, ctypes.byref(cfg), mode, ps.ptr, None, B, T, v.data_ptr(), d.data_ptr() + 4 * doff, stream),
@@ -435,6 +435,19 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         cfg = _loss_cfg(loss_type, average_by_discriminators, True, True, False, 1.0, 0.0)
         names, tensors = self._raw_parameters()
         return _DiscriminatorLossFunction.apply(self, y_fake.detach(), y_real.detach(), cfg, names, *tensors)
+
+    def _real_pass(self, y_real, params, stream):
+        """D(y_real) of the generator step and of the discriminator step that follows it are the same computation (same batch, the
+        discriminator is only updated afterwards — train.py:347,421): the forward tape is kept and handed out again while neither the
+        tensor nor any parameter has changed."""
+        key = (y_real.data_ptr(), y_real._version, tuple(y_real.shape), tuple(p._version for p in params), tuple(p.data_ptr() for p in params[:4]))
+        cached = self.__dict__.get("_real_cache")
+        if cached is not None and cached[0] == key:  # (cached[2] keeps the storage alive: same address + version = same data)
+            self.__dict__["_real_cache"] = None  # one re-use: the discriminator update that follows invalidates it anyway
+            return cached[1]
+        ps = _Pass(self, y_real, stream)
+        self.__dict__["_real_cache"] = (key, ps, y_real)
+        return ps
 
     def _check(self, x):
         if not x.is_cuda:
