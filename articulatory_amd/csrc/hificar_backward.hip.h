@@ -325,6 +325,115 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
     }
 }
 
+// One-tap form with a 128 x 128 tile (the discriminators' GEMM-form convs: dW [N x Kg] = dZ^T A with few rows M and wide Kg): a wave owns
+// a 64 x 64 block as 2 x 2 accumulators, so a 64-row chunk staged once (64 KB) feeds 128 MFMAs per wave instead of the 32 of the
+// 64 x 64 tile above, which is bound by the staging traffic at one tap.  Same partial layout, bias sums and z replicas.
+constexpr int kWggR = 64;
+
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradTapsPair pair) {
+    extern __shared__ __attribute__((aligned(1024))) char wgg_smem[];
+    const WgradTapsParams& q = pair.q[blockIdx.z / pair.zg];
+    const int zi = blockIdx.z % pair.zg;
+    const float* const g_base = q.w.g + (size_t)zi * q.zs_g;
+    const float* const a_base = q.w.a + (size_t)zi * q.zs_a;
+    float* const partial_base = q.w.partial + (size_t)zi * q.zs_partial;
+    float* const bias_base = q.w.bias_partial ? q.w.bias_partial + (size_t)zi * q.zs_bias : nullptr;
+    const WgradParams& p = q.w;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hf = lane >> 5;
+    const int at_n = (p.n_ablk + 3) >> 2;
+    const int at = blockIdx.x % at_n, gt = blockIdx.x / at_n;
+    const int split = blockIdx.y;
+    const int gw = wave >> 1, aw = wave & 1;
+    constexpr int buf_floats = 2 * kWggR * 128;  // G rows then A rows
+    const int cps = (p.L + kWggR - 1) / kWggR;
+    const int nchunks = p.nseq * cps;
+    const int c_lo = (int)((long long)nchunks * split / p.nsplit), c_hi = (int)((long long)nchunks * (split + 1) / p.nsplit);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // LDS-DMA: 1 KiB = 2 rows of 128 channels per wave-instruction, lane -> (row 2 i + lane / 32, channels 4 (lane % 32) ..)
+    auto stage = [&](int c, int b) {
+        const int seq = c / cps;
+        const int t0 = (c - seq * cps) * kWggR;
+        char* dst = wgg_smem + (size_t)b * buf_floats * 4;
+        const int c4 = (lane & 31) * 4;
+        for (int i = wave; i < kWggR / 2; i += 4) {
+            const int t = t0 + 2 * i + (lane >> 5);
+            const char* gsrc = q.zeros;
+            const char* asrc = q.zeros;
+            const int gch = gt * 128 + c4, ach = at * 128 + c4;
+            if (t < p.L) {
+                if (gch < p.gpitch) gsrc = reinterpret_cast<const char*>(g_base + ((size_t)seq * p.L + t) * p.gpitch + gch);
+                if (ach < p.apitch) asrc = reinterpret_cast<const char*>(a_base + ((size_t)seq * p.L + t) * p.apitch + ach);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)asrc,
+                                             (__attribute__((address_space(3))) void*)(dst + kWggR * 512 + i * 1024), 16, 0, 0);
+        }
+    };
+    const bool do_bias = bias_base && at == 0;
+    float bsum = 0.f;
+    if (c_lo < c_hi) stage(c_lo, 0);
+    __syncthreads();
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int b = (c - c_lo) & 1;
+        if (c + 1 < c_hi) stage(c + 1, b ^ 1);
+        const float* gs = reinterpret_cast<const float*>(wgg_smem) + (size_t)b * buf_floats;
+        const float* as = gs + kWggR * 128;
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = tid >> 7; r < kWggR; r += 2) bsum += gs[r * 128 + (tid & 127)];
+        }
+        {
+            const float* gp = gs + hf * 128 + gw * 64 + li;
+            const float* ap = as + hf * 128 + aw * 64 + li;
+            float g0[2] = {gp[0], gp[32]}, a0[2] = {ap[0], ap[32]}, g1[2], a1[2];
+#pragma unroll
+            for (int kb = 0; kb < kWggR; kb += 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k += 4) {
+                    const int r1 = (kb + k + 2) * 128, r2 = (kb + k + 4) * 128;  // (the last fetch reads two rows past the chunk: unused)
+                    g1[0] = gp[r1], g1[1] = gp[r1 + 32], a1[0] = ap[r1], a1[1] = ap[r1 + 32];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0[i], a0[j], acc[i][j], 0, 0, 0);
+                    g0[0] = gp[r2], g0[1] = gp[r2 + 32], a0[0] = ap[r2], a0[1] = ap[r2 + 32];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[i], a1[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (do_bias) {
+        float* red = reinterpret_cast<float*>(wgg_smem);
+        red[(tid >> 7) * 128 + (tid & 127)] = bsum;
+        __syncthreads();
+        const int ch = gt * 128 + tid;
+        if (tid < 128 && ch < p.n_gblk * 32) bias_base[(size_t)split * p.n_gblk * 32 + ch] = red[tid] + red[128 + tid];
+    }
+    const int gpad = p.n_gblk * 32, apad = p.n_ablk * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gblk = gt * 4 + gw * 2 + i, ablk = at * 4 + aw * 2 + j;
+            if (gblk >= p.n_gblk || ablk >= p.n_ablk) continue;
+            float* dst = partial_base + ((size_t)split * gpad + gblk * 32) * apad + ablk * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hf) * apad] = acc[i][j][r];
+        }
+}
+
 // dW in the reference's layout from the partials, summed over the splits in a fixed order.
 //   Conv1d          : dst[(co * cin + ci) * K + k]     g = co, a = ci, k = tap
 //   ConvTranspose1d : dst[(ci * cout + co) * K + k]    g = r * cout_pad + co (phase-major), a = ci, k = tap_k[r][tap] (< 0: no such weight)

@@ -20,6 +20,7 @@ from bench import CAR_PARAMS  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--torch-profile", action="store_true")
 a = ap.parse_args()
 adam = {"lr": 1.0e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}
 sched = {"gamma": 0.5, "milestones": [40000, 80000, 120000, 160000]}
@@ -49,3 +50,11 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(f"GAN iteration (G step + D step, batch {a.batch} x 2000 samples): {dt * 1e3:.2f} ms, {a.batch / dt:.0f} windows/s, "
       + ", ".join(f"{k.split('/')[1]} {float(v):.4f}" for k, v in sorted(log.items())))
+if a.torch_profile:
+    from torch.profiler import ProfilerActivity, profile
+
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(2):
+            trainer.train_step(batch)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
