@@ -96,6 +96,22 @@ for prec in ("f32", "bf16x3"):
     print(open(f"profiles/{tag}_{prec}_kernel_stats.csv").read()[:1500])
     print(open(f"profiles/{tag}_{prec}_pmc_mfma.csv").read()[:2500])
     print(traffic)
+for what, cmd in (("train", "python tools/train_bench.py --steps 5"), ("gan", "python tools/gan_bench.py --steps 5")):
+    base = f"gpurun_out/prof_{tag}_{what}"
+    if not os.path.isdir(base + "_stats"):
+        continue
+    rows = list(csv.DictReader(open(find(base + "_stats", "*kernel_stats.csv"))))
+    with open(f"profiles/{tag}_{what}_kernel_stats.csv", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -f csv -- {cmd}  ({tag}; 3 warm-up + 5 timed iterations, torch kernels included); durations in ns\n")
+        w = csv.writer(f)
+        w.writerow(rows[0].keys())
+        for r in rows:
+            if float(r.get("Percentage", 0) or 0) >= 0.05:
+                w.writerow(r.values())
+    txt = f"{base}_bench.txt"
+    if os.path.exists(txt):
+        lines = [ln for ln in open(txt).read().splitlines() if "ms" in ln and ("step" in ln or "iteration" in ln)]
+        open(f"profiles/{tag}_{what}_bench_under_rocprof.txt", "w").write("\n".join(lines) + "\n")
 allt["_comment"] = ("HBM bytes per launch from rocprofv3 PMC, (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction), "
                     "see profiles/*_pmc_hbm.csv; keyed by precision then kernel name as bench.py reports it")
 json.dump(allt, open("profiles/hbm_traffic.json", "w"), indent=1, sort_keys=True)
