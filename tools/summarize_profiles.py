@@ -12,9 +12,9 @@ import sys
 
 
 def find(path, pattern):
-    hits = sorted(glob.glob(os.path.join(path, "**", pattern), recursive=True))
+    hits = sorted(glob.glob(os.path.join(path, "**", pattern), recursive=True), key=os.path.getmtime)
     assert hits, (path, pattern)
-    return hits[0]
+    return hits[-1]  # gpurun merges a new run's files into the old directories: the newest is this run's
 
 
 def short(k):
