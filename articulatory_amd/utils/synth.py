@@ -283,13 +283,14 @@ def disc_param_spec(**kw):
         layers = period_disc_layers(**pp)
         for l, L in enumerate(layers):
             base = f"mpd.discriminators.{i}." + (f"convs.{l}.0" if L["act"] else "output_conv")
-            spec[base + ".bias"] = (L["cout"],)
             shape = (L["cout"], L["cin"], L["k"], 1)
-            if wn:
+            if wn:  # a weight-normed module lists bias first (bias, weight_g, weight_v), a plain one weight, bias
+                spec[base + ".bias"] = (L["cout"],)
                 spec[base + ".weight_g"] = (L["cout"], 1, 1, 1)
                 spec[base + ".weight_v"] = shape
             else:
                 spec[base + ".weight"] = shape
+                spec[base + ".bias"] = (L["cout"],)
     return spec
 
 

@@ -57,6 +57,33 @@ def test_config_struct_matches_header_layout(tmp_path):
     assert got == want
 
 
+def test_training_structs_match_header_layout(tmp_path):
+    """The discriminator / loss / mel structs of the training entry points: ctypes mirrors vs the C header, field by field."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    pairs = [("hificar_disc_config", _native.HificarDiscConfig), ("hificar_disc_output", _native.HificarDiscOutput),
+             ("hificar_gan_loss_config", _native.HificarGanLossConfig), ("hificar_mel_config", _native.HificarMelConfig)]
+    body, want = "", []
+    for cname, cls in pairs:
+        body += f'  printf("%zu\\n", sizeof({cname}));\n'
+        want.append(ctypes.sizeof(cls))
+        for f in cls._fields_:
+            body += f'  printf("%zu\\n", offsetof({cname}, {f[0]}));\n'
+            want.append(getattr(cls, f[0]).offset)
+    src = tmp_path / "layout2.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hificar.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    exe = tmp_path / "layout2"
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == want
+    assert _native.DISC_MAX_SUBS == 8 and _native.DISC_MAX_LAYERS == 12  # HIFICAR_DISC_MAX_* of the header
+    hdr = open(os.path.join(inc, "hificar.h")).read()
+    assert "#define HIFICAR_DISC_MAX_SUBS 8" in hdr and "#define HIFICAR_DISC_MAX_LAYERS 12" in hdr
+
+
 def test_create_macs_workspace(lib):
     cfg = _native.make_config(_full_params(), _native.PREC_F32)
     h = ctypes.c_void_p()

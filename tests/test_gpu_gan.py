@@ -108,3 +108,30 @@ def test_training_moves_both_networks_and_checkpoint_roundtrip(tmp_path):
     b = {k: float(v) for k, v in t2.train_step(batch).items()}
     for k in a:
         assert abs(a[k] - b[k]) <= 1e-5 * max(abs(a[k]), 1e-3), (k, a[k], b[k])  # resumed run = uninterrupted run
+
+
+def test_distributed_iteration_over_rccl_world1():
+    """Trainer(distributed=True): both networks all-reduce their flat gradient buffers inside backward over the "nccl" (RCCL) backend.
+    One GPU here, so a world of one rank: the collectives run and the iteration equals the single-process one."""
+    import torch.distributed as dist
+
+    config = make_config(True)
+    t0, _, _, batch = build(config)
+    t0.steps = 1
+    want = {k: float(v) for k, v in t0.train_step(batch).items()}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        t = Trainer(config, torch.device("cuda:0"), distributed=True)
+        t.G.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(config["generator_params"], seed=31).items()})
+        t.D.load_state_dict({k: torch.from_numpy(v) for k, v in synth_disc_state_dict(config["discriminator_params"], seed=32).items()})
+        assert t.G._grad_sync is not None and t.D._grad_sync is not None
+        t.steps = 1
+        got = {k: float(v) for k, v in t.train_step(batch).items()}
+        for k in want:
+            assert abs(got[k] - want[k]) <= 1e-5 * max(abs(want[k]), 1e-3), (k, got[k], want[k])
+        a, b = t.D.state_dict(), t0.D.state_dict()
+        assert all(torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7) for k in a)
+    finally:
+        dist.destroy_process_group()
