@@ -64,6 +64,8 @@ SYMBOLS = (
     "hificar_mel_destroy",
     "hificar_mel_workspace_bytes",
     "hificar_mel_loss",
+    "hificar_stft_loss_forward",
+    "hificar_stft_loss_backward",
     "hificar_tape_bytes",
     "hificar_forward_train",
     "hificar_backward_workspace_bytes",
@@ -163,6 +165,7 @@ class HificarMelConfig(ctypes.Structure):
         ("num_mels", ctypes.c_int32),
         ("eps", ctypes.c_float),
         ("log_base", ctypes.c_int32),
+        ("mode", ctypes.c_int32),
     ]
 
 
@@ -292,6 +295,10 @@ def load_library():
     lib.hificar_mel_workspace_bytes.restype = cs
     lib.hificar_mel_loss.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, cs, vp]
     lib.hificar_mel_loss.restype = ci
+    lib.hificar_stft_loss_forward.argtypes = [vp, vp, vp, ci, ci, vp, vp, cs, vp]
+    lib.hificar_stft_loss_forward.restype = ci
+    lib.hificar_stft_loss_backward.argtypes = [vp, ci, ci, vp, vp, vp, cs, vp]
+    lib.hificar_stft_loss_backward.restype = ci
     lib.hificar_tape_bytes.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.hificar_tape_bytes.restype = ctypes.c_size_t
     lib.hificar_forward_train.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]

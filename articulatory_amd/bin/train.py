@@ -28,7 +28,7 @@ import numpy as np
 import torch
 import yaml
 
-from articulatory_amd.losses import MelSpectrogramLoss
+from articulatory_amd.losses import MelSpectrogramLoss, MultiResolutionSTFTLoss
 from articulatory_amd.models import HiFiGANGenerator, HiFiGANMultiScaleMultiPeriodDiscriminator
 
 
@@ -112,14 +112,15 @@ class Trainer:
             raise NotImplementedError(f"generator_type {config['generator_type']} is not built")
         if config.get("discriminator_type", "HiFiGANMultiScaleMultiPeriodDiscriminator") != "HiFiGANMultiScaleMultiPeriodDiscriminator":
             raise NotImplementedError(f"discriminator_type {config['discriminator_type']} is not built")
-        for flag in ("use_stft_loss", "use_subband_stft_loss", "use_inter_loss", "use_ph_loss", "use_pcd"):
+        for flag in ("use_subband_stft_loss", "use_inter_loss", "use_ph_loss", "use_pcd"):
             if config.get(flag, False):
-                raise NotImplementedError(f"{flag} is not built (SURVEY.md §8 f1 covers the shipped HiFi-GAN / HiFi-CAR recipes: mel loss)")
+                raise NotImplementedError(f"{flag} is not built (SURVEY.md §8 f1 covers the HiFi-GAN / HiFi-CAR recipes: mel or multi-resolution STFT loss)")
         gp = config["generator_params"]
         self.use_ar = bool(gp.get("use_ar", False))
         self.G = HiFiGANGenerator(**gp, precision="f32").to(device).train()
         self.D = HiFiGANMultiScaleMultiPeriodDiscriminator(**config["discriminator_params"]).to(device).train()
         self.mel = MelSpectrogramLoss(**config["mel_loss_params"]) if config.get("use_mel_loss", False) else None
+        self.stft = MultiResolutionSTFTLoss(**config.get("stft_loss_params", {})) if config.get("use_stft_loss", False) else None  # train.py:1688
         if distributed:
             self.G.sync_gradients()
             self.D.sync_gradients()
@@ -154,6 +155,11 @@ class Trainer:
         if self.steps > cfg.get("generator_train_start_steps", 0):
             y_ = self.G(x, ar=ar)
             gen_loss = 0.0
+            if self.stft is not None:  # train.py:288-297
+                sc_loss, mag_loss = self.stft(y_, y)
+                gen_loss = gen_loss + sc_loss + mag_loss
+                log["train/spectral_convergence_loss"] = sc_loss.detach()
+                log["train/log_stft_magnitude_loss"] = mag_loss.detach()
             if self.mel is not None:
                 mel_loss = self.mel(y_, y)
                 gen_loss = gen_loss + mel_loss

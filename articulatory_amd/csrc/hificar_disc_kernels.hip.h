@@ -442,4 +442,70 @@ __global__ __launch_bounds__(256) void mel_ola_kernel(const OlaParams p) {  // b
     }
 }
 
+// Multi-resolution STFT loss (articulatory/losses/stft_loss.py:43-170), one resolution: on the magnitudes x = |STFT(y_hat)|, y = |STFT(y)|
+//   spectral convergence  ||y - x||_F / ||y||_F        log STFT magnitude  mean |log y - log x|
+// sums: per-workgroup partials of (sum (y - x)^2, sum y^2, sum |log y - log x|); final: the two values + the totals the gradient needs.
+struct StftLossParams {
+    const float* x;    // [M][nfp] magnitudes of the generated signal
+    const float* y;    // ground truth
+    float* partial;    // [blocks][3]
+    float* sums;       // [4]: S1, S2, S3, -
+    float* values;     // [2]: sc, mag
+    const float* gw;   // backward: [2] upstream gradients of (sc, mag)
+    float* dx;         // backward: [M][nfp]
+    long long total;   // M * nfp
+    int nf, nfp, blocks;
+    float inv_numel;   // 1 / (M * nf)
+};
+
+__global__ __launch_bounds__(256) void stft_loss_sums_kernel(const StftLossParams p) {
+    __shared__ float red[4];
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        if ((int)(i % p.nfp) >= p.nf) continue;
+        const float x = p.x[i], y = p.y[i];
+        s1 += (y - x) * (y - x);
+        s2 += y * y;
+        s3 += fabsf(logf(y) - logf(x));
+    }
+    s1 = wg_sum256(s1, red);
+    s2 = wg_sum256(s2, red);
+    s3 = wg_sum256(s3, red);
+    if (threadIdx.x == 0) {
+        p.partial[blockIdx.x * 3] = s1;
+        p.partial[blockIdx.x * 3 + 1] = s2;
+        p.partial[blockIdx.x * 3 + 2] = s3;
+    }
+}
+
+__global__ void stft_loss_final_kernel(const StftLossParams p) {  // one thread: fixed-order totals
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int b = 0; b < p.blocks; ++b) {
+        s1 += p.partial[b * 3];
+        s2 += p.partial[b * 3 + 1];
+        s3 += p.partial[b * 3 + 2];
+    }
+    p.sums[0] = s1;
+    p.sums[1] = s2;
+    p.sums[2] = s3;
+    p.values[0] = sqrtf(s1) / sqrtf(s2);
+    p.values[1] = s3 * p.inv_numel;
+}
+
+__global__ __launch_bounds__(256) void stft_loss_grad_kernel(const StftLossParams p) {  // d(gw0 * sc + gw1 * mag) / dx
+    const float s1 = p.sums[0], s2 = p.sums[1];
+    const float csc = s1 > 0.f ? p.gw[0] / (sqrtf(s1) * sqrtf(s2)) : 0.f;
+    const float cmag = p.gw[1] * p.inv_numel;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        float g = 0.f;
+        if ((int)(i % p.nfp) < p.nf) {
+            const float x = p.x[i], y = p.y[i];
+            const float dl = logf(x) - logf(y);
+            g = csc * (x - y) + cmag * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f)) / x;
+        }
+        p.dx[i] = g;
+    }
+}
+
 }  // namespace hificar

@@ -111,7 +111,7 @@ class MelSpectrogramLoss(torch.nn.Module):
         fmax = fs / 2 if fmax is None else fmax
         self.melmat = np.ascontiguousarray(mel_filterbank(fs, fft_size, num_mels, fmin, fmax))
         self._cfg = _native.HificarMelConfig(fft_size, hop_size, fft_size if win_length is None else win_length, num_mels, eps,
-                                             0 if log_base is None else int(log_base))
+                                             0 if log_base is None else int(log_base), 0)
         self._lib = self._handle = None
 
     def _native_handle(self, dev):
@@ -141,3 +141,83 @@ class MelSpectrogramLoss(torch.nn.Module):
             raise RuntimeError(f"Expected two (B, C, T) tensors of one shape, got {tuple(y_hat.shape)} and {tuple(y.shape)}")
         self._native_handle(y_hat.device)
         return _MelLossFunction.apply(self, y_hat, y)
+
+
+# ------------------------------------------------------------------------------------------------
+# Multi-resolution STFT loss (stft_loss.py:128-170)
+# ------------------------------------------------------------------------------------------------
+class _StftLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, y_hat, y):
+        lib, handle = module._lib, module._handle
+        B, T = y_hat.shape
+        dev = y_hat.device
+        yh = y_hat.detach().to(torch.float32).contiguous()
+        yr = y.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            wsb = int(lib.hificar_mel_workspace_bytes(handle, B, T))
+            ws = torch.empty(wsb // 4 + 64, dtype=torch.float32, device=dev)
+            woff = ((-ws.data_ptr()) % 256) // 4
+            values = torch.empty(2, dtype=torch.float32, device=dev)
+            rc = lib.hificar_stft_loss_forward(handle, yh.data_ptr(), yr.data_ptr(), B, T, values.data_ptr(), ws.data_ptr() + 4 * woff, wsb, stream)
+        _native.check(rc, "hificar_stft_loss_forward")
+        ctx.module, ctx.ws, ctx.woff, ctx.wsb, ctx.BT = module, ws, woff, wsb, (B, T)
+        return values[0], values[1]
+
+    @staticmethod
+    def backward(ctx, g_sc, g_mag):
+        module = ctx.module
+        B, T = ctx.BT
+        dev = ctx.ws.device
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            gw = torch.stack([g_sc, g_mag]).to(torch.float32).contiguous()
+            dy = torch.empty((B, T), dtype=torch.float32, device=dev)
+            rc = module._lib.hificar_stft_loss_backward(module._handle, B, T, gw.data_ptr(), dy.data_ptr(), ctx.ws.data_ptr() + 4 * ctx.woff, ctx.wsb, stream)
+        _native.check(rc, "hificar_stft_loss_backward")
+        ctx.ws = None
+        return None, dy, None
+
+
+class STFTLoss(torch.nn.Module):
+    """One resolution (stft_loss.py:87-125): (spectral convergence, log STFT magnitude).  MI355X-native."""
+
+    def __init__(self, fft_size=1024, shift_size=120, win_length=600, window="hann_window"):
+        super().__init__()
+        if window != "hann_window":
+            raise NotImplementedError("STFTLoss: only window='hann_window' is built")
+        self._cfg = _native.HificarMelConfig(fft_size, shift_size, win_length, 0, 1e-7, 0, 1)  # clamp(re^2 + im^2, 1e-7), stft_loss.py:40
+        self._lib = self._handle = None
+
+    _native_handle = MelSpectrogramLoss._native_handle
+    __del__ = MelSpectrogramLoss.__del__
+    melmat = np.zeros((1, 1), np.float32)  # (unused in this mode)
+
+    def forward(self, x, y):
+        """x (predicted), y (ground truth): (B, T) -> (sc_loss, mag_loss)."""
+        if not x.is_cuda:
+            raise RuntimeError("STFTLoss needs CUDA/HIP tensors; there is no CPU fallback")
+        self._native_handle(x.device)
+        return _StftLossFunction.apply(self, x, y)
+
+
+class MultiResolutionSTFTLoss(torch.nn.Module):
+    """Constructor arguments and return values as the reference's (stft_loss.py:128-170)."""
+
+    def __init__(self, fft_sizes=[1024, 2048, 512], hop_sizes=[120, 240, 50], win_lengths=[600, 1200, 240], window="hann_window"):
+        super().__init__()
+        assert len(fft_sizes) == len(hop_sizes) == len(win_lengths)
+        self.stft_losses = torch.nn.ModuleList([STFTLoss(fs, ss, wl, window) for fs, ss, wl in zip(fft_sizes, hop_sizes, win_lengths)])
+
+    def forward(self, x, y):
+        if x.dim() == 3:
+            x = x.reshape(-1, x.size(2))  # (B, C, T) -> (B x C, T)
+            y = y.reshape(-1, y.size(2))
+        sc_loss, mag_loss = 0.0, 0.0
+        for f in self.stft_losses:
+            sc, mag = f(x, y)
+            sc_loss = sc_loss + sc
+            mag_loss = mag_loss + mag
+        n = len(self.stft_losses)
+        return sc_loss / n, mag_loss / n

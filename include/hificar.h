@@ -338,11 +338,19 @@ typedef struct hificar_mel_config {
     int fft_size, hop_size, win_length, num_mels;
     float eps;
     int log_base;
+    int mode;   /* 0: mel-spectrogram loss; 1: one resolution of the multi-resolution STFT loss (melmat, num_mels, log_base unused) */
 } hificar_mel_config;
 typedef struct hificar_mel hificar_mel;
 int hificar_mel_create(const hificar_mel_config* cfg, const float* melmat, hificar_mel** out);
 void hificar_mel_destroy(hificar_mel* m);
 size_t hificar_mel_workspace_bytes(const hificar_mel* m, int B, int T);
+/* One resolution of MultiResolutionSTFTLoss (articulatory/losses/stft_loss.py:87-125; train.py:289-290) on a mode-1 handle: forward ->
+ * values = {spectral convergence, log STFT magnitude} (2 device floats), the magnitudes stay in `workspace`; backward (same workspace):
+ * dy_hat (B, T) = d(gweights[0] * sc + gweights[1] * mag) / dy_hat, gweights = 2 DEVICE floats (the upstream gradients). */
+int hificar_stft_loss_forward(hificar_mel* m, const float* y_hat, const float* y, int B, int T, float* values2, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int hificar_stft_loss_backward(hificar_mel* m, int B, int T, const float* gweights2, float* dy_hat, void* workspace, size_t workspace_bytes,
+                               void* stream);
 int hificar_mel_loss(hificar_mel* m, const float* y_hat, const float* y, int B, int T, float* value, float* dy_hat, void* workspace,
                      size_t workspace_bytes, void* stream);
 

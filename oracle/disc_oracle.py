@@ -13,6 +13,7 @@ Follows, function by function:
   articulatory/losses/adversarial_loss.py:12-123  Generator / Discriminator adversarial losses (mse, hinge)
   articulatory/losses/feat_match_loss.py:12-54    FeatureMatchLoss
   articulatory/losses/mel_loss.py:16-166          MelSpectrogram / MelSpectrogramLoss (torch.stft, center, hann; librosa.filters.mel)
+  articulatory/losses/stft_loss.py:16-170         stft magnitude, SpectralConvergenceLoss, LogSTFTMagnitudeLoss, MultiResolutionSTFTLoss
 Pinned by tests/golden/gold_disc_*.npz (oracle/make_golden_disc.py, real reference) — except the mel filterbank: librosa is not in
 this image, so ``mel_filterbank`` restates librosa.filters.mel 0.9 (Slaney scale, slaney norm) from its published algorithm and the mel
 loss is PARITY UNPINNED against the reference (it is checked against an independent float64 DFT restatement instead).
@@ -185,6 +186,25 @@ def mel_spectrogram(x, fs=22050, fft_size=1024, hop_size=256, win_length=None, w
 
 def mel_loss(y_hat, y, **kw):
     return F.l1_loss(mel_spectrogram(y_hat, **kw), mel_spectrogram(y, **kw))
+
+
+def stft_magnitude(x, fft_size, hop_size, win_length):
+    """stft_loss.py:16-40 (hann window, center, reflect padding; clamp 1e-7)."""
+    win = torch.hann_window(win_length, dtype=x.dtype)
+    spec = torch.view_as_real(torch.stft(x, fft_size, hop_size, win_length, win, return_complex=True))
+    return torch.sqrt(torch.clamp(spec[..., 0] ** 2 + spec[..., 1] ** 2, min=1e-7)).transpose(2, 1)
+
+
+def multi_resolution_stft_loss(x, y, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50), win_lengths=(600, 1200, 240)):
+    """stft_loss.py:43-170: x predicted, y ground truth, (B, T) or (B, C, T) -> (sc_loss, mag_loss)."""
+    if x.dim() == 3:
+        x, y = x.reshape(-1, x.size(2)), y.reshape(-1, y.size(2))
+    sc, mag = 0.0, 0.0
+    for fs, ss, wl in zip(fft_sizes, hop_sizes, win_lengths):
+        xm, ym = stft_magnitude(x, fs, ss, wl), stft_magnitude(y, fs, ss, wl)
+        sc = sc + torch.norm(ym - xm, p="fro") / torch.norm(ym, p="fro")
+        mag = mag + F.l1_loss(torch.log(ym), torch.log(xm))
+    return sc / len(fft_sizes), mag / len(fft_sizes)
 
 
 def disc_gradients(sd, params, x, cots, dtype=torch.float32):

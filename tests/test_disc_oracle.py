@@ -137,3 +137,32 @@ def test_mel_filterbank_and_spectrogram_against_float64_dft():
         ref[:, :, t] = np.log(np.maximum(amp @ fb.T.astype(np.float64), 1e-10))
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() < 2e-3  # log-mel of fp32 STFT vs float64
+
+
+def test_stft_loss_oracle_against_float64_dft():
+    """The reference's stft() calls torch.stft(..., return_complex=False), which torch 2.x rejects, so its MultiResolutionSTFTLoss cannot
+    be run here: the restatement (same torch.stft parameters, complex output) is checked against a direct float64 DFT of the frames —
+    window shorter than the frame (centred, zero-padded), reflect padding — and the two loss formulas are recomputed by hand."""
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((2, 1500)) * 0.1).astype(np.float32)
+    y = (x + rng.standard_normal((2, 1500)) * 0.02).astype(np.float32)
+    fs, ss, wl = 512, 50, 240
+
+    def mags(sig):
+        pad = np.pad(sig.astype(np.float64), ((0, 0), (fs // 2, fs // 2)), mode="reflect")
+        n = np.arange(wl)
+        win = np.zeros(fs)
+        win[(fs - wl) // 2:(fs - wl) // 2 + wl] = 0.5 - 0.5 * np.cos(2 * np.pi * n / wl)
+        frames = 1 + sig.shape[1] // ss
+        out = np.zeros((sig.shape[0], frames, fs // 2 + 1))
+        for t in range(frames):
+            out[:, t] = np.sqrt(np.maximum(np.abs(np.fft.rfft(pad[:, t * ss:t * ss + fs] * win, axis=1)) ** 2, 1e-7))
+        return out
+
+    got = DO.stft_magnitude(torch.from_numpy(x), fs, ss, wl).numpy()
+    ref = mags(x)
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-5 * ref.max()
+    sc, mag = DO.multi_resolution_stft_loss(torch.from_numpy(x), torch.from_numpy(y), [fs], [ss], [wl])
+    xm, ym = mags(x), mags(y)
+    assert abs(float(sc) - np.linalg.norm(ym - xm) / np.linalg.norm(ym)) < 1e-4 * float(sc)
+    assert abs(float(mag) - np.abs(np.log(ym) - np.log(xm)).mean()) < 1e-4 * float(mag)

@@ -200,3 +200,27 @@ def test_mel_loss_vs_oracle(log_base, T):
     # |.| of log-mel differences is kinked (sign flips where the two log-mels agree to rounding): direction + most elements
     assert 1.0 - float(g @ gr) / float(np.linalg.norm(g) * np.linalg.norm(gr)) < 1e-5
     assert (np.abs(g - gr) < 1e-3 * np.abs(gr).max()).mean() > 0.98
+
+
+@pytest.mark.parametrize("T", [2000, 2483])
+def test_multi_resolution_stft_loss_vs_oracle(T):
+    """MultiResolutionSTFTLoss with the reference's default resolutions (fft 1024 / 2048 / 512, windows shorter than the frames):
+    both values and the gradient of a weighted sum against torch.stft on the CPU."""
+    from articulatory_amd.losses import MultiResolutionSTFTLoss
+
+    B = 3
+    rng = np.random.default_rng(13)
+    y = (rng.standard_normal((B, 1, T)) * 0.2).astype(np.float32)
+    yh = (y + rng.standard_normal((B, 1, T)) * 0.05).astype(np.float32)
+    crit = MultiResolutionSTFTLoss()
+    a = torch.from_numpy(yh).cuda().requires_grad_(True)
+    sc, mag = crit(a, torch.from_numpy(y).cuda())
+    (0.7 * sc + 1.3 * mag).backward()
+    ar = torch.from_numpy(yh).requires_grad_(True)
+    sc_r, mag_r = DO.multi_resolution_stft_loss(ar, torch.from_numpy(y))
+    (0.7 * sc_r + 1.3 * mag_r).backward()
+    assert abs(float(sc.detach()) - float(sc_r.detach())) < 1e-4 * float(sc_r.detach())
+    assert abs(float(mag.detach()) - float(mag_r.detach())) < 1e-4 * float(mag_r.detach())
+    g, gr = a.grad.cpu().numpy().reshape(-1).astype(np.float64), ar.grad.numpy().reshape(-1).astype(np.float64)
+    assert 1.0 - float(g @ gr) / float(np.linalg.norm(g) * np.linalg.norm(gr)) < 1e-5
+    assert (np.abs(g - gr) < 1e-3 * np.abs(gr).max()).mean() > 0.98

@@ -55,8 +55,8 @@ def test_npy_pairs_drops_short_utterances_and_aligns_lengths(tmp_path):
 
 def test_trainer_rejects_unbuilt_options_before_touching_the_gpu():
     base = dict(generator_params={}, discriminator_params={})
-    with pytest.raises(NotImplementedError, match="use_stft_loss"):
-        T.Trainer(dict(base, use_stft_loss=True), torch.device("cpu"))
+    with pytest.raises(NotImplementedError, match="use_subband_stft_loss"):
+        T.Trainer(dict(base, use_subband_stft_loss=True), torch.device("cpu"))
     with pytest.raises(NotImplementedError, match="generator_type"):
         T.Trainer(dict(base, generator_type="ParallelWaveGANGenerator"), torch.device("cpu"))
 

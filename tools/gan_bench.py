@@ -21,6 +21,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--recipe", default="car", choices=["car", "e2w", "mri"],
                 help="car: e2w_hifigan_car.yaml (batch 64 x 2000 samples); e2w: e2w_hifigan.yaml (32 x 8000, mel hop 80); "
                      "mri: mri2w_hifigan_car.yaml (16 x 30000, 230-dim features, x240 upsampling, 20 kHz)")
+ap.add_argument("--aux", default="mel", choices=["mel", "stft"], help="auxiliary loss: the shipped YAMLs' mel loss, or the multi-resolution "
+                "STFT loss BASELINE config 5 names (reference defaults: fft 1024 / 2048 / 512)")
 ap.add_argument("--batch", type=int, default=None)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--torch-profile", action="store_true")
@@ -39,7 +41,7 @@ config = dict(  # e2w_hifigan_car.yaml
     generator_type="HiFiGANGenerator", generator_params=dict(CAR_PARAMS, **g_over),
     discriminator_type="HiFiGANMultiScaleMultiPeriodDiscriminator",
     discriminator_params=dict(scale_discriminator_params=dict(disc_params()["scale_discriminator_params"], downsample_scales=[4, 4, 4, 4, 1])),
-    use_stft_loss=False, use_mel_loss=True,
+    use_stft_loss=a.aux == "stft", use_mel_loss=a.aux == "mel", stft_loss_params={},
     mel_loss_params=dict(fs=r_fs, fft_size=1024, hop_size=r_melhop, win_length=None, window="hann", num_mels=80, fmin=0, fmax=11025, log_base=None),
     generator_adv_loss_params={"average_by_discriminators": False}, discriminator_adv_loss_params={"average_by_discriminators": False},
     use_feat_match_loss=True, feat_match_loss_params={"average_by_discriminators": False, "average_by_layers": False, "include_final_outputs": False},
