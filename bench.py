@@ -180,6 +180,67 @@ def roofline_block(stats, precision, wall_s, steps, traffic_table):
     return blk
 
 
+def training_leg(gen_params):
+    """Secondary, informational: the train step of BASELINE config 5's recipe on this GPU — the generator's
+    forward + backward + Adam, and the full GAN iteration of articulatory_amd/bin/train.py::Trainer (generator + multi-scale /
+    multi-period discriminators, mel + adversarial + feature-matching losses, both Adam updates) at e2w_hifigan_car.yaml's batch
+    (64 windows of 2000 samples + 512 AR samples).  Exact fp32.  Not part of `value`."""
+    import numpy as np
+    import torch
+
+    from articulatory_amd.bin.train import SyntheticPairs, Trainer, WindowCollater
+    from articulatory_amd.utils.synth import disc_params
+
+    adam = {"lr": 1.0e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}
+    sched = {"gamma": 0.5, "milestones": [40000, 80000, 120000, 160000]}
+    cfg = dict(
+        generator_params=dict(gen_params),
+        discriminator_params=dict(scale_discriminator_params=dict(disc_params()["scale_discriminator_params"], downsample_scales=[4, 4, 4, 4, 1])),
+        use_mel_loss=True, mel_loss_params=dict(fs=16000, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=0,
+                                                fmax=11025, log_base=None),
+        generator_adv_loss_params={"average_by_discriminators": False}, discriminator_adv_loss_params={"average_by_discriminators": False},
+        use_feat_match_loss=True, feat_match_loss_params={"average_by_discriminators": False, "average_by_layers": False, "include_final_outputs": False},
+        lambda_aux=45.0, lambda_adv=1.0, lambda_feat_match=2.0, batch_size=64, batch_max_steps=2000,
+        generator_optimizer_type="Adam", generator_optimizer_params=adam, generator_scheduler_type="MultiStepLR", generator_scheduler_params=sched,
+        discriminator_optimizer_type="Adam", discriminator_optimizer_params=adam, discriminator_scheduler_type="MultiStepLR",
+        discriminator_scheduler_params=sched, discriminator_train_start_steps=0, distributed=False)
+    trainer = Trainer(cfg, torch.device("cuda"))
+    data = SyntheticPairs(64, 100, 13, HOP, seed=0)
+    batch = WindowCollater(2000, HOP, 512, np.random.default_rng(0))([data[i] for i in range(64)])
+
+    def timed(fn, k):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+
+    trainer.steps = 0  # discriminator_train_start_steps = 0: step 0 trains nothing adversarial -> generator + mel only
+    x, y, ar = batch["x"].cuda(), batch["y"].cuda(), batch["ar"].cuda()
+
+    def gen_only():
+        trainer.optimizer["generator"].zero_grad(set_to_none=True)
+        (trainer.G(x, ar=ar) - y).abs().mean().backward()
+        trainer.optimizer["generator"].step()
+
+    t_gen = timed(gen_only, 10)
+
+    def gan():
+        trainer.steps = 1
+        trainer.train_step(batch)
+
+    t_gan = timed(gan, 5)
+    macs = trainer.G.macs(64, 25)
+    return {"note": "informational: BASELINE config 5's recipe on ONE GPU, exact fp32 (the reference has no bf16 path)",
+            "workload": "e2w_hifigan_car.yaml: batch 64 x (2000 + 512 AR) samples",
+            "generator_train_step_ms": round(t_gen * 1e3, 2), "generator_train_step_algorithmic_tflops": round(6 * macs / t_gen / 1e12, 1),
+            "gan_iteration_ms": round(t_gan * 1e3, 2), "gan_windows_per_s": round(64 / t_gan, 1),
+            "gan_training_samples_per_s": round(64 * 2000 / t_gan, 1)}
+
+
 def main(argv=None, synth_factory=None):
     """``synth_factory`` is a test hook (tests/test_distributed_gloo.py runs this very function under a 2-process gloo
     torchrun on CPU with a stand-in synthesis function); the product path never passes it."""
@@ -198,6 +259,7 @@ def main(argv=None, synth_factory=None):
     ap.add_argument("--no-fast-leg", action="store_true", help="skip the secondary bf16x3 leg (N=1 only)")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the batch 1 / 8 legs (N=1 only)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-training", action="store_true", help="skip the training leg (N=1 only): generator train step and GAN iteration")
     args = ap.parse_args(argv)
 
     import numpy as np  # noqa: F401
@@ -374,6 +436,9 @@ def main(argv=None, synth_factory=None):
                 leg["roofline"] = roofline_block(stats, "bf16x3", te, args.steps, traffic_table)
             g.set_precision(args.precision)
         out["fast_bf16x3"] = leg
+
+    if solo and args.precision == "f32" and not args.no_training:
+        out["training"] = training_leg(params)
 
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, sd, args.chunk_frames, seed=20260929)

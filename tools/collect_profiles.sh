@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-common="--no-cpu-baseline --no-fast-leg --no-batch-sweep"
+common="--no-cpu-baseline --no-fast-leg --no-batch-sweep --no-training"
 rocprofv3 -L > $out/prof_${tag}_counters_available.txt 2>&1
 for prec in f32 bf16x3; do
   rocprofv3 --kernel-trace --stats -f csv -d $out/prof_${tag}_${prec}_stats -- python $root/bench.py --precision $prec --steps 3 --warmup 1 $common > $out/prof_${tag}_${prec}_bench_under_rocprof.json 2> $out/prof_${tag}_${prec}_stats.log
