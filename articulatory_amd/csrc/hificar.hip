@@ -77,6 +77,9 @@ struct hificar_handle {
     bool profile_detail = false;   // HIFICAR_PROFILE_DETAIL=1: profile rows carry the layer name
     bool use_pair = true;          // HIFICAR_PAIR=0: run narrow stages layer by layer (A/B runs)
     bool use_lpt = true;           // HIFICAR_LPT=0: round-robin tile walk instead of the host LPT schedule (A/B runs)
+    double mi1_penalty = 1.05;     // cost factor of 32-row tiles in the exact-fp32 tile choice (they re-stream the weights most often: L2-bound when
+                                   // K is long).  The discriminator engine raises it: its launches overlap on several streams, so a nearly
+                                   // empty last round of taller tiles costs little there, while the L2 traffic of short tiles is shared by all
     int ksplit = 1;                // HIFICAR_KSPLIT: 0 = never use the split-K conv form, 1 = when it is estimated faster (default), 2 = always
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
     int cin_pad = 0;  // padded input-conv channels
@@ -990,8 +993,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         double worst = std::max(heaviest, total_cost / G);
         if (total % G != 0) worst = std::max(worst, total_cost / G + 0.5 * lightest);
         // shorter wave tiles re-read the weight stream more often per MFMA (MI = 2 measured ~10 % slower per flop)
-        static const double mi1_f32 = getenv("HIFICAR_MI1") ? atof(getenv("HIFICAR_MI1")) : 1.05;
-        if (t.MI < 4) worst *= f32 ? (t.MI == 2 ? 1.02 : mi1_f32) : (t.MI == 2 ? 1.10 : 1.25);
+        if (t.MI < 4) worst *= f32 ? (t.MI == 2 ? 1.02 : h->mi1_penalty) : (t.MI == 2 ? 1.10 : 1.25);
         if (t.KS == 4) worst *= 1.05;  // near-ties go to the dense form
         if (worst < best * 0.98) {  // near-ties keep the earlier (taller) shape
             best = worst;

@@ -42,6 +42,11 @@ class DiscOutput:
 
 
 def _send(module, names, tensors, stream):
+    """Hand the raw parameters over (weight norm folded, every pack refreshed: ~0.9 ms for the 70 M-parameter discriminator) — skipped
+    when nothing changed since the last hand-over: the generator part and the discriminator part of one iteration see the same weights."""
+    sig = (names, tuple(t.data_ptr() for t in tensors), tuple(t._version for t in tensors))
+    if module.__dict__.get("_sent_sig") == sig and all(t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
+        return module.__dict__["_sent_held"]
     held = [t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous() for t in tensors]
     cn = getattr(module, "_raw_cnames", None)
     if cn is None or cn[0] != names:
@@ -49,6 +54,7 @@ def _send(module, names, tensors, stream):
     ptrs = (ctypes.c_void_p * len(held))(*[t.data_ptr() for t in held])
     _native.check(module._lib.hificar_disc_set_parameters_device(module._handle, cn[1], ptrs, len(held), stream),
                   "hificar_disc_set_parameters_device")
+    module.__dict__["_sent_sig"], module.__dict__["_sent_held"] = sig, held
     return held
 
 
@@ -389,6 +395,13 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
                 self._info_cache.clear()
             self._info_cache[key] = infos
         return self._info_cache[key]
+
+    def invalidate_parameters(self):
+        """Force the next call to hand the parameters over again.  In-place updates through autograd-visible ops (optimizer.step(),
+        load_state_dict, p.copy_ under no_grad) are noticed by themselves through the tensors' version counters; writes through
+        ``p.data`` are not."""
+        self.__dict__.pop("_sent_sig", None)
+        self.__dict__["_real_cache"] = None
 
     def _raw_parameters(self):
         names, tensors = [], []
