@@ -7,7 +7,7 @@
 //                                                                 (ConvParams::mask_src); a ConvTranspose1d's data gradient is a plain
 //                                                                 3-tap Conv1d over its phase-major "virtual channel" rows
 //   weight gradient  dW[co, ci, k] = sum_{b,t} dy[b, t, co] * a[b, t + off_k, ci]   -> wgrad_kernel (MFMA, reduction over rows)
-//   bias gradient    db[co] = sum_{b,t} dy[b, t, co]                                -> colsum_kernel
+//   bias gradient    db[co] = sum_{b,t} dy[b, t, co]                                -> column sums of the weight-gradient kernels' staged tiles
 // plus the small ends of the network (output conv + tanh, MRF mean, feature transpose, PastFCEncoder) as VALU kernels.
 // All reductions are two-stage (partials per row split, then a fixed-order sum): deterministic, no atomics.
 #pragma once
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hf = lane >> 5;
     const int gpt = p.g_per_tile;
-    const int gt_n = (p.n_gblk + gpt - 1) / gpt, at_n = (p.n_ablk + 1) >> 1;
+    const int at_n = (p.n_ablk + 1) >> 1;
     const int at = blockIdx.x % at_n, gt = blockIdx.x / at_n;
     const int split = blockIdx.y;
     const int rs = p.row_split, nblk = 4 / rs;
@@ -509,27 +509,6 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
             dst_p[d] = o[j];
         }
     }
-}
-
-// Column sums of gradient rows (bias gradients): partial[split][ch] = sum of the split's rows of g[row, ch]
-struct ColsumParams {
-    const float* g;
-    float* partial;  // [nsplit][pitch]
-    long long rows;
-    int pitch;
-    int nsplit;
-};
-
-__global__ __launch_bounds__(256) void colsum_kernel(const ColsumParams p) {
-    __shared__ float red[4][64];
-    const int ch = blockIdx.x * 64 + (threadIdx.x & 63), rs = threadIdx.x >> 6;
-    const long long r_lo = p.rows * blockIdx.y / p.nsplit, r_hi = p.rows * (blockIdx.y + 1) / p.nsplit;
-    float s = 0.f;
-    if (ch < p.pitch)
-        for (long long r = r_lo + rs; r < r_hi; r += 4) s += p.g[(size_t)r * p.pitch + ch];
-    red[rs][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rs == 0 && ch < p.pitch) p.partial[(size_t)blockIdx.y * p.pitch + ch] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // db[co] = sum over splits (and over the phases of a ConvTranspose1d) of the column sums
