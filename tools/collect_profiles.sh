@@ -20,4 +20,6 @@ done
 # training: generator train step and the full GAN iteration
 rocprofv3 --kernel-trace --stats -f csv -d $out/prof_${tag}_train_stats -- python $root/tools/train_bench.py --steps 5 > $out/prof_${tag}_train_bench.txt 2> $out/prof_${tag}_train_stats.log
 rocprofv3 --kernel-trace --stats -f csv -d $out/prof_${tag}_gan_stats -- python $root/tools/gan_bench.py --steps 5 > $out/prof_${tag}_gan_bench.txt 2> $out/prof_${tag}_gan_stats.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -f csv -d $out/prof_${tag}_train_mfma -- python $root/tools/train_bench.py --steps 1 > /dev/null 2> $out/prof_${tag}_train_mfma.log
+HIFICAR_DISC_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -f csv -d $out/prof_${tag}_gan_mfma -- python $root/tools/gan_bench.py --steps 1 > /dev/null 2> $out/prof_${tag}_gan_mfma.log
 ls $out | grep prof_${tag}

@@ -108,6 +108,20 @@ for what, cmd in (("train", "python tools/train_bench.py --steps 5"), ("gan", "p
         for r in rows:
             if float(r.get("Percentage", 0) or 0) >= 0.05:
                 w.writerow(r.values())
+    if os.path.isdir(base + "_mfma"):
+        mf, dur = counters(base + "_mfma")
+        with open(f"profiles/{tag}_{what}_pmc_mfma.csv", "w") as f:
+            f.write(f"# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace "
+                    f"-- {cmd.replace('--steps 5', '--steps 1')} ({tag}; the GAN pass with HIFICAR_DISC_STREAMS=0 so that launches do not overlap); "
+                    "per-launch averages, columns as in the forward-path files\n")
+            f.write("Kernel,Launches,avg_duration_us,GRBM_GUI_ACTIVE,SQ_VALU_MFMA_BUSY_CYCLES,mfma_util\n")
+            for k in sorted(mf, key=lambda k: -dur[k][1]):
+                if "hificar" not in k:
+                    continue
+                c = {name: v[1] / max(v[0], 1) for name, v in mf[k].items()}
+                gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+                util = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8 * 1024) if gui else 0.0
+                f.write(f"\"{k}\",{dur[k][0]},{dur[k][1] / dur[k][0] / 1e3:.2f},{gui:.0f},{c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.0f},{util:.4f}\n")
     txt = f"{base}_bench.txt"
     if os.path.exists(txt):
         lines = [ln for ln in open(txt).read().splitlines() if "ms" in ln and ("step" in ln or "iteration" in ln)]
