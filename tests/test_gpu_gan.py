@@ -135,3 +135,52 @@ def test_distributed_iteration_over_rccl_world1():
         assert all(torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7) for k in a)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant", ["warmup_generator_only", "no_feature_matching_hinge", "stft_aux_batch1"])
+def test_trainer_option_variants(variant):
+    """The branches of _train_step the shipped recipes also pass through or switch on: the generator-only warm-up before
+    discriminator_train_start_steps (train.py:347,386), no feature matching + hinge losses, the multi-resolution STFT auxiliary loss."""
+    config = make_config(True)
+    if variant == "warmup_generator_only":
+        config["discriminator_train_start_steps"] = 5
+    elif variant == "no_feature_matching_hinge":
+        config["use_feat_match_loss"] = False
+        config["generator_adv_loss_params"] = {"average_by_discriminators": True, "loss_type": "hinge"}
+        config["discriminator_adv_loss_params"] = {"average_by_discriminators": True, "loss_type": "hinge"}
+    else:
+        config.update(use_mel_loss=False, use_stft_loss=True, stft_loss_params={"fft_sizes": [256, 512, 128], "hop_sizes": [30, 60, 12],
+                                                                               "win_lengths": [150, 300, 60], "window": "hann_window"})
+    t, gsd, dsd, batch = build(config)
+    if variant == "stft_aux_batch1":
+        batch = {k: v[:1] for k, v in batch.items()}
+    d_before = {k: v.clone() for k, v in t.D.state_dict().items()}
+    t.steps = 1  # (as in the reference, nothing trains at step 0: `steps > generator_train_start_steps`, train.py:266)
+    logs = [{k: float(v) for k, v in t.train_step(batch).items()} for _ in range(3)]
+    assert all(np.isfinite(v) for log in logs for v in log.values())
+    if variant == "warmup_generator_only":
+        assert all(sorted(log) == ["train/generator_loss", "train/mel_loss"] for log in logs)      # no adversarial part yet
+        assert all(torch.equal(v, d_before[k]) for k, v in t.D.state_dict().items())                # the discriminator is untouched
+        x, y, ar = batch["x"], batch["y"], batch["ar"]
+        with torch.no_grad():
+            mel = DO.mel_loss(O.generator_forward(O.fold_weight_norm(gsd), config["generator_params"], x, ar), y, **config["mel_loss_params"])
+        assert abs(logs[0]["train/generator_loss"] - 45.0 * float(mel)) < 1e-4 * 45.0 * float(mel)
+    elif variant == "no_feature_matching_hinge":
+        assert "train/feature_matching_loss" not in logs[0] and "train/adversarial_loss" in logs[0] and "train/real_loss" in logs[0]
+        x, y, ar = batch["x"], batch["y"], batch["ar"]
+        with torch.no_grad():
+            y_ = O.generator_forward(O.fold_weight_norm(gsd), config["generator_params"], x, ar)
+            dw = DO.fold_disc_weight_norm(dsd)
+            p_, p = DO.disc_forward(dw, SMALL, torch.cat([ar, y_], 2)), DO.disc_forward(dw, SMALL, torch.cat([ar, y], 2))
+            adv = DO.gen_adv_loss(p_, True, "hinge")
+            real = DO.dis_adv_loss(p_, p, True, "hinge")[0]
+        assert abs(logs[0]["train/adversarial_loss"] - float(adv)) < 1e-4 * max(abs(float(adv)), 1e-2)
+        assert abs(logs[0]["train/real_loss"] - float(real)) < 1e-4 * float(real)
+    else:
+        assert "train/spectral_convergence_loss" in logs[0] and "train/log_stft_magnitude_loss" in logs[0] and "train/mel_loss" not in logs[0]
+        x, y, ar = batch["x"], batch["y"], batch["ar"]
+        with torch.no_grad():
+            y_ = O.generator_forward(O.fold_weight_norm(gsd), config["generator_params"], x, ar)
+            sc, mag = DO.multi_resolution_stft_loss(y_, y, [256, 512, 128], [30, 60, 12], [150, 300, 60])
+        assert abs(logs[0]["train/spectral_convergence_loss"] - float(sc)) < 1e-4 * float(sc)
+        assert abs(logs[0]["train/log_stft_magnitude_loss"] - float(mag)) < 1e-4 * float(mag)
