@@ -142,22 +142,36 @@ def list_features(feats_scp=None, dumpdir=None, fmt="npy"):
                     raise ValueError("Not supported feats.scp type (only 'utt_id /path/to/utt_id.npy' entries are read here).")
                 pairs.append((parts[0], parts[1]))
     else:
-        if fmt != "npy":
-            raise ValueError("Support only npy format here (h5py is not available in this image).")
-        for path in sorted(glob.glob(os.path.join(dumpdir, "**", "*-feats.npy"), recursive=True)):
-            pairs.append((os.path.basename(path)[: -len("-feats.npy")], path))
+        if fmt == "hdf5":  # decode.py:210-212: <utt_id>.h5 files holding a "feats" dataset
+            for path in sorted(glob.glob(os.path.join(dumpdir, "**", "*.h5"), recursive=True)):
+                pairs.append((os.path.splitext(os.path.basename(path))[0], path))
+        elif fmt == "npy":
+            for path in sorted(glob.glob(os.path.join(dumpdir, "**", "*-feats.npy"), recursive=True)):
+                pairs.append((os.path.basename(path)[: -len("-feats.npy")], path))
+        else:
+            raise ValueError("Support only hdf5 or npy format.")
     return pairs
 
 
+def _load(path):
+    if path.endswith(".h5"):
+        from articulatory_amd.utils.hdf5 import read_hdf5
+
+        return read_hdf5(path, "feats")
+    return np.load(path)
+
+
 def npy_frames(path):
-    """Frame count of a (T, C) .npy feature file from its header alone (no data is read)."""
+    """Frame count of a (T, C) feature file (.npy: from its header alone, no data is read)."""
+    if path.endswith(".h5"):
+        return int(_load(path).shape[0])
     return int(np.load(path, mmap_mode="r").shape[0])
 
 
 def load_features(pairs):
     """(utt_id, path) pairs -> (utt_id, (T, C) ndarray), one utterance at a time, as the reference's loop streams them."""
     for utt_id, path in pairs:
-        yield utt_id, np.load(path)
+        yield utt_id, _load(path)
 
 
 def iter_features(feats_scp=None, dumpdir=None, fmt="npy"):

@@ -10,8 +10,9 @@ discriminator update.  Every network, loss and gradient runs in libhificar; PyTo
 schedule.  Data parallelism: one process per GPU, ``sync_gradients`` on both networks (the reference's DDP wrap is disabled,
 train.py:1790-1801): one all-reduce per network per step over RCCL.
 
-Data: ``--audio-scp`` / ``--feats-scp`` (``utt path`` lines; audio and features as ``.npy`` — libsndfile / HDF5 readers are not in this
-image) or ``--synthetic N`` (N random utterances, for benchmarks and smoke runs).  Windows are cut as the reference's collater does
+Data: ``--train-dumpdir`` (the reference's dump directory: ``<utt>.h5`` files with "wave" / "feats" datasets, read by
+articulatory_amd/utils/hdf5.py, or ``-wave.npy`` / ``-feats.npy`` pairs), ``--audio-scp`` / ``--feats-scp`` (``utt path`` lines of ``.npy``
+arrays; libsndfile is not in this image) or ``--synthetic N`` (N random utterances, for benchmarks and smoke runs).  Windows are cut as the reference's collater does
 in ``random_window`` mode (train.py:1013-1097): ``batch_max_steps`` samples, the matching frames, and the ``ar_input`` samples before
 the window (zero padded on the left) as the AR context.
 
@@ -81,6 +82,37 @@ class NpyPairs(torch.utils.data.Dataset):
     def __getitem__(self, i):
         audio = np.load(self.items[i][0]).astype(np.float32).reshape(-1)
         feats = np.load(self.items[i][1]).astype(np.float32)
+        n = min(len(audio) // self.hop_size, len(feats))
+        return audio[: n * self.hop_size], feats[:n]
+
+
+class DumpDirPairs(torch.utils.data.Dataset):
+    """The reference's dump directory (AudioMelDataset, articulatory/datasets/audio_mel_dataset.py as set up at train.py:1530-1570):
+    ``format: hdf5`` -> ``<utt>.h5`` files with "wave" and "feats" datasets; ``format: npy`` -> ``<utt>-wave.npy`` + ``<utt>-feats.npy``."""
+
+    def __init__(self, dumpdir, fmt, hop_size, min_frames):
+        import glob
+
+        from articulatory_amd.utils.hdf5 import read_hdf5
+
+        self.hop_size = hop_size
+        if fmt == "hdf5":
+            files = sorted(glob.glob(os.path.join(dumpdir, "**", "*.h5"), recursive=True))
+            self.load = lambda f: (read_hdf5(f, "wave"), read_hdf5(f, "feats"))
+        elif fmt == "npy":
+            files = sorted(glob.glob(os.path.join(dumpdir, "**", "*-wave.npy"), recursive=True))
+            self.load = lambda f: (np.load(f), np.load(f.replace("-wave.npy", "-feats.npy")))
+        else:
+            raise ValueError("support only hdf5 or npy format.")
+        self.files = [f for f in files if (read_hdf5(f, "feats") if fmt == "hdf5" else np.load(f.replace("-wave.npy", "-feats.npy"), mmap_mode="r")).shape[0]
+                      >= min_frames]
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i):
+        audio, feats = self.load(self.files[i])
+        audio, feats = np.asarray(audio, np.float32).reshape(-1), np.asarray(feats, np.float32)
         n = min(len(audio) // self.hop_size, len(feats))
         return audio[: n * self.hop_size], feats[:n]
 
@@ -242,6 +274,7 @@ def main(argv=None):
     ap.add_argument("--outdir", required=True)
     ap.add_argument("--audio-scp")
     ap.add_argument("--feats-scp")
+    ap.add_argument("--train-dumpdir", help="dump directory of <utt>.h5 (wave + feats) or <utt>-wave.npy / <utt>-feats.npy files (config: format)")
     ap.add_argument("--synthetic", type=int, default=0, help="train on this many random utterances instead of a dataset")
     ap.add_argument("--resume", default="")
     ap.add_argument("--max-steps", type=int, default=None, help="override train_max_steps")
@@ -265,9 +298,11 @@ def main(argv=None):
     ar_len = gp.get("ar_input") if gp.get("use_ar", False) else None
     if a.synthetic:
         data = SyntheticPairs(a.synthetic, 4 * frames, feature_dims(config), hop, seed=rank)
+    elif a.train_dumpdir:
+        data = DumpDirPairs(a.train_dumpdir, config.get("format", "hdf5"), hop, frames)
     else:
         if not (a.audio_scp and a.feats_scp):
-            raise SystemExit("give --audio-scp and --feats-scp, or --synthetic N")
+            raise SystemExit("give --train-dumpdir, or --audio-scp and --feats-scp, or --synthetic N")
         data = NpyPairs(a.audio_scp, a.feats_scp, hop, frames)
     sampler = torch.utils.data.distributed.DistributedSampler(data, world, rank, shuffle=True) if world > 1 else None
     loader = torch.utils.data.DataLoader(data, batch_size=config["batch_size"], shuffle=sampler is None, sampler=sampler, drop_last=True,

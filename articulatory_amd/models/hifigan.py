@@ -356,13 +356,10 @@ class HiFiGANGenerator(torch.nn.Module):
         """Register mean/scale buffers for input normalisation (hifigan.py:280-296)."""
         assert stats.endswith(".h5") or stats.endswith(".npy")
         if stats.endswith(".h5"):
-            try:
-                import h5py
-            except ImportError as e:  # h5py is not in this image
-                raise RuntimeError("register_stats: .h5 statistics need h5py; use the .npy form") from e
-            with h5py.File(stats, "r") as f:
-                mean = f["mean"][()].reshape(-1)
-                scale = f["scale"][()].reshape(-1)
+            from ..utils.hdf5 import read_hdf5  # h5py when importable, else the built-in reader of plain HDF5 files
+
+            mean = read_hdf5(stats, "mean").reshape(-1)
+            scale = read_hdf5(stats, "scale").reshape(-1)
         else:
             arr = np.load(stats)
             mean = arr[0].reshape(-1)

@@ -67,3 +67,22 @@ def test_main_fails_loudly_without_a_gpu(tmp_path):
     cfg.write_text("batch_size: 2\n")
     with pytest.raises(SystemExit, match="MI355X"):
         T.main(["--config", str(cfg), "--outdir", str(tmp_path), "--synthetic", "4"])
+
+
+def test_dump_dir_pairs_hdf5_and_npy(tmp_path):
+    from articulatory_amd.utils.hdf5 import write_hdf5
+
+    hop = 10
+    for utt, frames in (("a", 12), ("b", 3), ("c", 20)):
+        feats = np.full((frames, 4), frames, np.float32)
+        wave = np.arange(frames * hop + 3, dtype=np.float32)
+        write_hdf5(str(tmp_path / "h5" / f"{utt}.h5"), "wave", wave)
+        write_hdf5(str(tmp_path / "h5" / f"{utt}.h5"), "feats", feats)
+        os.makedirs(tmp_path / "npy", exist_ok=True)
+        np.save(tmp_path / "npy" / f"{utt}-wave.npy", wave)
+        np.save(tmp_path / "npy" / f"{utt}-feats.npy", feats)
+    for fmt in ("hdf5", "npy"):
+        ds = T.DumpDirPairs(str(tmp_path / ("h5" if fmt == "hdf5" else "npy")), fmt, hop, min_frames=5)
+        assert len(ds) == 2
+        audio, feats = ds[1]
+        assert feats.shape == (20, 4) and len(audio) == 200 and audio[7] == 7
