@@ -184,3 +184,18 @@ def test_trainer_option_variants(variant):
             sc, mag = DO.multi_resolution_stft_loss(y_, y, [256, 512, 128], [30, 60, 12], [150, 300, 60])
         assert abs(logs[0]["train/spectral_convergence_loss"] - float(sc)) < 1e-4 * float(sc)
         assert abs(logs[0]["train/log_stft_magnitude_loss"] - float(mag)) < 1e-4 * float(mag)
+
+
+def test_iterations_are_bit_reproducible():
+    """No atomics anywhere in the training kernels (split sums are reduced in a fixed order, the sub-discriminators' streams only
+    overlap independent work): two runs from the same state give bit-identical losses and parameters."""
+    config = make_config(True)
+    runs = []
+    for _ in range(2):
+        t, _, _, batch = build(config)
+        t.steps = 1
+        logs = [{k: float(v) for k, v in t.train_step(batch).items()} for _ in range(4)]
+        runs.append((logs, {k: v.clone() for k, v in t.G.state_dict().items()}, {k: v.clone() for k, v in t.D.state_dict().items()}))
+    assert runs[0][0] == runs[1][0]
+    assert all(torch.equal(runs[0][1][k], runs[1][1][k]) for k in runs[0][1])
+    assert all(torch.equal(runs[0][2][k], runs[1][2][k]) for k in runs[0][2])
