@@ -236,6 +236,66 @@ class Trainer:
         self.steps += 1
         return log
 
+    # ------------------------------------------------------------------ evaluation (train.py:470-640)
+    @torch.no_grad()
+    def eval_step(self, batch):
+        """The losses of one dev batch without updates (``_eval_step``): both networks in eval mode; the adversarial terms are always
+        computed here (no start-step condition in the reference's evaluation either)."""
+        cfg = self.config
+        x = batch["x"].to(self.device, non_blocking=True)
+        y = batch["y"].to(self.device, non_blocking=True)
+        ar = batch["ar"].to(self.device, non_blocking=True) if self.use_ar else None
+        ga, da, fm = cfg.get("generator_adv_loss_params", {}), cfg.get("discriminator_adv_loss_params", {}), cfg.get("feat_match_loss_params", {})
+        log = {}
+        y_ = self.G(x, ar=ar)
+        aux_loss = 0.0
+        if self.stft is not None:
+            sc_loss, mag_loss = self.stft(y_, y)
+            aux_loss = aux_loss + sc_loss + mag_loss
+            log["eval/spectral_convergence_loss"], log["eval/log_stft_magnitude_loss"] = sc_loss, mag_loss
+        if self.mel is not None:
+            mel_loss = self.mel(y_, y)
+            aux_loss = aux_loss + mel_loss
+            log["eval/mel_loss"] = mel_loss
+        aux_loss = aux_loss * cfg.get("lambda_aux", 1.0)
+        disc_y = torch.cat([ar, y], dim=2) if self.use_ar else y
+        disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
+        use_fm = cfg.get("use_feat_match_loss", False)
+        total, adv, fml = self.D.generator_loss(
+            disc_y_, disc_y if use_fm else None, loss_type=ga.get("loss_type", "mse"), average_by_discriminators=ga.get("average_by_discriminators", True),
+            lambda_adv=cfg["lambda_adv"], lambda_feat_match=cfg.get("lambda_feat_match", 0.0) if use_fm else 0.0,
+            fm_average_by_layers=fm.get("average_by_layers", True), fm_average_by_discriminators=fm.get("average_by_discriminators", True),
+            fm_include_final_outputs=fm.get("include_final_outputs", False))
+        dis_loss, real_loss, fake_loss = self.D.discriminator_loss(disc_y_, disc_y, loss_type=da.get("loss_type", "mse"),
+                                                                   average_by_discriminators=da.get("average_by_discriminators", True))
+        log.update({"eval/adversarial_loss": adv, "eval/generator_loss": aux_loss + total, "eval/real_loss": real_loss, "eval/fake_loss": fake_loss,
+                    "eval/discriminator_loss": dis_loss})
+        if use_fm:
+            log["eval/feature_matching_loss"] = fml
+        return log
+
+    def eval_epoch(self, loader, outdir=None):
+        """``_eval_epoch``: average dev losses; the best mel loss so far keeps ``best_mel_ckpt.pkl`` / ``best_mel_step.txt`` (train.py:621-626)."""
+        self.G.eval()
+        self.D.eval()
+        totals, n = defaultdict(float), 0
+        for batch in loader:
+            for k, v in self.eval_step(batch).items():
+                totals[k] += float(v)
+            n += 1
+        self.G.train()
+        self.D.train()
+        if n == 0:
+            return {}
+        avg = {k: v / n for k, v in totals.items()}
+        if outdir is not None and "eval/mel_loss" in avg and avg["eval/mel_loss"] < getattr(self, "best_mel_loss", float("inf")):
+            self.best_mel_loss = avg["eval/mel_loss"]
+            os.makedirs(outdir, exist_ok=True)
+            with open(os.path.join(outdir, "best_mel_step.txt"), "w+") as f:
+                f.write("%d\n" % self.steps)
+            self.save_checkpoint(os.path.join(outdir, "best_mel_ckpt.pkl"))
+        return avg
+
     # ------------------------------------------------------------------ checkpoints (train.py:140-238)
     def save_checkpoint(self, path):
         state = {
@@ -275,6 +335,7 @@ def main(argv=None):
     ap.add_argument("--audio-scp")
     ap.add_argument("--feats-scp")
     ap.add_argument("--train-dumpdir", help="dump directory of <utt>.h5 (wave + feats) or <utt>-wave.npy / <utt>-feats.npy files (config: format)")
+    ap.add_argument("--dev-dumpdir", help="dev-set dump directory: evaluated every eval_interval_steps (rank 0)")
     ap.add_argument("--synthetic", type=int, default=0, help="train on this many random utterances instead of a dataset")
     ap.add_argument("--resume", default="")
     ap.add_argument("--max-steps", type=int, default=None, help="override train_max_steps")
@@ -310,6 +371,11 @@ def main(argv=None):
                                          num_workers=config.get("num_workers", 0), pin_memory=config.get("pin_memory", False))
     if len(loader) == 0:
         raise SystemExit(f"fewer utterances ({len(data)}) than one batch ({config['batch_size']})")
+    dev_loader = None
+    if a.dev_dumpdir and rank == 0:
+        dev = DumpDirPairs(a.dev_dumpdir, config.get("format", "hdf5"), hop, frames)
+        dev_loader = torch.utils.data.DataLoader(dev, batch_size=config["batch_size"], shuffle=False, drop_last=False,
+                                                 collate_fn=WindowCollater(config["batch_max_steps"], hop, ar_len, np.random.default_rng(4321)))
     trainer = Trainer(config, device, distributed=world > 1)
     if a.resume:
         trainer.load_checkpoint(a.resume)
@@ -328,6 +394,9 @@ def main(argv=None):
                 logging.info(f"(Steps: {trainer.steps}) " + ", ".join(f"{k} = {v / n:.4f}" for k, v in sorted(trainer.total_train_loss.items()))
                              + f", {(time.time() - t0) / max(trainer.steps - n0, 1) * 1e3:.1f} ms/step")
                 trainer.total_train_loss = defaultdict(float)
+            if dev_loader is not None and trainer.steps % config.get("eval_interval_steps", 10 ** 9) == 0:
+                avg = trainer.eval_epoch(dev_loader, a.outdir)
+                logging.info(f"(Steps: {trainer.steps}) " + ", ".join(f"{k} = {v:.4f}" for k, v in sorted(avg.items())))
             if trainer.steps % config.get("save_interval_steps", 10 ** 9) == 0 and rank == 0:
                 trainer.save_checkpoint(os.path.join(a.outdir, f"checkpoint-{trainer.steps}steps.pkl"))
             if trainer.steps >= max_steps:

@@ -199,3 +199,30 @@ def test_iterations_are_bit_reproducible():
     assert runs[0][0] == runs[1][0]
     assert all(torch.equal(runs[0][1][k], runs[1][1][k]) for k in runs[0][1])
     assert all(torch.equal(runs[0][2][k], runs[1][2][k]) for k in runs[0][2])
+
+
+def test_eval_step_and_best_mel_checkpoint(tmp_path):
+    """eval_step = the reference's _eval_step (train.py:470-600): no updates, every loss against the oracle; eval_epoch keeps the best-mel
+    checkpoint (train.py:621-626)."""
+    config = make_config(True)
+    t, gsd, dsd, batch = build(config)
+    g_before = {k: v.clone() for k, v in t.G.state_dict().items()}
+    avg = t.eval_epoch([batch, batch], str(tmp_path))
+    assert all(torch.equal(v, g_before[k]) for k, v in t.G.state_dict().items()) and t.G.training and t.D.training
+    x, y, ar = batch["x"], batch["y"], batch["ar"]
+    with torch.no_grad():
+        y_ = O.generator_forward(O.fold_weight_norm(gsd), config["generator_params"], x, ar)
+        mel = DO.mel_loss(y_, y, **config["mel_loss_params"])
+        dw = DO.fold_disc_weight_norm(dsd)
+        p_, p = DO.disc_forward(dw, SMALL, torch.cat([ar, y_], 2)), DO.disc_forward(dw, SMALL, torch.cat([ar, y], 2))
+        adv, fm = DO.gen_adv_loss(p_, False), DO.feat_match_loss(p_, p, False, False, False)
+        real, fake = DO.dis_adv_loss(p_, p, False)
+    ref = {"eval/mel_loss": mel, "eval/adversarial_loss": adv, "eval/feature_matching_loss": fm, "eval/generator_loss": 45.0 * mel + adv + 2.0 * fm,
+           "eval/real_loss": real, "eval/fake_loss": fake, "eval/discriminator_loss": real + fake}
+    assert sorted(avg) == sorted(ref)
+    for k, v in ref.items():
+        assert abs(avg[k] - float(v)) < 1e-4 * max(abs(float(v)), 1e-3), (k, avg[k], float(v))
+    assert open(tmp_path / "best_mel_step.txt").read().strip() == "0" and os.path.exists(tmp_path / "best_mel_ckpt.pkl")
+    os.remove(tmp_path / "best_mel_ckpt.pkl")
+    t.eval_epoch([batch], str(tmp_path))       # not better than the best so far: no new checkpoint
+    assert not os.path.exists(tmp_path / "best_mel_ckpt.pkl")
