@@ -226,3 +226,26 @@ def test_eval_step_and_best_mel_checkpoint(tmp_path):
     os.remove(tmp_path / "best_mel_ckpt.pkl")
     t.eval_epoch([batch], str(tmp_path))       # not better than the best so far: no new checkpoint
     assert not os.path.exists(tmp_path / "best_mel_ckpt.pkl")
+
+
+def test_train_cli_end_to_end_and_resume(tmp_path):
+    """python -m articulatory_amd.bin.train on a YAML config: synthetic utterances, three iterations, checkpoint; resumed for two more."""
+    import yaml
+
+    from articulatory_amd.bin import train as T
+
+    config = make_config(True)
+    config.update(train_max_steps=3, save_interval_steps=100, log_interval_steps=1, num_workers=0, pin_memory=False)
+    cfg = tmp_path / "conf.yaml"
+    cfg.write_text(yaml.safe_dump(config))
+    out = tmp_path / "exp"
+    T.main(["--config", str(cfg), "--outdir", str(out), "--synthetic", "8", "--verbose", "0"])
+    ck = out / "checkpoint-3steps.pkl"
+    assert ck.exists()
+    state = torch.load(ck, map_location="cpu")
+    assert state["steps"] == 3 and state["optimizer"]["discriminator"]["state"]   # steps 1 and 2 were adversarial: D has Adam moments
+    T.main(["--config", str(cfg), "--outdir", str(out), "--synthetic", "8", "--verbose", "0", "--resume", str(ck), "--max-steps", "5"])
+    state2 = torch.load(out / "checkpoint-5steps.pkl", map_location="cpu")
+    assert state2["steps"] == 5
+    k = next(iter(state["model"]["generator"]))
+    assert not torch.equal(state["model"]["generator"][k], state2["model"]["generator"][k])
