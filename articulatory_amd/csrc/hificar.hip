@@ -935,6 +935,8 @@ struct ConvIO {
     char* ys;
     const float* mask_src = nullptr;  // backward launches: LeakyReLU'(mask_src) scales the result before res is added
     float mask_slope = 0.f;
+    long long x_seq_bytes = 0;        // input row addressing (ConvParams::x_seq_bytes / x_row_bytes); 0: packed rows
+    int x_row_bytes = 0;
 };
 
 // Replicas of every branch at regular strides (the groups of a grouped conv): see MultiConvParams::zrep
@@ -1014,6 +1016,8 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         mp.p[b].ys = io[b].ys;
         mp.p[b].mask_src = io[b].mask_src;
         mp.p[b].mask_slope = io[b].mask_slope;
+        mp.p[b].x_seq_bytes = io[b].x_seq_bytes;
+        mp.p[b].x_row_bytes = io[b].x_row_bytes;
         mp.p[b].zeros = h->d_zeros;
         mp.p[b].slope_out = slope_out;
         mp.p[b].cout_real = Lb.cout_pad;

@@ -160,6 +160,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // partial layout, row shares and bias sums as above.  NT = accumulators instantiated (>= ntaps).
 struct WgradTapsParams {
     long long zs_g = 0, zs_a = 0, zs_partial = 0, zs_bias = 0;  // per-group strides (floats)
+    // A-operand addressing: row t of sequence s at a + s * a_seq_pitch + t * apitch, acols valid columns.  0 = packed rows
+    // (a_seq_pitch = L * apitch, acols = apitch); a pitch shorter than the row = the sliding-window view of ConvParams::x_row_bytes
+    long long a_seq_pitch = 0;
+    int acols = 0;
     WgradParams w;
     const char* zeros;  // >= 16 zero bytes (rows outside the sequence)
     int off_min;        // smallest tap offset of the layer (over all phases), halo = largest - smallest
@@ -207,6 +211,8 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
     const int g_bytes = kWgtR * 256, a_bytes = ((a_rows * 256 + 1023) >> 10) << 10, buf_bytes = g_bytes + a_bytes;
     const int cps = (p.L + kWgtR - 1) / kWgtR;
     const int nchunks = p.nseq * cps;
+    const int a_cols = q.acols ? q.acols : p.apitch;
+    const size_t a_seq_pitch = q.a_seq_pitch ? (size_t)q.a_seq_pitch : (size_t)p.L * p.apitch;
     const int c_lo = (int)((long long)nchunks * split / p.nsplit), c_hi = (int)((long long)nchunks * (split + 1) / p.nsplit);
     f32x16 acc[NT];
 #pragma unroll
@@ -235,7 +241,8 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
             const int ach = at * 64 + c4;
             // an A row is only ever multiplied with G rows of the same chunk: rows whose G partner lies beyond the sequence need no masking
             // (those G rows are zero), but A rows outside [0, L) are the conv's zero padding
-            if (r < a_rows && ta >= 0 && ta < p.L && ach < p.apitch) src = reinterpret_cast<const char*>(a_base + ((size_t)seq * p.L + ta) * p.apitch + ach);
+            if (r < a_rows && ta >= 0 && ta < p.L && ach < a_cols)
+                src = reinterpret_cast<const char*>(a_base + (size_t)seq * a_seq_pitch + (size_t)ta * p.apitch + ach);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + g_bytes + i * 1024), 16, 0, 0);
         }
@@ -348,6 +355,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradTapsPair pai
     constexpr int buf_floats = 2 * kWggR * 128;  // G rows then A rows
     const int cps = (p.L + kWggR - 1) / kWggR;
     const int nchunks = p.nseq * cps;
+    const int a_cols = q.acols ? q.acols : p.apitch;
+    const size_t a_seq_pitch = q.a_seq_pitch ? (size_t)q.a_seq_pitch : (size_t)p.L * p.apitch;
     const int c_lo = (int)((long long)nchunks * split / p.nsplit), c_hi = (int)((long long)nchunks * (split + 1) / p.nsplit);
     f32x16 acc[2][2];
 #pragma unroll
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradTapsPair pai
             const int gch = gt * 128 + c4, ach = at * 128 + c4;
             if (t < p.L) {
                 if (gch < p.gpitch) gsrc = reinterpret_cast<const char*>(g_base + ((size_t)seq * p.L + t) * p.gpitch + gch);
-                if (ach < p.apitch) asrc = reinterpret_cast<const char*>(a_base + ((size_t)seq * p.L + t) * p.apitch + ach);
+                if (ach < a_cols) asrc = reinterpret_cast<const char*>(a_base + (size_t)seq * a_seq_pitch + (size_t)t * p.apitch + ach);
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);

@@ -72,6 +72,12 @@ struct ConvParams {
     const int* seq_len;
     int len_const;
     int len_f0, len_max, len_mul;
+    // input row addressing (conv_ws_body's staging only): row t of sequence s starts at xs + s * x_seq_bytes + t * x_row_bytes.  The
+    // defaults (0) mean packed rows: x_row_bytes = cin * 4, x_seq_bytes = L * cin * 4.  A row pitch SHORTER than the row (overlapping
+    // rows) makes the staged rows sliding windows of one flat buffer: a strided conv in GEMM form reads its im2col rows
+    // A[t] = x_flat[t * stride * cin_g .. + k * cin_g) straight from the activations (hificar_disc.hip.inc), no im2col copy.
+    long long x_seq_bytes;
+    int x_row_bytes;
 };
 
 __device__ __forceinline__ bool is_ragged(const ConvParams& p) { return p.seq_len != nullptr || p.len_const >= 0; }
@@ -387,10 +393,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             const ConvParams& p = mp.p[T.b];
             const int R = TM + p.halo;
             const int ninstr = (R * SPR + 63) >> 6;  // 1 KiB of LDS per wave-instruction
-            const size_t seq_base = (size_t)T.seq * p.L;
             const int Ls = seq_rows(p, T.seq);
-            const int row_bytes = p.cin * 4;
-            const char* const xs_z = p.xs + (size_t)T.z * mp.zs_x;
+            const int row_bytes = p.x_row_bytes ? p.x_row_bytes : p.cin * 4;
+            const char* const xs_z = p.xs + (size_t)T.z * mp.zs_x + (size_t)T.seq * (p.x_seq_bytes ? (size_t)p.x_seq_bytes : (size_t)p.L * p.cin * 4);
             char* dst = smem_b + (jj & 1) * buf_bytes;
             const int c0b = c * CH * 2;  // byte offset of this chunk inside the hi (and lo) half of a row
             for (int i = lw; i < ninstr; i += 4) {
@@ -400,8 +405,8 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                 const int t = T.t0 + p.off_min + r;
                 const char* src = p.zeros;
                 if (r < R && t >= 0 && t < Ls) {
-                    if constexpr (F32) src = xs_z + (seq_base + t) * row_bytes + 2 * c0b + sl * 16;
-                    else src = xs_z + (seq_base + t) * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
+                    if constexpr (F32) src = xs_z + (size_t)t * row_bytes + 2 * c0b + sl * 16;
+                    else src = xs_z + (size_t)t * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
                 }
                 // aux = 2: non-temporal — an activation row is staged by one or two CUs only (+2.3 % end to end)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
