@@ -210,13 +210,9 @@ static int plan_layer(ConvLayer& L) {
             const int k0 = (r + p) % s;
             for (int t = 0; t < L.ntaps; ++t) {
                 const int k = k0 + t * s;
-                if (k < L.K) {
-                    L.tap_k[r][t] = k;
-                    L.tap_off[r][t] = (r + p - k) / s;  // exact: r + p - k is a multiple of s
-                } else {
-                    L.tap_k[r][t] = -1;
-                    L.tap_off[r][t] = 0;
-                }
+                // (a tap past the kernel's end has zero weights; its offset continues the progression the K loop steps through)
+                L.tap_k[r][t] = k < L.K ? k : -1;
+                L.tap_off[r][t] = (r + p - k) / s;  // exact: r + p - k is a multiple of s
             }
         }
     }

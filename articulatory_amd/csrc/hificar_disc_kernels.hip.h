@@ -94,6 +94,9 @@ struct Col2imParams {
     int L_in, L_out;        // rows per sequence of the previous layer's output (= this layer's input) / of this layer's output
     int kt, stride, pad, cin_g, Kg_pad;
     float slope;
+    // sliding-window layers: dA holds the data gradient itself, dX [group][seq][win_rows][win_pitch] (the transposed conv's output), not
+    // the gradient of an im2col matrix: one read instead of the tap sum
+    int win, win_rows, win_pitch;
 };
 
 __global__ __launch_bounds__(256) void col2im_mask_kernel(const Col2imParams p) {
@@ -109,8 +112,9 @@ __global__ __launch_bounds__(256) void col2im_mask_kernel(const Col2imParams p) 
             const int g = ca / p.cin_g, c = ca - g * p.cin_g;
             const float* da = p.dA + (size_t)g * p.da_gstride;
             float s = dyg ? dyg[i] : 0.f;
+            if (p.win) s += da[((size_t)seq * p.win_rows + t) * p.win_pitch + c];
             // taps with (t + pad - tap) divisible by the stride and the output position in range, ascending tap order
-            for (int tap = (t + p.pad) % p.stride; tap < p.kt; tap += p.stride) {
+            for (int tap = p.win ? p.kt : (t + p.pad) % p.stride; tap < p.kt; tap += p.stride) {
                 const int num = t + p.pad - tap;
                 if (num < 0) break;
                 const int to = num / p.stride;
