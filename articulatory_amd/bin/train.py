@@ -130,8 +130,10 @@ class SyntheticPairs(torch.utils.data.Dataset):
         return self.items[i]
 
 
-def _optimizer(kind, params, kw):
+def _optimizer(kind, params, kw, fused=False):
     cls = getattr(torch.optim, kind)  # (the reference's articulatory.optimizers re-exports torch.optim + RAdam; torch has RAdam now)
+    if fused and kind in ("Adam", "AdamW") and "fused" not in kw:
+        kw = dict(kw, fused=True)  # one multi-tensor kernel per step instead of torch's foreach sequence (same update rule)
     return cls(params, **kw)
 
 
@@ -157,9 +159,10 @@ class Trainer:
             self.G.sync_gradients()
             self.D.sync_gradients()
         self.optimizer = {
-            "generator": _optimizer(config.get("generator_optimizer_type", "RAdam"), self.G.parameters(), config["generator_optimizer_params"]),
+            "generator": _optimizer(config.get("generator_optimizer_type", "RAdam"), self.G.parameters(), config["generator_optimizer_params"],
+                                    config.get("fused_optimizers", False)),
             "discriminator": _optimizer(config.get("discriminator_optimizer_type", "RAdam"), self.D.parameters(),
-                                        config["discriminator_optimizer_params"]),
+                                        config["discriminator_optimizer_params"], config.get("fused_optimizers", False)),
         }
         self.scheduler = {
             k: getattr(torch.optim.lr_scheduler, config.get(f"{k}_scheduler_type", "StepLR"))(optimizer=self.optimizer[k],

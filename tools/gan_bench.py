@@ -23,6 +23,7 @@ ap.add_argument("--recipe", default="car", choices=["car", "e2w", "mri"],
                      "mri: mri2w_hifigan_car.yaml (16 x 30000, 230-dim features, x240 upsampling, 20 kHz)")
 ap.add_argument("--aux", default="mel", choices=["mel", "stft"], help="auxiliary loss: the shipped YAMLs' mel loss, or the multi-resolution "
                 "STFT loss BASELINE config 5 names (reference defaults: fft 1024 / 2048 / 512)")
+ap.add_argument("--fused-adam", action="store_true", help="config key fused_optimizers: torch.optim.Adam(fused=True)")
 ap.add_argument("--batch", type=int, default=None)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--torch-profile", action="store_true")
@@ -48,7 +49,7 @@ config = dict(  # e2w_hifigan_car.yaml
     lambda_aux=45.0, lambda_adv=1.0, lambda_feat_match=2.0, batch_size=a.batch, batch_max_steps=r_steps,
     generator_optimizer_type="Adam", generator_optimizer_params=adam, generator_scheduler_type="MultiStepLR", generator_scheduler_params=sched,
     generator_grad_norm=-1, discriminator_optimizer_type="Adam", discriminator_optimizer_params=adam, discriminator_scheduler_type="MultiStepLR",
-    discriminator_scheduler_params=sched, discriminator_grad_norm=-1, discriminator_train_start_steps=0, distributed=False)
+    discriminator_scheduler_params=sched, discriminator_grad_norm=-1, discriminator_train_start_steps=0, distributed=False, fused_optimizers=a.fused_adam)
 trainer = Trainer(config, torch.device("cuda"))
 trainer.steps = 1  # past discriminator_train_start_steps: the full iteration
 data = SyntheticPairs(a.batch, 2 * r_steps // r_hop, r_dims, r_hop, seed=0)
