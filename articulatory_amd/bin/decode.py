@@ -24,6 +24,8 @@ import numpy as np
 import torch
 import yaml
 
+from articulatory_amd.utils.scp import is_supported, load_scp_value
+
 
 def _chunk_frames(config, params_key="generator_params"):
     in_chunk_len = int(config["batch_max_steps"] / config["hop_size"])
@@ -138,8 +140,8 @@ def list_features(feats_scp=None, dumpdir=None, fmt="npy"):
                 parts = line.strip().split()
                 if len(parts) < 2:
                     continue
-                if not parts[1].endswith(".npy"):
-                    raise ValueError("Not supported feats.scp type (only 'utt_id /path/to/utt_id.npy' entries are read here).")
+                if not is_supported(parts[1]):
+                    raise ValueError("Not supported feats.scp type.")
                 pairs.append((parts[0], parts[1]))
     else:
         if fmt == "hdf5":  # decode.py:210-212: <utt_id>.h5 files holding a "feats" dataset
@@ -154,16 +156,12 @@ def list_features(feats_scp=None, dumpdir=None, fmt="npy"):
 
 
 def _load(path):
-    if path.endswith(".h5"):
-        from articulatory_amd.utils.hdf5 import read_hdf5
-
-        return read_hdf5(path, "feats")
-    return np.load(path)
+    return load_scp_value(path)  # .npy, .h5[:dataset], .ark:offset (articulatory_amd/utils/scp.py)
 
 
 def npy_frames(path):
     """Frame count of a (T, C) feature file (.npy: from its header alone, no data is read)."""
-    if path.endswith(".h5"):
+    if not path.endswith(".npy"):
         return int(_load(path).shape[0])
     return int(np.load(path, mmap_mode="r").shape[0])
 

@@ -20,6 +20,7 @@ import yaml
 
 from articulatory_amd.bin.decode import ar_loop, ar_loop_ragged, windows
 from articulatory_amd.utils import load_model
+from articulatory_amd.utils.scp import load_scp_value
 
 
 def write_wav(path, y, sampling_rate):
@@ -41,7 +42,7 @@ def write_wav(path, y, sampling_rate):
 
 
 def read_scp(path):
-    """kaldi-style 'utt_id path.npy' lines (predict_wav.py:95-105)."""
+    """kaldi-style 'utt_id value' lines (predict_wav.py:95-105); values as articulatory_amd/utils/scp.py reads them (.npy, .h5, .ark:offset)."""
     fids, featps = [], []
     with open(path, "r") as inf:
         for line in inf:
@@ -75,7 +76,7 @@ def synthesize_file_list(model, fids, featps, config, device, outdir, batch_size
 
     def kept():
         for fid, featp in zip(fids, featps):
-            c = torch.tensor(np.load(featp), dtype=torch.float).to(device)
+            c = torch.tensor(load_scp_value(featp), dtype=torch.float).to(device)
             if c.shape[0] > 250:  # the reference skips short utterances (predict_wav.py:130)
                 yield fid, c
 

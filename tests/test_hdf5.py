@@ -153,3 +153,37 @@ def test_stats_and_dump_dir_through_the_product_paths(tmp_path):
         assert np.array_equal(arr, feats[utt])
     with pytest.raises(ValueError, match="hdf5 or npy"):
         D.list_features(dumpdir=str(tmp_path / "dump"), fmt="mat")
+
+
+def test_scp_values_npy_h5_and_kaldi_ark(tmp_path):
+    """The three feats.scp value forms of the reference's loaders (scp_dataset.py:20-46), incl. a binary Kaldi archive assembled by hand
+    (key, "\0B", "FM " / "DM ", "\4" rows, "\4" cols, row-major data)."""
+    from articulatory_amd.bin import decode as D
+    from articulatory_amd.utils.scp import load_scp_value
+
+    rng = np.random.default_rng(2)
+    a, b, c = (rng.standard_normal((n, 5)).astype(np.float32) for n in (7, 9, 4))
+    np.save(tmp_path / "a.npy", a)
+    H.write_hdf5(str(tmp_path / "b.h5"), "feats", b)
+    H.write_hdf5(str(tmp_path / "b.h5"), "other", b * 2)
+    ark = tmp_path / "feats.ark"
+    offs = {}
+    with open(ark, "wb") as f:
+        for key, m, tok in (("c", c, b"FM "), ("d", c.astype(np.float64) * 3, b"DM ")):
+            f.write(key.encode() + b" ")
+            offs[key] = f.tell()
+            f.write(b"\0B" + tok + b"\4" + struct.pack("<i", m.shape[0]) + b"\4" + struct.pack("<i", m.shape[1]) + m.tobytes())
+    scp = tmp_path / "feats.scp"
+    scp.write_text(f"a {tmp_path / 'a.npy'}\nb {tmp_path / 'b.h5'}\nb2 {tmp_path / 'b.h5'}:other\nc {ark}:{offs['c']}\nd {ark}:{offs['d']}\n")
+    pairs = D.list_features(feats_scp=str(scp))
+    got = dict(D.load_features(pairs))
+    assert np.array_equal(got["a"], a) and np.array_equal(got["b"], b) and np.array_equal(got["b2"], b * 2)
+    assert np.array_equal(got["c"], c) and np.array_equal(got["d"], c.astype(np.float64) * 3)
+    assert [D.npy_frames(p) for _, p in pairs] == [7, 9, 9, 4, 4]
+    (tmp_path / "bad.scp").write_text("x /path/x.mat\n")
+    with pytest.raises(ValueError, match="Not supported feats.scp type"):
+        D.list_features(feats_scp=str(tmp_path / "bad.scp"))
+    with pytest.raises(ValueError, match="compressed"):
+        with open(tmp_path / "cm.ark", "wb") as f:
+            f.write(b"k \0BCM ")
+        load_scp_value(f"{tmp_path / 'cm.ark'}:2")
