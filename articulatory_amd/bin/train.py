@@ -60,7 +60,7 @@ class WindowCollater:
 
 
 class NpyPairs(torch.utils.data.Dataset):
-    """(audio, features) pairs from two ``utt path`` scp files of ``.npy`` arrays; utterances shorter than the window are dropped
+    """(audio, features) pairs from two ``utt value`` scp files (values as articulatory_amd/utils/scp.py reads them); utterances shorter than the window are dropped
     (remove_short_samples, audio_mel_dataset.py of the reference)."""
 
     def __init__(self, audio_scp, feats_scp, hop_size, min_frames):
@@ -68,20 +68,24 @@ class NpyPairs(torch.utils.data.Dataset):
             with open(p) as f:
                 return dict(line.split(None, 1) for line in f.read().splitlines() if line.strip())
 
+        from articulatory_amd.utils.scp import load_scp_value
+
+        self._load = load_scp_value  # values: .npy, .h5[:dataset] ("wave" / "feats" by default), .ark:offset
         a, c = read(audio_scp), read(feats_scp)
         self.items = []
         for utt in sorted(set(a) & set(c)):
-            feats = np.load(c[utt].strip(), mmap_mode="r")
-            if feats.shape[0] >= min_frames:
-                self.items.append((a[utt].strip(), c[utt].strip()))
+            v = c[utt].strip()
+            frames = np.load(v, mmap_mode="r").shape[0] if v.endswith(".npy") else self._load(v, "feats").shape[0]
+            if frames >= min_frames:
+                self.items.append((a[utt].strip(), v))
         self.hop_size = hop_size
 
     def __len__(self):
         return len(self.items)
 
     def __getitem__(self, i):
-        audio = np.load(self.items[i][0]).astype(np.float32).reshape(-1)
-        feats = np.load(self.items[i][1]).astype(np.float32)
+        audio = np.asarray(self._load(self.items[i][0], "wave"), np.float32).reshape(-1)
+        feats = np.asarray(self._load(self.items[i][1], "feats"), np.float32)
         n = min(len(audio) // self.hop_size, len(feats))
         return audio[: n * self.hop_size], feats[:n]
 
