@@ -30,7 +30,7 @@ import torch
 import yaml
 
 from articulatory_amd.losses import MelSpectrogramLoss, MultiResolutionSTFTLoss
-from articulatory_amd.models import HiFiGANGenerator, HiFiGANMultiScaleMultiPeriodDiscriminator
+from articulatory_amd.models import HiFiGANGenerator
 
 
 class WindowCollater:
@@ -148,15 +148,18 @@ class Trainer:
         self.config, self.device, self.distributed = config, device, distributed
         if config.get("generator_type", "HiFiGANGenerator") != "HiFiGANGenerator":
             raise NotImplementedError(f"generator_type {config['generator_type']} is not built")
-        if config.get("discriminator_type", "HiFiGANMultiScaleMultiPeriodDiscriminator") != "HiFiGANMultiScaleMultiPeriodDiscriminator":
-            raise NotImplementedError(f"discriminator_type {config['discriminator_type']} is not built")
+        import articulatory_amd.models as models
+
+        dtype_name = config.get("discriminator_type", "HiFiGANMultiScaleMultiPeriodDiscriminator")
+        if dtype_name not in ("HiFiGANMultiScaleMultiPeriodDiscriminator", "HiFiGANMultiScaleDiscriminator", "HiFiGANMultiPeriodDiscriminator"):
+            raise NotImplementedError(f"discriminator_type {dtype_name} is not built")
         for flag in ("use_subband_stft_loss", "use_inter_loss", "use_ph_loss", "use_pcd"):
             if config.get(flag, False):
                 raise NotImplementedError(f"{flag} is not built (SURVEY.md §8 f1 covers the HiFi-GAN / HiFi-CAR recipes: mel or multi-resolution STFT loss)")
         gp = config["generator_params"]
         self.use_ar = bool(gp.get("use_ar", False))
         self.G = HiFiGANGenerator(**gp, precision="f32").to(device).train()
-        self.D = HiFiGANMultiScaleMultiPeriodDiscriminator(**config["discriminator_params"]).to(device).train()
+        self.D = getattr(models, dtype_name)(**config["discriminator_params"]).to(device).train()  # train.py:1661-1668
         self.mel = MelSpectrogramLoss(**config["mel_loss_params"]) if config.get("use_mel_loss", False) else None
         self.stft = MultiResolutionSTFTLoss(**config.get("stft_loss_params", {})) if config.get("use_stft_loss", False) else None  # train.py:1688
         if distributed:

@@ -3,7 +3,11 @@
 Same lookup the reference performs on ``articulatory.models`` (articulatory/bin/train.py:1649-1653,
 articulatory/utils/utils.py:325-328; plugin recipe in the reference README.md:65).
 """
-from .discriminator import HiFiGANMultiScaleMultiPeriodDiscriminator  # noqa: F401
+from .discriminator import (  # noqa: F401
+    HiFiGANMultiPeriodDiscriminator,
+    HiFiGANMultiScaleDiscriminator,
+    HiFiGANMultiScaleMultiPeriodDiscriminator,
+)
 from .hifigan import HiFiGANGenerator  # noqa: F401
 
-__all__ = ["HiFiGANGenerator", "HiFiGANMultiScaleMultiPeriodDiscriminator"]
+__all__ = ["HiFiGANGenerator", "HiFiGANMultiScaleMultiPeriodDiscriminator", "HiFiGANMultiScaleDiscriminator", "HiFiGANMultiPeriodDiscriminator"]

@@ -288,6 +288,7 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
 
     def __init__(self, **kw):
         super().__init__()
+        layout = kw.pop("_layout", "msmpd")  # "msd" / "mpd": the stand-alone multi-scale / multi-period classes below
         p = self._params = disc_params(**kw)
         if p["scale_downsample_pooling"] != "AvgPool1d":
             raise NotImplementedError("scale_downsample_pooling: only AvgPool1d is built")
@@ -334,6 +335,12 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
                 else:
                     d.output_conv = conv
             self.mpd.discriminators.append(d)
+        self._name_prefix = ""
+        if layout != "msmpd":  # stand-alone class: its sub-discriminators sit at the top ("discriminators.0...."), hifigan.py:451-500,666-738
+            self._name_prefix = layout + "."
+            subs = getattr(self, layout).discriminators
+            del self.msd, self.mpd
+            self.discriminators = subs
         self._lib = self._handle = None
         self._grad_sync = None
         self._info_cache = {}
@@ -406,7 +413,7 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
     def _raw_parameters(self):
         names, tensors = [], []
         for name, p in self.named_parameters():
-            names.append(name)
+            names.append(self._name_prefix + name)  # the engine's names are the combined discriminator's
             tensors.append(p)
         return tuple(names), tensors
 
@@ -498,3 +505,25 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
                 r[-1] = torch.flatten(r[-1], 1, -1)  # (B, 1, H, P) -> (B, H * P)   (hifigan.py:414)
             ref.append(r)
         return ref
+
+
+class HiFiGANMultiScaleDiscriminator(HiFiGANMultiScaleMultiPeriodDiscriminator):
+    """HiFi-GAN multi-scale discriminator alone (hifigan.py:666-738), same engine."""
+
+    def __init__(self, scales=3, downsample_pooling="AvgPool1d", downsample_pooling_params={"kernel_size": 4, "stride": 2, "padding": 2},
+                 discriminator_params=None, follow_official_norm=False):
+        kw = {} if discriminator_params is None else {"scale_discriminator_params": discriminator_params}
+        super().__init__(scales=scales, scale_downsample_pooling=downsample_pooling, scale_downsample_pooling_params=downsample_pooling_params,
+                         follow_official_norm=follow_official_norm, periods=[], _layout="msd", **kw)
+        if scales < 1:
+            raise ValueError("scales must be at least 1")
+
+
+class HiFiGANMultiPeriodDiscriminator(HiFiGANMultiScaleMultiPeriodDiscriminator):
+    """HiFi-GAN multi-period discriminator alone (hifigan.py:451-500), same engine."""
+
+    def __init__(self, periods=[2, 3, 5, 7, 11], discriminator_params=None):
+        kw = {} if discriminator_params is None else {"period_discriminator_params": discriminator_params}
+        super().__init__(scales=0, periods=list(periods), _layout="mpd", **kw)
+        if not periods:
+            raise ValueError("periods must not be empty")

@@ -166,3 +166,15 @@ def test_stft_loss_oracle_against_float64_dft():
     xm, ym = mags(x), mags(y)
     assert abs(float(sc) - np.linalg.norm(ym - xm) / np.linalg.norm(ym)) < 1e-4 * float(sc)
     assert abs(float(mag) - np.abs(np.log(ym) - np.log(xm)).mean()) < 1e-4 * float(mag)
+
+
+def test_stand_alone_discriminator_classes_state_dict_layout():
+    """HiFiGANMultiScaleDiscriminator / HiFiGANMultiPeriodDiscriminator hold their sub-discriminators at the top level
+    ("discriminators.<i>. ...", hifigan.py:451-500,666-738): the combined class's keys without the msd. / mpd. prefix (checked against the
+    real reference classes when this was written)."""
+    from articulatory_amd.models import HiFiGANMultiPeriodDiscriminator, HiFiGANMultiScaleDiscriminator
+
+    spec = disc_param_spec()
+    assert list(HiFiGANMultiScaleDiscriminator().state_dict()) == [k[4:] for k in spec if k.startswith("msd.")]
+    assert list(HiFiGANMultiPeriodDiscriminator().state_dict()) == [k[4:] for k in spec if k.startswith("mpd.")]
+    assert len(HiFiGANMultiScaleDiscriminator(scales=2).state_dict()) == 32 and len(HiFiGANMultiPeriodDiscriminator(periods=[2, 5]).state_dict()) == 36

@@ -224,3 +224,45 @@ def test_multi_resolution_stft_loss_vs_oracle(T):
     g, gr = a.grad.cpu().numpy().reshape(-1).astype(np.float64), ar.grad.numpy().reshape(-1).astype(np.float64)
     assert 1.0 - float(g @ gr) / float(np.linalg.norm(g) * np.linalg.norm(gr)) < 1e-5
     assert (np.abs(g - gr) < 1e-3 * np.abs(gr).max()).mean() > 0.98
+
+
+@pytest.mark.parametrize("which", ["msd", "mpd"])
+def test_stand_alone_multi_scale_and_multi_period_classes(which):
+    """HiFiGANMultiScaleDiscriminator / HiFiGANMultiPeriodDiscriminator (hifigan.py:666-738, 451-500) on the same engine: the reference's
+    state_dict keys ("discriminators.<i>. ...", the combined class's keys without the msd. / mpd. prefix), outputs and gradients against
+    the oracle."""
+    from articulatory_amd.models import HiFiGANMultiPeriodDiscriminator, HiFiGANMultiScaleDiscriminator
+
+    if which == "msd":
+        d = HiFiGANMultiScaleDiscriminator(scales=2, discriminator_params=SMALL_SCALE)
+        params = dict(scales=2, scale_discriminator_params=SMALL_SCALE, periods=[])
+    else:
+        d = HiFiGANMultiPeriodDiscriminator(periods=[3, 5], discriminator_params=SMALL_PERIOD)
+        params = dict(scales=0, periods=[3, 5], period_discriminator_params=SMALL_PERIOD)
+    sd = synth_disc_state_dict(params, seed=61)
+    assert list(d.state_dict()) == [k[len(which) + 1:] for k in sd]
+    d.load_state_dict({k[len(which) + 1:]: torch.from_numpy(v) for k, v in sd.items()})
+    d = d.cuda()
+    x_np = uniform(3, "x", (2, 1, 613), -0.6, 0.6)
+    x = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    outs = d(x)
+    cots = [[uniform(3, f"cot.{i}.{l}", tuple(t.shape), -1.0, 1.0) / np.sqrt(np.prod(t.shape[1:])) for l, t in enumerate(o)] for i, o in enumerate(outs)]
+    ref_outs, ref = DO.disc_gradients(sd, params, x_np, cots)
+    loss = 0.0
+    for o, r, c in zip(outs, ref_outs, cots):
+        for t, tr, ct in zip(o, r, c):
+            assert float((t.detach().cpu() - tr).abs().max()) < 2e-5 * float(tr.abs().max())
+            loss = loss + (t * torch.from_numpy(ct).cuda()).sum()
+    loss.backward()
+    for k, p in d.named_parameters():
+        a, b = p.grad.cpu().double().reshape(-1), ref[which + "." + k].double().reshape(-1)
+        err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        cos = 1.0 - float(a @ b / (a.norm() * b.norm()).clamp_min(1e-30))
+        assert err < 2e-4 or cos < 1e-5, (k, err, cos)
+
+
+SMALL_SCALE = {"in_channels": 1, "out_channels": 1, "kernel_sizes": [15, 41, 5, 3], "channels": 16, "max_downsample_channels": 64, "max_groups": 4,
+               "bias": True, "downsample_scales": [4, 4, 1], "nonlinear_activation": "LeakyReLU", "nonlinear_activation_params": {"negative_slope": 0.1}}
+SMALL_PERIOD = {"in_channels": 1, "out_channels": 1, "kernel_sizes": [5, 3], "channels": 8, "downsample_scales": [3, 3, 1], "max_downsample_channels": 64,
+                "bias": True, "nonlinear_activation": "LeakyReLU", "nonlinear_activation_params": {"negative_slope": 0.1}, "use_weight_norm": True,
+                "use_spectral_norm": False}
