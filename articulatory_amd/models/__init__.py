@@ -7,7 +7,10 @@ from .discriminator import (  # noqa: F401
     HiFiGANMultiPeriodDiscriminator,
     HiFiGANMultiScaleDiscriminator,
     HiFiGANMultiScaleMultiPeriodDiscriminator,
+    HiFiGANPeriodDiscriminator,
+    HiFiGANScaleDiscriminator,
 )
 from .hifigan import HiFiGANGenerator  # noqa: F401
 
-__all__ = ["HiFiGANGenerator", "HiFiGANMultiScaleMultiPeriodDiscriminator", "HiFiGANMultiScaleDiscriminator", "HiFiGANMultiPeriodDiscriminator"]
+__all__ = ["HiFiGANGenerator", "HiFiGANMultiScaleMultiPeriodDiscriminator", "HiFiGANMultiScaleDiscriminator", "HiFiGANMultiPeriodDiscriminator",
+           "HiFiGANScaleDiscriminator", "HiFiGANPeriodDiscriminator"]

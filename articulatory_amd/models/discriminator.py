@@ -336,7 +336,14 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
                     d.output_conv = conv
             self.mpd.discriminators.append(d)
         self._name_prefix = ""
-        if layout != "msmpd":  # stand-alone class: its sub-discriminators sit at the top ("discriminators.0...."), hifigan.py:451-500,666-738
+        self._single = layout in ("scale", "period")
+        if self._single:  # ONE scale / period discriminator: its layers sit at the top ("layers.0.0.weight", "convs.0.0.bias", "output_conv.*")
+            sub = (self.msd if layout == "scale" else self.mpd).discriminators[0]
+            self._name_prefix = ("msd" if layout == "scale" else "mpd") + ".discriminators.0."
+            del self.msd, self.mpd
+            for name, child in list(sub.named_children()):
+                setattr(self, name, child)
+        elif layout != "msmpd":  # stand-alone multi class: its sub-discriminators sit at the top ("discriminators.0...."), hifigan.py:451-500,666-738
             self._name_prefix = layout + "."
             subs = getattr(self, layout).discriminators
             del self.msd, self.mpd
@@ -497,14 +504,14 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
                 i += n
             outs.append(layers)
         if native:
-            return outs
+            return outs[0] if self._single else outs
         ref = []
         for layers in outs:
             r = [o.reference_layout() for o in layers]
             if layers[-1].period:
                 r[-1] = torch.flatten(r[-1], 1, -1)  # (B, 1, H, P) -> (B, H * P)   (hifigan.py:414)
             ref.append(r)
-        return ref
+        return ref[0] if self._single else ref
 
 
 class HiFiGANMultiScaleDiscriminator(HiFiGANMultiScaleMultiPeriodDiscriminator):
@@ -527,3 +534,19 @@ class HiFiGANMultiPeriodDiscriminator(HiFiGANMultiScaleMultiPeriodDiscriminator)
         super().__init__(scales=0, periods=list(periods), _layout="mpd", **kw)
         if not periods:
             raise ValueError("periods must not be empty")
+
+
+class HiFiGANScaleDiscriminator(HiFiGANMultiScaleMultiPeriodDiscriminator):
+    """ONE HiFi-GAN scale discriminator (hifigan.py:503-663): forward returns the list of its layer outputs."""
+
+    def __init__(self, **discriminator_params):
+        super().__init__(scales=1, periods=[], scale_discriminator_params=dict(disc_params()["scale_discriminator_params"], **discriminator_params),
+                         _layout="scale")
+
+
+class HiFiGANPeriodDiscriminator(HiFiGANMultiScaleMultiPeriodDiscriminator):
+    """ONE HiFi-GAN period discriminator (hifigan.py:317-448)."""
+
+    def __init__(self, period=3, **discriminator_params):
+        super().__init__(scales=0, periods=[period], period_discriminator_params=dict(disc_params()["period_discriminator_params"], **discriminator_params),
+                         _layout="period")

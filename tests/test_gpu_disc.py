@@ -266,3 +266,27 @@ SMALL_SCALE = {"in_channels": 1, "out_channels": 1, "kernel_sizes": [15, 41, 5, 
 SMALL_PERIOD = {"in_channels": 1, "out_channels": 1, "kernel_sizes": [5, 3], "channels": 8, "downsample_scales": [3, 3, 1], "max_downsample_channels": 64,
                 "bias": True, "nonlinear_activation": "LeakyReLU", "nonlinear_activation_params": {"negative_slope": 0.1}, "use_weight_norm": True,
                 "use_spectral_norm": False}
+
+
+@pytest.mark.parametrize("which", ["scale", "period"])
+def test_single_scale_and_period_discriminator_classes(which):
+    """HiFiGANScaleDiscriminator / HiFiGANPeriodDiscriminator (one sub-discriminator, forward returns its list of layer outputs)."""
+    from articulatory_amd.models import HiFiGANPeriodDiscriminator, HiFiGANScaleDiscriminator
+
+    if which == "scale":
+        d = HiFiGANScaleDiscriminator(**SMALL_SCALE)
+        params, prefix = dict(scales=1, scale_discriminator_params=SMALL_SCALE, periods=[]), "msd.discriminators.0."
+    else:
+        d = HiFiGANPeriodDiscriminator(period=5, **SMALL_PERIOD)
+        params, prefix = dict(scales=0, periods=[5], period_discriminator_params=SMALL_PERIOD), "mpd.discriminators.0."
+    sd = synth_disc_state_dict(params, seed=62)
+    assert list(d.state_dict()) == [k[len(prefix):] for k in sd]
+    d.load_state_dict({k[len(prefix):]: torch.from_numpy(v) for k, v in sd.items()})
+    d = d.cuda()
+    x_np = uniform(4, "x", (2, 1, 517), -0.6, 0.6)
+    outs = d(torch.from_numpy(x_np).cuda())
+    with torch.no_grad():
+        ref = DO.disc_forward(DO.fold_disc_weight_norm(sd), params, torch.from_numpy(x_np))[0]
+    assert len(outs) == len(ref)
+    for t, tr in zip(outs, ref):
+        assert tuple(t.shape) == tuple(tr.shape) and float((t.detach().cpu() - tr).abs().max()) < 2e-5 * float(tr.abs().max())
