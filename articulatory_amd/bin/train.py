@@ -34,18 +34,38 @@ from articulatory_amd.models import HiFiGANGenerator
 
 
 class WindowCollater:
-    """random_window packaging of (audio, features) pairs (train.py:1013-1035, 1071-1097 for the a2w + AR case)."""
+    """random_window packaging of (audio, features) pairs (train.py:978-1035, 1071-1097 for the a2w + AR case).
 
-    def __init__(self, batch_max_steps, hop_size, ar_len=None, rng=None):
+    As in the reference, an utterance must be LONGER than the window (``len(art) + end_offset > start_offset``, train.py:987: shorter
+    or equal ones are left out of the batch) and the first frame is drawn from ``[0, len - batch_max_frames)`` (np.random.randint's
+    exclusive upper bound, train.py:1013).  In a DataLoader worker process the generator is re-seeded from the worker's own seed
+    (distinct per worker, and per epoch because torch draws a new base seed for every iterator): copies of one parent generator would
+    otherwise all replay the same draws."""
+
+    def __init__(self, batch_max_steps, hop_size, ar_len=None, rng=None, seed=None):
         assert batch_max_steps % hop_size == 0
         self.batch_max_steps, self.hop_size, self.ar_len = batch_max_steps, hop_size, ar_len
         self.batch_max_frames = batch_max_steps // hop_size
-        self.rng = rng or np.random.default_rng()
+        self.seed = seed
+        self.rng = rng or np.random.default_rng(seed)
+        self._worker_seed = None
+
+    def _generator(self):
+        info = torch.utils.data.get_worker_info()
+        if info is not None and self._worker_seed != info.seed:
+            self._worker_seed = info.seed
+            self.rng = np.random.default_rng([int(info.seed) & 0xFFFFFFFFFFFFFFFF, 0 if self.seed is None else int(self.seed)])
+        return self.rng
 
     def __call__(self, items):
         """items: [(audio (T,), feats (frames, C))] -> {"x": (B, C, frames), "y": (B, 1, T), "ar": (B, 1, ar_len)}."""
+        rng = self._generator()
+        items = [(a, c[: len(a) // self.hop_size]) for a, c in items]
+        items = [(a, c) for a, c in items if len(c) > self.batch_max_frames]
+        if not items:
+            raise ValueError(f"no utterance of the batch is longer than the window ({self.batch_max_frames} frames)")
         audios, feats = zip(*items)
-        starts = np.array([self.rng.integers(0, len(c) - self.batch_max_frames + 1) for c in feats])
+        starts = np.array([rng.integers(0, len(c) - self.batch_max_frames) for c in feats])
         wav_starts = starts * self.hop_size
         y = np.stack([a[s:s + self.batch_max_steps] for a, s in zip(audios, wav_starts)])
         x = np.stack([c[s:s + self.batch_max_frames] for c, s in zip(feats, starts)])
@@ -76,7 +96,7 @@ class NpyPairs(torch.utils.data.Dataset):
         for utt in sorted(set(a) & set(c)):
             v = c[utt].strip()
             frames = np.load(v, mmap_mode="r").shape[0] if v.endswith(".npy") else self._load(v, "feats").shape[0]
-            if frames >= min_frames:
+            if frames > min_frames:  # (strictly longer than the window: audio_mel_dataset.py:57-80 keeps lengths > threshold)
                 self.items.append((a[utt].strip(), v))
         self.hop_size = hop_size
 
@@ -109,7 +129,7 @@ class DumpDirPairs(torch.utils.data.Dataset):
         else:
             raise ValueError("support only hdf5 or npy format.")
         self.files = [f for f in files if (read_hdf5(f, "feats") if fmt == "hdf5" else np.load(f.replace("-wave.npy", "-feats.npy"), mmap_mode="r")).shape[0]
-                      >= min_frames]
+                      > min_frames]
 
     def __len__(self):
         return len(self.files)
@@ -226,7 +246,7 @@ class Trainer:
             if cfg.get("generator_grad_norm", -1) > 0:
                 torch.nn.utils.clip_grad_norm_(self.G.parameters(), cfg["generator_grad_norm"])
             self.optimizer["generator"].step()
-            self.scheduler["generator"].step()
+            self._scheduler_step("generator", gen_loss)
         #######################
         #    Discriminator    #
         #######################
@@ -242,9 +262,15 @@ class Trainer:
             if cfg.get("discriminator_grad_norm", -1) > 0:
                 torch.nn.utils.clip_grad_norm_(self.D.parameters(), cfg["discriminator_grad_norm"])
             self.optimizer["discriminator"].step()
-            self.scheduler["discriminator"].step()
+            self._scheduler_step("discriminator", dis_loss)
         self.steps += 1
         return log
+
+    def _scheduler_step(self, which, loss):
+        if self.config.get(f"{which}_scheduler_type", "StepLR") == "ReduceLROnPlateau":  # train.py:380-383,432-435
+            self.scheduler[which].step(loss.detach())
+        else:
+            self.scheduler[which].step()
 
     # ------------------------------------------------------------------ evaluation (train.py:470-640)
     @torch.no_grad()
@@ -377,7 +403,7 @@ def main(argv=None):
         data = NpyPairs(a.audio_scp, a.feats_scp, hop, frames)
     sampler = torch.utils.data.distributed.DistributedSampler(data, world, rank, shuffle=True) if world > 1 else None
     loader = torch.utils.data.DataLoader(data, batch_size=config["batch_size"], shuffle=sampler is None, sampler=sampler, drop_last=True,
-                                         collate_fn=WindowCollater(config["batch_max_steps"], hop, ar_len, np.random.default_rng(1234 + rank)),
+                                         collate_fn=WindowCollater(config["batch_max_steps"], hop, ar_len, seed=1234 + rank),
                                          num_workers=config.get("num_workers", 0), pin_memory=config.get("pin_memory", False))
     if len(loader) == 0:
         raise SystemExit(f"fewer utterances ({len(data)}) than one batch ({config['batch_size']})")

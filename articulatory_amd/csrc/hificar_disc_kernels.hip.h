@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void sum_kernel(const SumParams p) {
 // GAN losses on the engine's own output buffers (articulatory/losses/adversarial_loss.py:12-123, feat_match_loss.py:12-54): every term
 // is a mean over the elements of one layer output, so one pass per output buffer gives both the term's sum and its gradient.
 //   adv_kind  0 none | 1 (a - 1)^2 | 2 a^2 | 3 -a | 4 -min(a - 1, 0) | 5 -min(-a - 1, 0)      (mse real / gen, mse fake, hinge gen, real, fake)
-//   w_fm != 0: |a - b| against the reference pass's buffer at the same offset (feature matching; b is a constant)
+//   c_fm != 0: |a - b| against the reference pass's buffer at the same offset (feature matching; b is a constant)
 // dout = w_adv * d(adv term) + w_fm * sign(a - b); partial sums per (entry, chunk) are combined in a fixed order by loss_reduce_kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int kLossChunks = 32;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossEntry* entries, con
     for (long long i = lo + threadIdx.x; i < hi; i += 256) {
         const f32x4 av = reinterpret_cast<const f32x4*>(a)[i];
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (b && e.w_fm != 0.f) bv = reinterpret_cast<const f32x4*>(b)[i];
+        if (b && e.c_fm != 0.f) bv = reinterpret_cast<const f32x4*>(b)[i];
         const int col = (int)((i * 4) % e.pitch);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossEntry* entries, con
                 default: break;
             }
             float gf = 0.f;
-            if (e.w_fm != 0.f) {
+            if (e.c_fm != 0.f) {  // (feature matching takes part; w_fm may be 0 when a lambda is 0: the value is still logged)
                 const float df = x - bv[u];
                 s_fm += fabsf(df);
                 gf = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);

@@ -282,6 +282,13 @@ class _SubDisc(torch.nn.Module):
     pass
 
 
+def _slope(sub_params):
+    """LeakyReLU slope of a scale / period discriminator's parameter dict.  A dict WITHOUT the key gets the sub-discriminator class's own
+    default {"negative_slope": 0.1} (hifigan.py:331,517: the user's sub-dict replaces the multi-discriminator's default dict as a whole);
+    an explicit dict without "negative_slope" (e.g. {}) gets torch.nn.LeakyReLU's 0.01."""
+    return float(sub_params.get("nonlinear_activation_params", {"negative_slope": 0.1}).get("negative_slope", 0.01))
+
+
 class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
     """HiFi-GAN multi-scale + multi-period discriminator (MI355X-native forward and backward).  Constructor arguments as the
     reference's (hifigan.py:744-781)."""
@@ -315,7 +322,7 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
                 conv._parameters["bias"] = conv._parameters.pop("bias")  # a plain Conv1d lists weight before bias
                 # (follow_official_norm asks for spectral / weight norm, but the reference's ScaleDiscriminator.apply_* test for Conv2d
                 # on this Conv1d stack: no norm is ever applied, hifigan.py:645-663 — plain weights, as its checkpoints hold)
-                slope = sp.get("nonlinear_activation_params", {}).get("negative_slope", 0.01)
+                slope = _slope(sp)
                 d.layers.append(torch.nn.Sequential(conv, torch.nn.LeakyReLU(slope)) if L["act"] else conv)
             self.msd.discriminators.append(d)
         self.mpd = _SubDisc()
@@ -323,7 +330,7 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         for _period in p["periods"]:
             d = _SubDisc()
             d.convs = torch.nn.ModuleList()
-            slope = pp.get("nonlinear_activation_params", {}).get("negative_slope", 0.01)
+            slope = _slope(pp)
             for L in self._p_layers:
                 conv = _ConvParams((L["cout"], L["cin"], L["k"], 1), L["cout"], bias=True)
                 if pp.get("use_weight_norm", True):
@@ -363,14 +370,14 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         for l, L in enumerate(self._s_layers):
             c.s_cin[l], c.s_cout[l], c.s_k[l], c.s_stride[l], c.s_pad[l], c.s_groups[l] = L["cin"], L["cout"], L["k"], L["stride"], L["pad"], L["groups"]
         c.s_bias = int(bool(self._s_layers[0]["bias"]))
-        c.s_slope = p["scale_discriminator_params"].get("nonlinear_activation_params", {}).get("negative_slope", 0.01)
+        c.s_slope = _slope(p["scale_discriminator_params"])
         c.n_periods = len(p["periods"])
         for i, per in enumerate(p["periods"]):
             c.periods[i] = per
         c.p_n_layers = len(self._p_layers)
         for l, L in enumerate(self._p_layers):
             c.p_cin[l], c.p_cout[l], c.p_k[l], c.p_stride[l], c.p_pad[l] = L["cin"], L["cout"], L["k"], L["stride"], L["pad"]
-        c.p_slope = p["period_discriminator_params"].get("nonlinear_activation_params", {}).get("negative_slope", 0.01)
+        c.p_slope = _slope(p["period_discriminator_params"])
         return c
 
     def _native_handle(self):

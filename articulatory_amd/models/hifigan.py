@@ -134,8 +134,8 @@ class _GeneratorFunction(torch.autograd.Function):
         lib, handle = module._lib, module._handle
         B, _, T = c.shape
         dev = c.device
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             held = _send_parameters(module, names, params, stream)
             tape = torch.empty(lib.hificar_tape_bytes(handle, B, T) + 256, dtype=torch.uint8, device=dev)
             toff = (-tape.data_ptr()) % 256
@@ -638,8 +638,10 @@ class HiFiGANGenerator(torch.nn.Module):
             if int(ph.min()) < 0 or int(ph.max()) >= self._params["num_ph"]:
                 raise IndexError("index out of range in self")
             ph = ph.to(device=c.device, dtype=torch.int32).contiguous()
+        # the autograd node (and its full-utterance tape) only when a gradient can be asked for: an input that requires grad, or a
+        # module in training mode with trainable parameters — model.eval() inference without torch.no_grad() stays on the inference kernels
         if torch.is_grad_enabled() and (c.requires_grad or (ar is not None and ar.requires_grad)
-                                        or any(p.requires_grad for p in self.parameters())):
+                                        or (self.training and any(p.requires_grad for p in self.parameters()))):
             if lengths is not None:
                 raise NotImplementedError("autograd with ragged lengths is not built")
             return self._forward_autograd(c, ar)

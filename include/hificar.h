@@ -32,7 +32,11 @@
  *     synchronises the device except hificar_finalize() (one-time weight upload) and the FIRST call for a new
  *     (batch, frames) shape, which builds and uploads that shape's tile schedules (small device allocations + blocking
  *     copies; cached in the handle afterwards, so a warm-up call per shape keeps the steady state fully asynchronous).
- *   - a handle is not thread-safe; use one handle per (process, device).
+ *   - a handle is not thread-safe; use one handle per (process, device) and, from one host thread at a time, preferably ONE stream
+ *     per handle.  The tile-schedule arenas, the packed AR loop's step table and the caller's workspace are shared state of the
+ *     handle: every entry point that enqueues work first makes its stream wait (hipStreamWaitEvent on an event recorded on the
+ *     previous call's stream) for everything earlier calls on this handle enqueued, so calls on DIFFERENT streams are serialised
+ *     behind each other, never overlapped.  Concurrency comes from separate handles (each with its own workspace), not from streams.
  */
 #ifndef HIFICAR_H
 #define HIFICAR_H

@@ -13,14 +13,15 @@ def test_window_collater_cuts_matching_windows_and_ar_context():
     hop, frames_w, ar_len = 20, 5, 64
     rng = np.random.default_rng(0)
     items = []
-    for n in (9, 30, 5):
+    for n in (9, 30, 6, 5):
         feats = np.arange(n * 3, dtype=np.float32).reshape(n, 3) + 1000 * n
         audio = np.arange(n * hop, dtype=np.float32) + 1
         items.append((audio, feats))
     col = T.WindowCollater(frames_w * hop, hop, ar_len, np.random.default_rng(7))
     seen_pad = seen_full = False
+    short = items.pop()                            # exactly one window long
     for _ in range(50):
-        b = col(items)
+        b = col(items + [short])                   # ... and left out of the batch (reference train.py:987)
         assert b["x"].shape == (3, 3, frames_w) and b["y"].shape == (3, 1, frames_w * hop) and b["ar"].shape == (3, 1, ar_len)
         for i, (audio, feats) in enumerate(items):
             y = b["y"][i, 0].numpy()
@@ -33,7 +34,26 @@ def test_window_collater_cuts_matching_windows_and_ar_context():
             seen_pad |= k < ar_len
             seen_full |= k == ar_len
     assert seen_pad and seen_full
-    assert col([items[2]])["y"][0, 0, 0] == 1      # an utterance exactly one window long: the only start is 0
+    # an utterance exactly one window long is left out of the batch (reference train.py:987) — here the 5-frame item never appears
+    with pytest.raises(ValueError):
+        col([short])
+    starts = {int(col([items[0]])["y"][0, 0, 0]) - 1 for _ in range(200)}
+    assert starts == {0, hop, 2 * hop, 3 * hop}    # 9 frames, window 5: np.random.randint(0, 9 - 5) -> 0..3, upper bound exclusive
+
+
+def test_window_collater_reseeds_per_dataloader_worker():
+    hop, frames_w = 4, 3
+    rng = np.random.default_rng(0)
+    data = [(np.arange(400 * hop, dtype=np.float32), rng.standard_normal((400, 2)).astype(np.float32)) for _ in range(8)]
+    col = T.WindowCollater(frames_w * hop, hop, None, seed=11)
+
+    def epoch():
+        loader = torch.utils.data.DataLoader(data, batch_size=2, collate_fn=col, num_workers=2)
+        return [tuple(b["y"][:, 0, 0].tolist()) for b in loader]
+
+    e1, e2 = epoch(), epoch()
+    assert e1[0] != e1[1]          # two workers: different draws (copies of one generator would repeat them)
+    assert e1 != e2                # a new epoch: new draws
 
 
 def test_npy_pairs_drops_short_utterances_and_aligns_lengths(tmp_path):
@@ -47,7 +67,7 @@ def test_npy_pairs_drops_short_utterances_and_aligns_lengths(tmp_path):
     (tmp_path / "wav.scp").write_text("\n".join(a_lines) + "\n")
     (tmp_path / "feats.scp").write_text("\n".join(c_lines) + "\n")
     ds = T.NpyPairs(str(tmp_path / "wav.scp"), str(tmp_path / "feats.scp"), hop, min_frames=5)
-    assert len(ds) == 2                                                   # "b" is shorter than a window
+    assert len(ds) == 2                                                   # "b" is not longer than a window
     for audio, feats in (ds[0], ds[1]):
         assert len(audio) == len(feats) * hop                             # trimmed to whole frames both ways
     assert len(ds[1][1]) == 18                                            # "c": 185 samples -> 18 frames
