@@ -14,9 +14,11 @@ Follows, function by function:
   articulatory/losses/feat_match_loss.py:12-54    FeatureMatchLoss
   articulatory/losses/mel_loss.py:16-166          MelSpectrogram / MelSpectrogramLoss (torch.stft, center, hann; librosa.filters.mel)
   articulatory/losses/stft_loss.py:16-170         stft magnitude, SpectralConvergenceLoss, LogSTFTMagnitudeLoss, MultiResolutionSTFTLoss
-Pinned by tests/golden/gold_disc_*.npz (oracle/make_golden_disc.py, real reference) — except the mel filterbank: librosa is not in
-this image, so ``mel_filterbank`` restates librosa.filters.mel 0.9 (Slaney scale, slaney norm) from its published algorithm and the mel
-loss is PARITY UNPINNED against the reference (it is checked against an independent float64 DFT restatement instead).
+Pinned by tests/golden/gold_disc_*.npz (oracle/make_golden_disc.py, real reference) and, for the mel / multi-resolution STFT losses,
+tests/golden/gold_loss_aux.npz (oracle/make_golden_loss.py: the reference's own MelSpectrogramLoss / MultiResolutionSTFTLoss modules run
+behind a torch.stft ``return_complex=False`` compatibility shim) — except the mel FILTERBANK MATRIX: librosa is not in this image, so
+``mel_filterbank`` restates librosa.filters.mel 0.9 (Slaney scale, slaney norm) from its published algorithm; the reference's mel loss
+was run with that restated basis, so the basis alone stays PARITY UNPINNED (checked for its defining properties instead).
 """
 from collections import OrderedDict
 
@@ -83,12 +85,12 @@ def disc_forward(w, params, x):
     xs = x
     for i in range(p["scales"]):
         outs.append(scale_disc_forward(w, f"msd.discriminators.{i}", scale_disc_layers(**sp), xs,
-                                       sp.get("nonlinear_activation_params", {}).get("negative_slope", 0.01)))
+                                       sp.get("nonlinear_activation_params", {"negative_slope": 0.1}).get("negative_slope", 0.01)))
         xs = F.avg_pool1d(xs, pool["kernel_size"], pool["stride"], pool["padding"])
     pp = p["period_discriminator_params"]
     for i, period in enumerate(p["periods"]):
         outs.append(period_disc_forward(w, f"mpd.discriminators.{i}", period_disc_layers(**pp), period, x,
-                                        pp.get("nonlinear_activation_params", {}).get("negative_slope", 0.01)))
+                                        pp.get("nonlinear_activation_params", {"negative_slope": 0.1}).get("negative_slope", 0.01)))
     return outs
 
 
@@ -205,6 +207,29 @@ def multi_resolution_stft_loss(x, y, fft_sizes=(1024, 2048, 512), hop_sizes=(120
         sc = sc + torch.norm(ym - xm, p="fro") / torch.norm(ym, p="fro")
         mag = mag + F.l1_loss(torch.log(ym), torch.log(xm))
     return sc / len(fft_sizes), mag / len(fft_sizes)
+
+
+def loss_test_signals(seed, B, T):
+    """Inputs of tests/golden/gold_loss_aux.npz (oracle/make_golden_loss.py).  (y_hat, y): band-limited pseudo-speech (a few decaying harmonics + noise) so that the spectra have structure, plus — for the
+    LAST sequence — a stretch of exact silence in y_hat longer than the largest frame, which puts whole frames on the magnitude clamps
+    (stft_loss.py:40, mel_loss.py:97,100)."""
+    from articulatory_amd.utils.synth import uniform
+
+    t = np.arange(T, dtype=np.float64) / 16000.0
+    out = []
+    for name in ("y_hat", "y"):
+        sig = np.zeros((B, T))
+        for b in range(B):
+            f0 = 90.0 + 35.0 * b + (7.0 if name == "y" else 0.0)
+            amp = uniform(seed, f"{name}.amp.{b}", (8,), 0.02, 0.12).astype(np.float64)
+            for h in range(8):
+                sig[b] += amp[h] * np.sin(2 * np.pi * f0 * (h + 1) * t + 0.3 * h + b)
+        sig += uniform(seed, f"{name}.noise", (B, T), -0.05, 0.05)
+        out.append(sig.astype(np.float32))
+    y_hat, y = out
+    if T >= 2600:
+        y_hat[-1, 200:2500] = 0.0
+    return y_hat[:, None, :], y[:, None, :]
 
 
 def disc_gradients(sd, params, x, cots, dtype=torch.float32):

@@ -178,3 +178,57 @@ def test_stand_alone_discriminator_classes_state_dict_layout():
     assert list(HiFiGANMultiScaleDiscriminator().state_dict()) == [k[4:] for k in spec if k.startswith("msd.")]
     assert list(HiFiGANMultiPeriodDiscriminator().state_dict()) == [k[4:] for k in spec if k.startswith("mpd.")]
     assert len(HiFiGANMultiScaleDiscriminator(scales=2).state_dict()) == 32 and len(HiFiGANMultiPeriodDiscriminator(periods=[2, 5]).state_dict()) == 36
+
+
+# ---------------------------------------------------------------- auxiliary losses vs the REAL reference modules (gold_loss_aux.npz)
+LOSS_CASES = [(tag, sname) for tag in ("recipe", "odd", "silence") for sname in ("default", "alt")]
+STFT_SETS = {"default": {}, "alt": {"fft_sizes": [512, 256], "hop_sizes": [128, 64], "win_lengths": [512, 200]}}
+MEL_SETS = {"recipe": dict(fs=16000, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=0, fmax=11025, log_base=None),
+            "default": {}}
+
+
+def kinked_gradient_close(g, ref, frac=0.98):
+    """|.| terms flip sign where two values agree to rounding (the reference in fp32 and fp64 differs by 1e-4 there, see the
+    ``f32_vs_f64`` entries of the fixture): direction + nearly all elements."""
+    g, ref = np.asarray(g, np.float64).reshape(-1), np.asarray(ref, np.float64).reshape(-1)
+    cos = 1.0 - float(g @ ref) / float(np.linalg.norm(g) * np.linalg.norm(ref))
+    return cos < 1e-5 and (np.abs(g - ref) < 1e-3 * np.abs(ref).max()).mean() > frac
+
+
+@pytest.mark.parametrize("tag,sname", LOSS_CASES)
+def test_stft_loss_oracle_vs_reference_golden(tag, sname):
+    """multi_resolution_stft_loss vs articulatory.losses.stft_loss.MultiResolutionSTFTLoss run by oracle/make_golden_loss.py."""
+    gold = np.load(os.path.join(GOLDEN, "gold_loss_aux.npz"))
+    yh_np, y_np = DO.loss_test_signals(int(gold[f"{tag}::seed"]), int(gold[f"{tag}::B"]), int(gold[f"{tag}::T"]))
+    for which in ("sc", "mag"):
+        yh = torch.from_numpy(yh_np).requires_grad_(True)
+        sc, mag = DO.multi_resolution_stft_loss(yh, torch.from_numpy(y_np), **STFT_SETS[sname])
+        val = sc if which == "sc" else mag
+        val.backward()
+        ref = float(gold[f"{tag}::stft::{sname}::{which}::f32"])
+        assert abs(float(val.detach()) - ref) < 2e-6 * abs(ref)
+        g, gr = yh.grad.numpy(), gold[f"{tag}::stft::{sname}::d{which}::f32"]
+        if which == "sc":
+            assert np.abs(g - gr).max() < 2e-5 * np.abs(gr).max()
+        else:
+            assert kinked_gradient_close(g, gr)
+
+
+@pytest.mark.parametrize("tag", ["recipe", "odd", "silence"])
+@pytest.mark.parametrize("mname", ["recipe", "default"])
+def test_mel_loss_oracle_vs_reference_golden(tag, mname):
+    """mel_loss / mel_spectrogram vs articulatory.losses.mel_loss.MelSpectrogramLoss / MelSpectrogram (restated filterbank on both sides)."""
+    gold = np.load(os.path.join(GOLDEN, "gold_loss_aux.npz"))
+    yh_np, y_np = DO.loss_test_signals(int(gold[f"{tag}::seed"]), int(gold[f"{tag}::B"]), int(gold[f"{tag}::T"]))
+    kw = MEL_SETS[mname]
+    fb = DO.mel_filterbank(kw.get("fs", 22050), kw.get("fft_size", 1024), kw.get("num_mels", 80), kw.get("fmin", 80), kw.get("fmax", 7600))
+    assert abs(float(fb.astype(np.float64).sum()) - float(gold[f"melmat::{mname}::sum"])) < 1e-9  # the basis the fixture was made with
+    spec = DO.mel_spectrogram(torch.from_numpy(yh_np), **kw).numpy()
+    ref_spec = gold[f"{tag}::mel::{mname}::spec"]
+    assert spec.shape == ref_spec.shape and np.abs(spec - ref_spec).max() < 1e-4
+    yh = torch.from_numpy(yh_np).requires_grad_(True)
+    loss = DO.mel_loss(yh, torch.from_numpy(y_np), **kw)
+    loss.backward()
+    ref = float(gold[f"{tag}::mel::{mname}::loss::f32"])
+    assert abs(float(loss.detach()) - ref) < 2e-6 * abs(ref)
+    assert kinked_gradient_close(yh.grad.numpy(), gold[f"{tag}::mel::{mname}::dloss::f32"])
