@@ -52,6 +52,7 @@ SYMBOLS = (
     "hificar_disc_set_parameters_device",
     "hificar_disc_weight_norm_backward",
     "hificar_disc_tape_bytes",
+    "hificar_disc_macs",
     "hificar_disc_backward_workspace_bytes",
     "hificar_disc_output_count",
     "hificar_disc_output_info",
@@ -271,6 +272,8 @@ def load_library():
     lib.hificar_disc_weight_norm_backward.restype = ci
     lib.hificar_disc_tape_bytes.argtypes = [vp, ci, ci]
     lib.hificar_disc_tape_bytes.restype = cs
+    lib.hificar_disc_macs.argtypes = [vp, ci, ci]
+    lib.hificar_disc_macs.restype = ctypes.c_double
     lib.hificar_disc_backward_workspace_bytes.argtypes = [vp, ci, ci]
     lib.hificar_disc_backward_workspace_bytes.restype = cs
     lib.hificar_disc_output_count.argtypes = [vp]

@@ -437,6 +437,11 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         self._grad_sync = (group, bool(average)) if enabled else None
         return self
 
+    def macs(self, B, T):
+        """Algorithmic multiply-accumulates of one forward over (B, 1, T) (hificar_disc_macs)."""
+        self._native_handle()
+        return float(self._lib.hificar_disc_macs(self._handle, B, T))
+
     def profile_begin(self):
         self._native_handle()
         _native.check(self._lib.hificar_profile_begin(self._lib.hificar_disc_engine(self._handle)), "hificar_profile_begin")

@@ -196,6 +196,40 @@ def synth_features(batch: int, frames: int, dims: int, seed: int) -> np.ndarray:
 # ------------------------------------------------------------------------------------------------
 # HiFiGANMultiScaleMultiPeriodDiscriminator (reference articulatory/models/hifigan.py:317-825)
 # ------------------------------------------------------------------------------------------------
+def synth_waveforms(seed, B, T):
+    """Waveform pairs for the loss / training fixtures (tests/golden/gold_loss_aux.npz, gold_train_step.npz).  (y_hat, y): band-limited pseudo-speech (a few decaying harmonics + noise) so that the spectra have structure, plus — for the
+    LAST sequence — a stretch of exact silence in y_hat longer than the largest frame, which puts whole frames on the magnitude clamps
+    (stft_loss.py:40, mel_loss.py:97,100)."""
+    t = np.arange(T, dtype=np.float64) / 16000.0
+    out = []
+    for name in ("y_hat", "y"):
+        sig = np.zeros((B, T))
+        for b in range(B):
+            f0 = 90.0 + 35.0 * b + (7.0 if name == "y" else 0.0)
+            amp = uniform(seed, f"{name}.amp.{b}", (8,), 0.02, 0.12).astype(np.float64)
+            for h in range(8):
+                sig[b] += amp[h] * np.sin(2 * np.pi * f0 * (h + 1) * t + 0.3 * h + b)
+        sig += uniform(seed, f"{name}.noise", (B, T), -0.05, 0.05)
+        out.append(sig.astype(np.float32))
+    y_hat, y = out
+    if T >= 2600:
+        y_hat[-1, 200:2500] = 0.0
+    return y_hat[:, None, :], y[:, None, :]
+
+
+def synth_train_batch(config, seed, batch):
+    """One training batch of a recipe as numpy: {"x": (B, dims, frames), "y": (B, 1, batch_max_steps), "ar": (B, 1, ar_input)} — what the
+    reference's collater hands _train_step for the a2w + AR recipes (train.py:1071-1097); the AR context and the window are one
+    continuous waveform."""
+    gp = config["generator_params"]
+    hop = int(np.prod(gp["upsample_scales"]))
+    frames = config["batch_max_steps"] // hop
+    dims = gp["in_channels"] - gp["ar_output"]
+    x = synth_features(batch, frames, dims, seed=seed).transpose(0, 2, 1).copy()
+    _, wav = synth_waveforms(seed + 1, batch, gp["ar_input"] + config["batch_max_steps"])
+    return {"x": x.astype(np.float32), "y": wav[:, :, gp["ar_input"]:].copy(), "ar": wav[:, :, : gp["ar_input"]].copy()}
+
+
 DISC_DEFAULTS = dict(
     scales=3,
     scale_downsample_pooling="AvgPool1d",

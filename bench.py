@@ -180,65 +180,109 @@ def roofline_block(stats, precision, wall_s, steps, traffic_table):
     return blk
 
 
-def training_leg(gen_params):
-    """Secondary, informational: the train step of BASELINE config 5's recipe on this GPU — the generator's
-    forward + backward + Adam, and the full GAN iteration of articulatory_amd/bin/train.py::Trainer (generator + multi-scale /
-    multi-period discriminators, mel + adversarial + feature-matching losses, both Adam updates) at e2w_hifigan_car.yaml's batch
-    (64 windows of 2000 samples + 512 AR samples).  Exact fp32.  Not part of `value`."""
+def training_leg(steps=5):
+    """Secondary leg: BASELINE config 5's train step on this GPU — the whole GAN iteration of
+    articulatory_amd/bin/train.py::Trainer on the shipped recipe e2w_hifigan_car.yaml (full generator + multi-scale / multi-period
+    discriminators, mel + adversarial + feature-matching losses, both Adam updates) at the recipe's batch (64 windows of 2000 samples +
+    512 AR samples).  Exact fp32 (the reference has no bf16 path).  Not part of `value`.
+
+    parity_gate   the fixture iteration first: the same Trainer at batch 8 on the seeds of tests/golden/gold_train_step.npz — every
+                  logged loss against the values the REAL reference's Trainer._train_step produced (oracle/make_golden_train.py).
+    flops         algorithmic FLOPs of one iteration AS THE STEP RUNS IT: generator forward x2 (with tape; again without, train.py:389)
+                  + backward (data + weight gradients = 2 forwards); discriminator forward x3 (fake, real; fake again — D(real) of the
+                  generator part is re-used), data-only backward x1 (generator part), full backward x2 (fake, real: 2 forwards each).
+                  Loss GEMMs (DFT / mel: < 0.5 %) and element-wise work are not counted.
+    kernels       an event-bracketed pass over the same iterations (libhificar's profile hooks on both engines)."""
     import numpy as np
     import torch
 
-    from articulatory_amd.bin.train import SyntheticPairs, Trainer, WindowCollater
-    from articulatory_amd.utils.synth import disc_params
+    from articulatory_amd.bin.train import Trainer
+    from articulatory_amd.utils.recipes import recipe_train_config
+    from articulatory_amd.utils.synth import synth_disc_state_dict, synth_state_dict, synth_train_batch
 
-    adam = {"lr": 1.0e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}
-    sched = {"gamma": 0.5, "milestones": [40000, 80000, 120000, 160000]}
-    cfg = dict(
-        generator_params=dict(gen_params),
-        discriminator_params=dict(scale_discriminator_params=dict(disc_params()["scale_discriminator_params"], downsample_scales=[4, 4, 4, 4, 1])),
-        use_mel_loss=True, mel_loss_params=dict(fs=16000, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=0,
-                                                fmax=11025, log_base=None),
-        generator_adv_loss_params={"average_by_discriminators": False}, discriminator_adv_loss_params={"average_by_discriminators": False},
-        use_feat_match_loss=True, feat_match_loss_params={"average_by_discriminators": False, "average_by_layers": False, "include_final_outputs": False},
-        lambda_aux=45.0, lambda_adv=1.0, lambda_feat_match=2.0, batch_size=64, batch_max_steps=2000,
-        generator_optimizer_type="Adam", generator_optimizer_params=adam, generator_scheduler_type="MultiStepLR", generator_scheduler_params=sched,
-        discriminator_optimizer_type="Adam", discriminator_optimizer_params=adam, discriminator_scheduler_type="MultiStepLR",
-        discriminator_scheduler_params=sched, discriminator_train_start_steps=0, distributed=False)
-    trainer = Trainer(cfg, torch.device("cuda"))
-    data = SyntheticPairs(64, 100, 13, HOP, seed=0)
-    batch = WindowCollater(2000, HOP, 512, np.random.default_rng(0))([data[i] for i in range(64)])
+    dev = torch.device("cuda")
 
-    def timed(fn, k):
-        for _ in range(2):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / k
+    def build(batch, seed_g, seed_d):
+        cfg = recipe_train_config("car", aux="mel", batch=batch)
+        t = Trainer(cfg, dev)
+        t.G.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg["generator_params"], seed=seed_g).items()})
+        t.D.load_state_dict({k: torch.from_numpy(v) for k, v in synth_disc_state_dict(cfg["discriminator_params"], seed=seed_d).items()})
+        return t, cfg
 
-    trainer.steps = 0  # discriminator_train_start_steps = 0: step 0 trains nothing adversarial -> generator + mel only
-    x, y, ar = batch["x"].cuda(), batch["y"].cuda(), batch["ar"].cuda()
+    # ---- parity gate on the reference's own numbers
+    gate = {"fixture": "tests/golden/gold_train_step.npz (articulatory.bin.train.Trainer._train_step on e2w_hifigan_car.yaml, batch 8)"}
+    gpath = os.path.join(REPO, "tests", "golden", "gold_train_step.npz")
+    gold = np.load(gpath)
+    seed_g, seed_d, seed_x = (int(v) for v in gold["seeds"])
+    t, cfg = build(int(gold["B"]), seed_g, seed_d)
+    t.steps = 2
+    log = {k: float(v) for k, v in t.train_step({k: torch.from_numpy(v) for k, v in synth_train_batch(cfg, seed_x, int(gold["B"])).items()}).items()}
+    worst = 0.0
+    for k, v in sorted(log.items()):
+        ref = float(gold[f"mel::log::{k}"])
+        err = abs(v - ref) / max(abs(ref), 1e-3)
+        worst = max(worst, err)
+        gate[k.split("/")[1]] = {"value": v, "reference": ref, "rel_err": float(f"{err:.2e}")}
+    gate["tolerance"], gate["ok"] = 1e-4, bool(worst < 1e-4)
+    assert gate["ok"], f"training parity gate failed: {gate}"
+    del t
 
-    def gen_only():
-        trainer.optimizer["generator"].zero_grad(set_to_none=True)
-        (trainer.G(x, ar=ar) - y).abs().mean().backward()
-        trainer.optimizer["generator"].step()
+    # ---- the recipe's batch
+    B = 64
+    t, cfg = build(B, 1234, 4321)
+    batch = {k: torch.from_numpy(v) for k, v in synth_train_batch(cfg, 20260929, B).items()}
+    frames = cfg["batch_max_steps"] // HOP
+    T_disc = cfg["generator_params"]["ar_input"] + cfg["batch_max_steps"]
 
-    t_gen = timed(gen_only, 10)
+    def iteration():
+        t.steps = 2
+        return t.train_step(batch)
 
-    def gan():
-        trainer.steps = 1
-        trainer.train_step(batch)
+    for _ in range(3):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        log = iteration()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert all(np.isfinite(float(v)) for v in log.values())
+    g_fwd, d_fwd = 2.0 * t.G.macs(B, frames), 2.0 * t.D.macs(B, T_disc)
+    breakdown = {"generator_forward_x2": 2 * g_fwd, "generator_backward": 2 * g_fwd, "discriminator_forward_x3": 3 * d_fwd,
+                 "discriminator_backward_data_only_x1": d_fwd, "discriminator_backward_full_x2": 4 * d_fwd}
+    flops = sum(breakdown.values())
+    t.G.profile_begin()
+    t.D.profile_begin()
+    for _ in range(steps):
+        iteration()
+    stats = {}
+    for s in t.G.profile_end() + t.D.profile_end():
+        a = stats.setdefault(s["name"], dict(name=s["name"], launches=0, total_ms=0.0, flops=0.0))
+        a["launches"] += s["launches"]
+        a["total_ms"] += s["total_ms"]
+        a["flops"] += s["flops"]
+    stats = sorted(stats.values(), key=lambda s: -s["total_ms"])
+    total_ms = sum(s["total_ms"] for s in stats)
+    dom = stats[0]
+    tf = flops / dt / 1e12
 
-    t_gan = timed(gan, 5)
-    macs = trainer.G.macs(64, 25)
-    return {"note": "informational: BASELINE config 5's recipe on ONE GPU, exact fp32 (the reference has no bf16 path)",
-            "workload": "e2w_hifigan_car.yaml: batch 64 x (2000 + 512 AR) samples",
-            "generator_train_step_ms": round(t_gen * 1e3, 2), "generator_train_step_algorithmic_tflops": round(6 * macs / t_gen / 1e12, 1),
-            "gan_iteration_ms": round(t_gan * 1e3, 2), "gan_windows_per_s": round(64 / t_gan, 1),
-            "gan_training_samples_per_s": round(64 * 2000 / t_gan, 1)}
+    def row(s):
+        return {"name": s["name"], "launches_per_iteration": round(s["launches"] / steps, 1), "avg_launch_us": round(s["total_ms"] * 1e3 / s["launches"], 2),
+                "ms_per_iteration": round(s["total_ms"] / steps, 3), "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2),
+                "kernel_time_share": round(s["total_ms"] / total_ms, 4)}
+
+    return {"note": "BASELINE config 5's recipe on ONE GPU, exact fp32 (the reference has no bf16 path); losses gated against the reference's "
+                    "own _train_step fixture before timing",
+            "workload": f"e2w_hifigan_car.yaml: batch {B} x ({cfg['batch_max_steps']} + {cfg['generator_params']['ar_input']} AR) samples, mel + adversarial + "
+                        "feature-matching losses, Adam x2",
+            "parity_gate": gate, "steps": steps, "gan_iteration_ms": round(dt * 1e3, 2), "gan_windows_per_s": round(B / dt, 1),
+            "gan_training_samples_per_s": round(B * cfg["batch_max_steps"] / dt, 1),
+            "flops_per_iteration": flops, "flops_breakdown": breakdown,
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["f32"], 4),
+                         "traffic": None, "dominant_kernel": row(dom)},
+            "kernel_ms_per_iteration_sum": round(total_ms / steps, 2),
+            "kernels": [row(s) for s in stats[:14]],
+            "first_losses": {k.split("/")[1]: float(v) for k, v in sorted(log.items())}}
 
 
 def main(argv=None, synth_factory=None):
@@ -438,7 +482,7 @@ def main(argv=None, synth_factory=None):
         out["fast_bf16x3"] = leg
 
     if solo and args.precision == "f32" and not args.no_training:
-        out["training"] = training_leg(params)
+        out["training"] = training_leg()
 
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, sd, args.chunk_frames, seed=20260929)

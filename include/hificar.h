@@ -327,6 +327,9 @@ int64_t hificar_disc_raw_grad_floats(const hificar_disc* d);
 int hificar_disc_set_parameters_device(hificar_disc* d, const char* const* names, const float* const* data, int n, void* stream);
 int hificar_disc_weight_norm_backward(hificar_disc* d, const float* grads, float* raw_grads, void* stream);
 size_t hificar_disc_tape_bytes(const hificar_disc* d, int B, int T);
+/* Algorithmic multiply-accumulates of one discriminator forward over (B, 1, T) (every Conv1d / Conv2d of hifigan.py:317-825: output
+ * positions x cout x cin / groups x k) — the training roofline's work unit, as hificar_macs is the generator's. */
+double hificar_disc_macs(const hificar_disc* d, int B, int T);
 size_t hificar_disc_backward_workspace_bytes(const hificar_disc* d, int B, int T);
 int hificar_disc_output_count(const hificar_disc* d);
 int hificar_disc_output_info(const hificar_disc* d, int B, int T, int i, hificar_disc_output* out);

@@ -210,26 +210,10 @@ def multi_resolution_stft_loss(x, y, fft_sizes=(1024, 2048, 512), hop_sizes=(120
 
 
 def loss_test_signals(seed, B, T):
-    """Inputs of tests/golden/gold_loss_aux.npz (oracle/make_golden_loss.py).  (y_hat, y): band-limited pseudo-speech (a few decaying harmonics + noise) so that the spectra have structure, plus — for the
-    LAST sequence — a stretch of exact silence in y_hat longer than the largest frame, which puts whole frames on the magnitude clamps
-    (stft_loss.py:40, mel_loss.py:97,100)."""
-    from articulatory_amd.utils.synth import uniform
+    """Inputs of tests/golden/gold_loss_aux.npz (oracle/make_golden_loss.py): articulatory_amd.utils.synth.synth_waveforms."""
+    from articulatory_amd.utils.synth import synth_waveforms
 
-    t = np.arange(T, dtype=np.float64) / 16000.0
-    out = []
-    for name in ("y_hat", "y"):
-        sig = np.zeros((B, T))
-        for b in range(B):
-            f0 = 90.0 + 35.0 * b + (7.0 if name == "y" else 0.0)
-            amp = uniform(seed, f"{name}.amp.{b}", (8,), 0.02, 0.12).astype(np.float64)
-            for h in range(8):
-                sig[b] += amp[h] * np.sin(2 * np.pi * f0 * (h + 1) * t + 0.3 * h + b)
-        sig += uniform(seed, f"{name}.noise", (B, T), -0.05, 0.05)
-        out.append(sig.astype(np.float32))
-    y_hat, y = out
-    if T >= 2600:
-        y_hat[-1, 200:2500] = 0.0
-    return y_hat[:, None, :], y[:, None, :]
+    return synth_waveforms(seed, B, T)
 
 
 def disc_gradients(sd, params, x, cots, dtype=torch.float32):

@@ -47,17 +47,9 @@ def recipe_config():
 
 
 def make_batch(cfg, seed=SEED_X, batch=B):
-    """{"x": (B, 13, 25), "y": (B, 1, 2000), "ar": (B, 1, 512)} as numpy (the collater's output for the a2w + AR recipe, train.py:1071-1097)."""
-    from articulatory_amd.utils.synth import synth_features
-    from disc_oracle import loss_test_signals
+    from articulatory_amd.utils.synth import synth_train_batch
 
-    gp = cfg["generator_params"]
-    hop = int(np.prod(gp["upsample_scales"]))
-    frames = cfg["batch_max_steps"] // hop
-    dims = gp["in_channels"] - gp["ar_output"]
-    x = synth_features(batch, frames, dims, seed=seed).transpose(0, 2, 1).copy()
-    _, wav = loss_test_signals(seed + 1, batch, gp["ar_input"] + cfg["batch_max_steps"])  # one continuous signal: context + window
-    return {"x": x.astype(np.float32), "y": wav[:, :, gp["ar_input"]:].copy(), "ar": wav[:, :, : gp["ar_input"]].copy()}
+    return synth_train_batch(cfg, seed, batch)
 
 
 def main():
