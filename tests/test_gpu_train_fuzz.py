@@ -3,9 +3,15 @@ strides 2 .. 8, kernel sizes 3 .. 11, dilations up to 5, 1 .. 3 ResBlocks of une
 AR branch — every element of every parameter / input gradient against the CPU oracle's autograd.  The backward has its own kernels per
 tap count (wgrad_taps_kernel<1,2,3,7,11>, wgrad_gemm_kernel) and split-K forms; this walks them.  HIFICAR_FUZZ_CASES raises the count.
 
-LeakyReLU makes gradients discontinuous where a pre-activation is within rounding distance of zero: the oracle is run in
-float64 AND float32, a tensor must be within 2e-4 of the float64 gradient, or — where the oracle's own float32 run is off by more than
-1e-4 for that tensor (a kink on this input) — no further from it than a few times the oracle's float32 deviation."""
+LeakyReLU makes gradients discontinuous where a pre-activation is within rounding distance of zero, and ONE activation
+that falls on the other side moves a whole output channel's weight gradient of a short sequence by percents (tests/dev/grad_fuzz_probe.py:
+cases 13 / 17 / 62 of the first version of this test — the same configurations are exact to 1e-6 on inputs without such an activation).
+So the input is chosen, per case, such that the float64 oracle sees NO LeakyReLU input (generator slope, the PastFCEncoder's 0.1, the
+output conv's 0.01) closer to zero than 2e-6 of its tensor's scale — a few times the device's forward deviation — by trying input seeds
+(the odd, kinked cases are sized to ~5 x 10^4 activations so that a few tries suffice).  Then EVERY element of EVERY gradient must be within
+2e-4 of the float64 oracle.  Even cases force negative_slope = 1.0 and keep the drawn, bigger shapes (many tiles, row splits): only the output
+conv and the MLP have kinks there; when no clean input turns up in a few seeds they fall back to flip-robust statistics (median tensor
+within 2e-5, none beyond 0.2)."""
 import os
 
 import numpy as np
@@ -40,11 +46,33 @@ def draw(rng):
                 nonlinear_activation_params={"negative_slope": float(rng.choice([0.1, 0.1, 0.2, 0.01, 1.0]))}), cf
 
 
+def kink_margin(sd, params, c_np, ar_np):
+    """Smallest |x| / max|x| over every LeakyReLU input of the float64 oracle forward (slope-1 calls do not count)."""
+    margins = []
+    real = O.F.leaky_relu
+
+    def spy(x, negative_slope=0.01, *a, **kw):
+        if negative_slope != 1.0 and x.numel():
+            margins.append(float(x.abs().min() / x.abs().max().clamp_min(1e-300)))
+        return real(x, negative_slope, *a, **kw)
+
+    O.F.leaky_relu = spy
+    try:
+        with torch.no_grad():
+            O.generator_forward(O.fold_weight_norm(sd, dtype=torch.float64), params, torch.from_numpy(c_np).double(),
+                                torch.from_numpy(ar_np).double() if ar_np is not None else None)
+    finally:
+        O.F.leaky_relu = real
+    return min(margins) if margins else 1.0
+
+
 @pytest.mark.parametrize("case", range(N_CASES))
 def test_random_configuration_gradients(case):
     assert torch.cuda.is_available()
     rng = np.random.default_rng(31000 + case)
     params, cf = draw(rng)
+    if case % 2 == 0:
+        params["nonlinear_activation_params"] = {"negative_slope": 1.0}
     hop = int(np.prod(params["upsample_scales"]))
     sd = synth_state_dict(params, seed=700 + case)
     g = HiFiGANGenerator(**params, precision="f32")
@@ -52,8 +80,23 @@ def test_random_configuration_gradients(case):
     g = g.train().cuda()
     B = int(rng.integers(1, 5)) if rng.integers(0, 4) else int(rng.integers(5, 24))
     T = int(rng.integers(2, 30)) if rng.integers(0, 4) else int(rng.integers(30, 120))
-    c_np = synth_features(B, T, cf, seed=case).transpose(0, 2, 1).copy()
-    ar_np = (synth_features(B, 512, 1, seed=case + 1)[:, :, 0] * 0.4).reshape(B, 1, 512).astype(np.float32) if params["use_ar"] else None
+    if case % 2:  # kinked: keep the number of activations near 5 x 10^4 (a clean input is then found within a few seeds)
+        per_frame, width, rate = 0, params["channels"], 1
+        for i, s_ in enumerate(params["upsample_scales"]):
+            width, rate = width // 2, rate * s_
+            per_frame += rate * width * (1 + 2 * sum(len(d) for d in params["resblock_dilations"]))
+        T = max(2, min(T, int(5e4 / max(per_frame * B, 1))))
+        B = max(1, min(B, int(5e4 / max(per_frame * T, 1))))
+    clean = False
+    for attempt in range(40 if case % 2 else 6):
+        c_np = synth_features(B, T, cf, seed=case + 1000 * attempt).transpose(0, 2, 1).copy()
+        ar_np = ((synth_features(B, 512, 1, seed=case + 1 + 1000 * attempt)[:, :, 0] * 0.4).reshape(B, 1, 512).astype(np.float32)
+                 if params["use_ar"] else None)
+        if kink_margin(sd, params, c_np, ar_np) > 2e-6:
+            clean = True
+            break
+    if not clean and case % 2:
+        pytest.fail(f"case {case}: no input without a LeakyReLU input within 2e-6 of zero in 40 seeds (B {B}, T {T})")
     cot = uniform(case, "cot", (B, 1, hop * T), -1.0, 1.0)
     c = torch.from_numpy(c_np).cuda().requires_grad_(True)
     ar = torch.from_numpy(ar_np).cuda().requires_grad_(True) if ar_np is not None else None
@@ -61,7 +104,6 @@ def test_random_configuration_gradients(case):
     (y * torch.from_numpy(cot).cuda()).sum().backward()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     out64, ref64 = O.gradients(sd, params, c_np, ar_np, cot, dtype=torch.float64)
-    _, ref32 = O.gradients(sd, params, c_np, ar_np, cot)
     tag = (case, {k: params[k] for k in ("channels", "kernel_size", "upsample_scales", "resblock_kernel_sizes", "resblock_dilations", "use_ar",
                                          "in_channels", "bias", "use_weight_norm", "nonlinear_activation_params")}, B, T)
     assert rel_err(y.detach().cpu().numpy(), out64.numpy()) < 2e-5, tag
@@ -70,13 +112,13 @@ def test_random_configuration_gradients(case):
     if ar is not None:
         got["ar"] = ar.grad
     assert sorted(got) == sorted(ref64), tag
-    bad = {}
+    errs = {}
     for k in ref64:
         assert got[k] is not None and bool(torch.isfinite(got[k]).all()), (tag, k)
-        e_dev = rel_err(got[k].cpu().numpy(), ref64[k].numpy())
-        e_cpu = rel_err(ref32[k].numpy(), ref64[k].numpy())
-        if e_dev >= max(TOL, 4.0 * e_cpu if e_cpu > 1e-4 else 0.0):
-            bad[k] = (e_dev, e_cpu)
-    # a kink that flips on the device but not in the CPU's float32 run shows in the few tensors its receptive field feeds: allow a
-    # handful, none beyond a few percent; anything systematic (a wrong tap, stride, split) fails every tensor of a layer at O(1)
-    assert len(bad) <= max(2, len(ref64) // 20) and all(v[0] < 5e-2 for v in bad.values()), (tag, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8])
+        errs[k] = rel_err(got[k].cpu().numpy(), ref64[k].numpy())
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    if clean:
+        assert worst[0][1] < TOL, (tag, attempt, worst)
+    else:  # (an even case whose output conv / MLP input comes within 2e-6 of a kink for every seed tried)
+        v = np.array(list(errs.values()))
+        assert np.median(v) < 2e-5 and v.max() < 0.2, (tag, float(np.median(v)), worst)
