@@ -74,6 +74,8 @@ SYMBOLS = (
     "hificar_grad_info",
     "hificar_grad_floats",
     "hificar_backward",
+    "hificar_forward_train_cond",
+    "hificar_backward_cond",
     "hificar_destroy",
     "hificar_last_error",
     "hificar_version",
@@ -316,6 +318,10 @@ def load_library():
     lib.hificar_grad_floats.restype = ctypes.c_int64
     lib.hificar_backward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.hificar_backward.restype = ctypes.c_int
+    lib.hificar_forward_train_cond.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]
+    lib.hificar_forward_train_cond.restype = ctypes.c_int
+    lib.hificar_backward_cond.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.hificar_backward_cond.restype = ctypes.c_int
     lib.hificar_destroy.argtypes = [vp]
     lib.hificar_destroy.restype = None
     lib.hificar_last_error.argtypes = []

@@ -173,11 +173,12 @@ class Trainer:
         dtype_name = config.get("discriminator_type", "HiFiGANMultiScaleMultiPeriodDiscriminator")
         if dtype_name not in ("HiFiGANMultiScaleMultiPeriodDiscriminator", "HiFiGANMultiScaleDiscriminator", "HiFiGANMultiPeriodDiscriminator"):
             raise NotImplementedError(f"discriminator_type {dtype_name} is not built")
-        for flag in ("use_subband_stft_loss", "use_inter_loss", "use_ph_loss", "use_pcd"):
+        for flag in ("use_subband_stft_loss", "use_inter_loss", "use_pcd"):
             if config.get(flag, False):
                 raise NotImplementedError(f"{flag} is not built (SURVEY.md §8 f1 covers the HiFi-GAN / HiFi-CAR recipes: mel or multi-resolution STFT loss)")
         gp = config["generator_params"]
         self.use_ar = bool(gp.get("use_ar", False))
+        self.use_ph_loss = bool(gp.get("use_ph_loss", False))  # train.py:1735-1739: the generator's flag decides, criterion = F.cross_entropy
         self.G = HiFiGANGenerator(**gp, precision="f32").to(device).train()
         self.D = getattr(models, dtype_name)(**config["discriminator_params"]).to(device).train()  # train.py:1661-1668
         self.mel = MelSpectrogramLoss(**config["mel_loss_params"]) if config.get("use_mel_loss", False) else None
@@ -205,6 +206,8 @@ class Trainer:
         x = batch["x"].to(self.device, non_blocking=True)
         y = batch["y"].to(self.device, non_blocking=True)
         ar = batch["ar"].to(self.device, non_blocking=True) if self.use_ar else None
+        spk_id = batch["spk_id"].to(self.device, non_blocking=True) if "spk_id" in batch else None  # train.py:248-249
+        ph = batch["ph"].to(self.device, non_blocking=True) if "ph" in batch else None
         log = {}
         adv_on = self.steps > cfg["discriminator_train_start_steps"]
         disc_y = (torch.cat([ar, y], dim=2) if self.use_ar else y) if adv_on else None  # train.py:340-346 (the same tensor in both parts)
@@ -215,7 +218,9 @@ class Trainer:
         #      Generator      #
         #######################
         if self.steps > cfg.get("generator_train_start_steps", 0):
-            y_ = self.G(x, ar=ar)
+            y_ = self.G(x, spk_id=spk_id, ar=ar, ph=ph)
+            if self.use_ph_loss:
+                y_, ph_ = y_
             gen_loss = 0.0
             if self.stft is not None:  # train.py:288-297
                 sc_loss, mag_loss = self.stft(y_, y)
@@ -227,6 +232,10 @@ class Trainer:
                 gen_loss = gen_loss + mel_loss
                 log["train/mel_loss"] = mel_loss.detach()
             gen_loss = gen_loss * cfg.get("lambda_aux", 1.0)
+            if self.use_ph_loss:  # train.py:327-331: frame-rate phoneme logits (B, num_ph, T) against the phoneme indices
+                ph_loss = torch.nn.functional.cross_entropy(ph_, ph.long())
+                gen_loss = gen_loss + cfg["lambda_ph"] * ph_loss
+                log["train/ph_loss"] = ph_loss.detach()
             if adv_on:
                 disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
                 use_fm = cfg.get("use_feat_match_loss", False)
@@ -252,7 +261,9 @@ class Trainer:
         #######################
         if adv_on:
             with torch.no_grad():
-                y_ = self.G(x, ar=ar)  # re-compute y_ (train.py:389-400): a training-mode forward without a graph
+                y_ = self.G(x, spk_id=spk_id, ar=ar, ph=ph)  # re-compute y_ (train.py:389-400): a training-mode forward without a graph
+                if self.use_ph_loss:
+                    y_, _ = y_
             disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
             dis_loss, real_loss, fake_loss = self.D.discriminator_loss(disc_y_, disc_y, loss_type=da.get("loss_type", "mse"),
                                                                        average_by_discriminators=da.get("average_by_discriminators", True))
@@ -283,7 +294,11 @@ class Trainer:
         ar = batch["ar"].to(self.device, non_blocking=True) if self.use_ar else None
         ga, da, fm = cfg.get("generator_adv_loss_params", {}), cfg.get("discriminator_adv_loss_params", {}), cfg.get("feat_match_loss_params", {})
         log = {}
-        y_ = self.G(x, ar=ar)
+        spk_id = batch["spk_id"].to(self.device, non_blocking=True) if "spk_id" in batch else None
+        ph = batch["ph"].to(self.device, non_blocking=True) if "ph" in batch else None
+        y_ = self.G(x, spk_id=spk_id, ar=ar, ph=ph)
+        if self.use_ph_loss:
+            y_, ph_ = y_
         aux_loss = 0.0
         if self.stft is not None:
             sc_loss, mag_loss = self.stft(y_, y)
@@ -294,6 +309,10 @@ class Trainer:
             aux_loss = aux_loss + mel_loss
             log["eval/mel_loss"] = mel_loss
         aux_loss = aux_loss * cfg.get("lambda_aux", 1.0)
+        if self.use_ph_loss:  # train.py:551-553
+            ph_loss = torch.nn.functional.cross_entropy(ph_, ph.long())
+            aux_loss = aux_loss + cfg["lambda_ph"] * ph_loss
+            log["eval/ph_loss"] = ph_loss
         disc_y = torch.cat([ar, y], dim=2) if self.use_ar else y
         disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
         use_fm = cfg.get("use_feat_match_loss", False)

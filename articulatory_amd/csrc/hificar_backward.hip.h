@@ -737,6 +737,166 @@ __global__ __launch_bounds__(256) void xin_grad_kernel(const XinGradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Conditioning branches, backward (hifigan.py:176-189, 212-220, 232-237).
+//   speaker:  c = c + spk_fc(spk_emb_mat[spk_id]).unsqueeze(2) on the first `ch` (= feature + AR) channels
+//     cond_spk_colsum : dspk[b, ch] = sum_t dxin[b, t, ch]
+//     cond_spk_bwd    : d spk_fc.bias[ch] = sum_b dspk;  d spk_fc.weight[ch, e] = sum_b dspk[b, ch] * emb[id[b], e];
+//                       d spk_emb_mat[s, e] = sum_{b: id[b] == s} sum_ch dspk[b, ch] * W[ch, e]          (fixed summation orders)
+//   phoneme:  channels [ph_off, ph_off + ph_e) of frame t hold ph_emb_mat[ph[b, t]]
+//     cond_ph_emb_bwd : d ph_emb_mat[s, e] = sum_{(b, t): ph[b, t] == s} dxin[b, t, ph_off + e]
+//   phoneme-loss head: ph_out[b, q, f] = (1 / 2hop) * sum_{t in window(f)} (ph_fc.weight[q, :] . m[b, t, :] + bias[q]), m = last stage's MRF mean,
+//   window(f) = [f hop - hop / 2, f hop + 3 hop / 2) clipped to the sequence (AvgPool1d(2 hop, hop, hop / 2), zero padding counted)
+//     ph_head_bwd     : per (f, b): g[q] = dph_out[b, q, f] / 2hop;  dwin[b, f, c] = sum_q W[q, c] g[q];
+//                       partial[(b, f)][q * C + c] = g[q] * windowsum(m)[c];  partial[(b, f)][num_ph * C + q] = g[q] * |window|
+//     ph_dm_add       : dm[b, t, c] += (dwin[b, f_hi, c] + dwin[b, f_hi - 1, c]) / nin,  f_hi = (t + hop / 2) / hop   (the two windows holding t)
+// ------------------------------------------------------------------------------------------------
+struct CondBwdParams {
+    const float* dxin;  // (B, T, cin_pad)
+    int B, T, cin_pad;
+    const int* spk_id;  // (B)
+    const float* spk_emb;  // (num_spk, spk_e)
+    const float* spk_w;    // (ch, spk_e)
+    int spk_e, ch, num_spk;
+    float* dspk;        // (B, ch) scratch
+    float* d_spk_emb;
+    float* d_spk_w;
+    float* d_spk_b;
+    const int* ph;      // (B, T)
+    int ph_e, ph_off, num_ph;
+    float* d_ph_emb;    // (num_ph, ph_e)
+};
+
+__global__ __launch_bounds__(256) void cond_spk_colsum_kernel(const CondBwdParams p) {
+    const int b = blockIdx.x;
+    const float* src = p.dxin + (size_t)b * p.T * p.cin_pad;
+    for (int ch = threadIdx.x; ch < p.ch; ch += 256) {
+        float s = 0.f;
+        for (int t = 0; t < p.T; ++t) s += src[(size_t)t * p.cin_pad + ch];
+        p.dspk[(size_t)b * p.ch + ch] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void cond_spk_bwd_kernel(const CondBwdParams p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < p.ch) {  // spk_fc: row `ch` of the weight and its bias element
+        float sb = 0.f;
+        for (int b = 0; b < p.B; ++b) sb += p.dspk[(size_t)b * p.ch + i];
+        p.d_spk_b[i] = sb;
+        for (int e = 0; e < p.spk_e; ++e) {
+            float s = 0.f;
+            for (int b = 0; b < p.B; ++b) s = fmaf(p.dspk[(size_t)b * p.ch + i], p.spk_emb[(size_t)p.spk_id[b] * p.spk_e + e], s);
+            p.d_spk_w[(size_t)i * p.spk_e + e] = s;
+        }
+    }
+    const int j = i - ((p.ch + 255) / 256) * 256;  // the workgroups after those: one thread per embedding element
+    if (j >= 0 && j < p.num_spk * p.spk_e) {
+        const int sidx = j / p.spk_e, e = j - sidx * p.spk_e;
+        float s = 0.f;
+        for (int b = 0; b < p.B; ++b) {
+            if (p.spk_id[b] != sidx) continue;
+            float sv = 0.f;
+            for (int ch = 0; ch < p.ch; ++ch) sv = fmaf(p.dspk[(size_t)b * p.ch + ch], p.spk_w[(size_t)ch * p.spk_e + e], sv);
+            s += sv;
+        }
+        p.d_spk_emb[j] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void cond_ph_emb_bwd_kernel(const CondBwdParams p) {
+    // workgroup = one phoneme; thread (strand, e): strands split the (b, t) positions, combined in a fixed order
+    __shared__ float red[256];
+    const int sidx = blockIdx.x;
+    const int e = threadIdx.x % p.ph_e, strand = threadIdx.x / p.ph_e, nstrands = 256 / p.ph_e;
+    float s = 0.f;
+    if (strand < nstrands)
+        for (int i = strand; i < p.B * p.T; i += nstrands)
+            if (p.ph[i] == sidx) s += p.dxin[(size_t)i * p.cin_pad + p.ph_off + e];
+    red[threadIdx.x] = strand < nstrands ? s : 0.f;
+    __syncthreads();
+    if (threadIdx.x < p.ph_e) {
+        float t = 0.f;
+        for (int q = 0; q < nstrands; ++q) t += red[q * p.ph_e + threadIdx.x];
+        p.d_ph_emb[(size_t)sidx * p.ph_e + threadIdx.x] = t;
+    }
+}
+
+struct PhHeadBwdParams {
+    const float* x0;
+    const float* x1;
+    const float* x2;
+    int nin;
+    const float* w;        // ph_fc.weight (num_ph, C)
+    const float* dph_out;  // (B, num_ph, T)
+    float* dwin;           // (B, T, Cp)
+    float* partial;        // [B * T][num_ph * (C + 1)]
+    float* dm;             // (B, L, Cp): accumulated into
+    int C, Cp, L, T, hop, num_ph;
+};
+
+__global__ __launch_bounds__(256) void ph_head_bwd_kernel(const PhHeadBwdParams p) {
+    __shared__ float part[8][128];
+    __shared__ float wsum[128];
+    __shared__ float g[256];
+    const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int t0 = f * p.hop - p.hop / 2, K = 2 * p.hop;
+    const int lo = max(t0, 0), hi = min(t0 + K, p.L);
+    const int ch = tid & 31, rs = tid >> 5;
+    for (int c0 = 0; c0 < p.C; c0 += 32) {  // the window's sum of the MRF mean, summed exactly as ph_head_kernel does
+        float s = 0.f;
+        if (c0 + ch < p.C)
+            for (int t = lo + rs; t < hi; t += 8) {
+                const size_t off = ((size_t)b * p.L + t) * p.Cp + c0 + ch;
+                float v = p.x0[off];
+                if (p.nin == 2) v = (v + p.x1[off]) / 2.0f;
+                else if (p.nin == 3) v = ((v + p.x1[off]) + p.x2[off]) / 3.0f;
+                s += v;
+            }
+        part[rs][c0 + ch] = s;
+    }
+    for (int q = tid; q < p.num_ph; q += 256) g[q] = p.dph_out[((size_t)b * p.num_ph + q) * p.T + f] / (float)K;
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        float s = 0.f;
+        for (int r = 0; r < 8; ++r) s += part[r][c];
+        wsum[c] = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < p.Cp; c += 256) {
+        float s = 0.f;
+        if (c < p.C)
+            for (int q = 0; q < p.num_ph; ++q) s = fmaf(p.w[(size_t)q * p.C + c], g[q], s);
+        p.dwin[((size_t)b * p.T + f) * p.Cp + c] = s;
+    }
+    float* dst = p.partial + ((size_t)b * p.T + f) * ((size_t)p.num_ph * (p.C + 1));
+    for (int i = tid; i < p.num_ph * p.C; i += 256) {
+        const int q = i / p.C, c = i - q * p.C;
+        dst[i] = g[q] * wsum[c];
+    }
+    for (int q = tid; q < p.num_ph; q += 256) dst[p.num_ph * p.C + q] = g[q] * (float)(hi - lo);
+}
+
+__global__ __launch_bounds__(256) void ph_dm_add_kernel(const PhHeadBwdParams p) {
+    const int c4n = p.Cp >> 2;
+    const long long total = (long long)p.L * c4n;
+    const int b = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i / c4n), c = (int)(i - (long long)t * c4n) * 4;
+        const int fh = (t + p.hop / 2) / p.hop;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (fh - 1 >= 0 && fh - 1 < p.T) a = *reinterpret_cast<const f32x4*>(p.dwin + ((size_t)b * p.T + fh - 1) * p.Cp + c);
+        if (fh < p.T) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.dwin + ((size_t)b * p.T + fh) * p.Cp + c);
+            a = a + v;
+        }
+        f32x4* d = reinterpret_cast<f32x4*>(p.dm + ((size_t)b * p.L + t) * p.Cp + c);
+        f32x4 o = *d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += a[e] / (float)p.nin;
+        *d = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PastFCEncoder backward (pytorch_layers.py:438-460): h0 = ar, h_{l+1} = lrelu_0.1(W_l h_l + b_l) for l < 4, feat = W_4 h_4 + b_4.
 //   mlp_bwd_delta : one workgroup per utterance: delta_4 = dfeat; delta_{l-1} = (W_l^T delta_l) * lrelu'(h_l); also dar = W_0^T delta_0
 //   mlp_bwd_weight: dW_l[o, i] = sum_b delta_l[b, o] * h_l[b, i];  db_l[o] = sum_b delta_l[b, o]

@@ -123,14 +123,16 @@ def _send_parameters(module, names, tensors, stream):
 
 
 class _GeneratorFunction(torch.autograd.Function):
-    """Autograd node of the native generator: forward = hificar_forward_train (keeps a tape), backward = hificar_backward.
+    """Autograd node of the native generator: forward = hificar_forward_train_cond (keeps a tape), backward = hificar_backward_cond.
 
-    Inputs after (module, c, ar, names) are the module's RAW parameters (weight_g / weight_v of the weight-normed convs,
-    hifigan.py:268-278; plain weights; biases): the fold w = g v / ||v||, every convolution, activation and the PastFCEncoder —
-    forward and backward, including the weight norm's chain rule — run in libhificar."""
+    Inputs after (module, c, ar, spk_id, ph, names) are the module's RAW parameters (weight_g / weight_v of the weight-normed convs,
+    hifigan.py:268-278; plain weights; biases; the speaker / phoneme embeddings and Linear layers of the conditioned variants,
+    hifigan.py:176-189): the fold w = g v / ||v||, every convolution, activation, the PastFCEncoder and the conditioning branches —
+    forward and backward, including the weight norm's chain rule — run in libhificar.  Returns the waveform, or (waveform, ph_out)
+    for a use_ph_loss model (hifigan.py:232-237)."""
 
     @staticmethod
-    def forward(ctx, module, c, ar, names, *params):
+    def forward(ctx, module, c, ar, spk_id, ph, names, *params):
         lib, handle = module._lib, module._handle
         B, _, T = c.shape
         dev = c.device
@@ -140,9 +142,12 @@ class _GeneratorFunction(torch.autograd.Function):
             tape = torch.empty(lib.hificar_tape_bytes(handle, B, T) + 256, dtype=torch.uint8, device=dev)
             toff = (-tape.data_ptr()) % 256
             out = torch.empty((B, 1, T * module.hop), dtype=torch.float32, device=dev)
+            ph_out = torch.empty((B, module._params["num_ph"], T), dtype=torch.float32, device=dev) if module.use_ph_loss else None
             ws_ptr, ws_bytes = module._workspace(B, T)
-            rc = lib.hificar_forward_train(handle, c.data_ptr(), ar.data_ptr() if ar is not None else None, out.data_ptr(), B, T,
-                                           ws_ptr, ws_bytes, tape.data_ptr() + toff, tape.numel() - toff, stream)
+            rc = lib.hificar_forward_train_cond(handle, c.data_ptr(), ar.data_ptr() if ar is not None else None,
+                                                spk_id.data_ptr() if spk_id is not None else None, ph.data_ptr() if ph is not None else None,
+                                                out.data_ptr(), ph_out.data_ptr() if ph_out is not None else None, B, T,
+                                                ws_ptr, ws_bytes, tape.data_ptr() + toff, tape.numel() - toff, stream)
         _native.check(rc, "hificar_forward_train")
         ctx.module, ctx.names, ctx.tape, ctx.toff, ctx.BT = module, names, tape, toff, (B, T)
         ctx.shapes = [tuple(w.shape) for w in params]
@@ -150,11 +155,12 @@ class _GeneratorFunction(torch.autograd.Function):
         ctx.versions = [p._version for p in params]
         ctx.params = params
         ctx.has_ar = ar is not None
+        ctx.cond = (spk_id, ph)  # the backward reads the same indices again (integer tensors: nothing to differentiate)
         ctx.save_for_backward(out)
-        return out
+        return out if ph_out is None else (out, ph_out)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dph_out=None):
         module = ctx.module
         lib, handle = module._lib, module._handle
         (out,) = ctx.saved_tensors
@@ -164,9 +170,11 @@ class _GeneratorFunction(torch.autograd.Function):
         if any(t._version != v for t, v in zip(ctx.params, ctx.versions)):
             raise RuntimeError("a generator parameter was modified in place between forward and backward (the weight norm's "
                                "gradient reads weight_g / weight_v)")
-        dout = dout.to(torch.float32).contiguous()
+        dout = (torch.zeros_like(out) if dout is None else dout).to(torch.float32).contiguous()
+        dph_out = dph_out.to(torch.float32).contiguous() if dph_out is not None else None
+        spk_id, ph = ctx.cond
         need_c, need_ar = ctx.needs_input_grad[1], ctx.has_ar and ctx.needs_input_grad[2]
-        cf = p["in_channels"] - (p["ar_output"] if module.use_ar else 0)
+        cf = p["in_channels"] - (p["ar_output"] if module.use_ar else 0) - (p["ph_emb_size"] if module.use_ph else 0)
         dc = torch.empty((B, cf, T), dtype=torch.float32, device=dev) if need_c else None
         dar = torch.empty((B, 1, p["ar_input"]), dtype=torch.float32, device=dev) if need_ar else None
         with torch.cuda.device(dev):
@@ -174,9 +182,11 @@ class _GeneratorFunction(torch.autograd.Function):
             ws = torch.empty(lib.hificar_backward_workspace_bytes(handle, B, T) + 256, dtype=torch.uint8, device=dev)
             woff = (-ws.data_ptr()) % 256
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            rc = lib.hificar_backward(handle, dout.data_ptr(), out.data_ptr(), B, T, ctx.tape.data_ptr() + ctx.toff,
-                                      ctx.tape.numel() - ctx.toff, grads.data_ptr(), dc.data_ptr() if dc is not None else None,
-                                      dar.data_ptr() if dar is not None else None, ws.data_ptr() + woff, ws.numel() - woff, stream)
+            rc = lib.hificar_backward_cond(handle, dout.data_ptr(), dph_out.data_ptr() if dph_out is not None else None, out.data_ptr(),
+                                           spk_id.data_ptr() if spk_id is not None else None, ph.data_ptr() if ph is not None else None,
+                                           B, T, ctx.tape.data_ptr() + ctx.toff, ctx.tape.numel() - ctx.toff, grads.data_ptr(),
+                                           dc.data_ptr() if dc is not None else None, dar.data_ptr() if dar is not None else None,
+                                           ws.data_ptr() + woff, ws.numel() - woff, stream)
             _native.check(rc, "hificar_backward")
             raw = torch.zeros(int(lib.hificar_raw_grad_floats(handle)), dtype=torch.float32, device=dev)
             _native.check(lib.hificar_weight_norm_backward(handle, grads.data_ptr(), raw.data_ptr(), stream), "hificar_weight_norm_backward")
@@ -194,8 +204,8 @@ class _GeneratorFunction(torch.autograd.Function):
             n = int(np.prod(shape))
             gw.append(raw[off:off + n].view(shape))
             off += (n + 3) & ~3
-        ctx.tape = ctx.held = ctx.params = None
-        return (None, dc, dar, None, *gw)
+        ctx.tape = ctx.held = ctx.params = ctx.cond = None
+        return (None, dc, dar, None, None, None, *gw)
 
 
 class HiFiGANGenerator(torch.nn.Module):
@@ -419,7 +429,7 @@ class HiFiGANGenerator(torch.nn.Module):
         if self._handle is not None:
             if getattr(self, "_param_sig", None) != self._param_signature():
                 # parameters were updated in place since the weights were handed over (optimizer.step(), p.data.copy_): re-send them
-                if self.precision == "f32" and not (self.use_spk_id or self.use_ph or self.use_ph_loss):
+                if self.precision == "f32":
                     names, tensors = self._raw_parameters()
                     dev = self._device()
                     with torch.no_grad(), torch.cuda.device(dev):
@@ -559,6 +569,8 @@ class HiFiGANGenerator(torch.nn.Module):
                         yield m._parameters.get("weight")
                     if m.bias is not None:
                         yield m.bias
+                elif isinstance(m, torch.nn.Embedding):
+                    yield m.weight
                 else:
                     yield m.weight
                     yield m.bias
@@ -573,20 +585,21 @@ class HiFiGANGenerator(torch.nn.Module):
             elif isinstance(m, torch.nn.Linear):
                 mods.append(m)
                 names += [name + ".weight", name + ".bias"]
+            elif isinstance(m, torch.nn.Embedding):
+                mods.append(m)
+                names.append(name + ".weight")
         tensors = list(current())
         self._raw_cache = (tuple(names), tensors, current)
         return self._raw_cache[0], tensors
 
-    def _forward_autograd(self, c, ar):
-        """Training-mode forward (train.py:276,398: y_ = generator(x, ar=ar) under autograd)."""
-        if self.use_spk_id or self.use_ph or self.use_ph_loss:
-            raise NotImplementedError("autograd through the speaker / phoneme conditioned generator is not built (SURVEY.md §8 f1)")
+    def _forward_autograd(self, c, ar, spk_id=None, ph=None):
+        """Training-mode forward (train.py:276,398: y_ = generator(x, spk_id=spk_id, ar=ar, ph=ph) under autograd)."""
         if self.precision != "f32":
             raise RuntimeError("training runs in the exact-fp32 arithmetic: construct with precision='f32'")
         if self._handle is None:
             self._native_handle()
         names, tensors = self._raw_parameters()
-        out = _GeneratorFunction.apply(self, c, ar, names, *tensors)
+        out = _GeneratorFunction.apply(self, c, ar, spk_id, ph, names, *tensors)
         self._param_sig = self._param_signature()  # the forward above handed the current weights over
         return out
 
@@ -644,7 +657,7 @@ class HiFiGANGenerator(torch.nn.Module):
                                         or (self.training and any(p.requires_grad for p in self.parameters()))):
             if lengths is not None:
                 raise NotImplementedError("autograd with ragged lengths is not built")
-            return self._forward_autograd(c, ar)
+            return self._forward_autograd(c, ar, spk_id if self.use_spk_id else None, ph if self.use_ph else None)
         handle = self._native_handle()
         if lengths is None:
             out = torch.empty((B, 1, T * self.hop), dtype=torch.float32, device=c.device)

@@ -193,7 +193,7 @@ int hificar_profile_end(hificar_handle* h, hificar_kernel_stat* stats, int max_s
  * Training: the generator half of the reference's train step (articulatory/bin/train.py:241-440: y_ = generator(x, ar=ar) under
  * autograd, gen_loss.backward()).  The reference has no native boundary here either (PyTorch autograd through torch.nn modules);
  * these entry points stand in for  HiFiGANGenerator.forward  in training mode and the autograd graph behind it.
- * Exact-fp32 arithmetic only.  The speaker / phoneme conditioned variants have no backward pass yet.
+ * Exact-fp32 arithmetic only.
  *
  *   hificar_set_weight_device  one FOLDED parameter (name / layout as hificar_set_weight) from DEVICE memory, repacked on the
  *                              device on `stream` — the weights of a model in training live on the device and change every step
@@ -213,6 +213,12 @@ int hificar_profile_end(hificar_handle* h, hificar_kernel_stat* stats, int max_s
  *                              at the offset hificar_grad_info reports, in the reference's folded layout), dc (B, C, T) gradient of
  *                              the features or NULL, dar (B, ar_input) gradient of the AR context or NULL.
  *                              workspace: hificar_backward_workspace_bytes(h, B, T) bytes.
+ *   hificar_forward_train_cond / hificar_backward_cond   the same pair for the conditioned generator (train.py:276 passes spk_id= / ph=
+ *                              under autograd; hifigan.py:176-189, 212-220, 232-237): spk_id (B) / ph (B, T) int32 as in
+ *                              hificar_forward_cond, ph_out (B, num_ph, T) the phoneme-loss head's output (use_ph_loss) or NULL; the
+ *                              backward takes the SAME spk_id / ph again and dph_out (B, num_ph, T), the gradient of ph_out (NULL: ph_out
+ *                              took no part in the loss).  `grads` then also holds spk_emb_mat.weight, spk_fc.{weight,bias},
+ *                              ph_emb_mat.weight, ph_fc.{weight,bias} (hificar_grad_info); hificar_set_parameters_device takes them too.
  * --------------------------------------------------------------------------------------------------------------------------- */
 int hificar_set_weight_device(hificar_handle* h, const char* name, const float* data, void* stream);
 int hificar_set_parameters_device(hificar_handle* h, const char* const* names, const float* const* data, int n, void* stream);
@@ -227,6 +233,11 @@ int hificar_grad_info(hificar_handle* h, int i, char* name96, int64_t* offset, i
 int64_t hificar_grad_floats(hificar_handle* h);
 int hificar_backward(hificar_handle* h, const float* dout, const float* out, int B, int T, const void* tape, size_t tape_bytes,
                      float* grads, float* dc, float* dar, void* workspace, size_t workspace_bytes, void* stream);
+int hificar_forward_train_cond(hificar_handle* h, const float* c, const float* ar, const int32_t* spk_id, const int32_t* ph, float* out,
+                               float* ph_out, int B, int T, void* workspace, size_t workspace_bytes, void* tape, size_t tape_bytes, void* stream);
+int hificar_backward_cond(hificar_handle* h, const float* dout, const float* dph_out, const float* out, const int32_t* spk_id,
+                          const int32_t* ph, int B, int T, const void* tape, size_t tape_bytes, float* grads, float* dc, float* dar,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* Parity aid: per-layer intermediates of the forwards that follow, copied into caller buffers in the reference's (B, C, L)
  * layout — what a forward hook on the reference's modules (articulatory/models/hifigan.py:221-231,

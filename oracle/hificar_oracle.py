@@ -230,11 +230,12 @@ def ar_loop_batched(w, params, x, batch_max_steps, hop_size):
 # --------------------------------------------------------------------------------------
 # training path: gradients (the generator half of articulatory/bin/train.py:276-440)
 # --------------------------------------------------------------------------------------
-def gradients(state_dict, params, c, ar, cot, dtype=torch.float32):
-    """d(sum(out * cot)) / d(every state_dict parameter, c, ar): the reference runs the generator under PyTorch autograd with weight
-    norm in the graph (w = v * g / ||v||, hifigan.py:268-278); the restatement differentiates ``generator_forward`` on weights folded
-    INSIDE the graph.  state_dict: reference-layout arrays (weight_g / weight_v / bias / Linear).  Returns
-    (out, {"c": .., "ar": .., state_dict key: ..})."""
+def gradients(state_dict, params, c, ar, cot, dtype=torch.float32, spk_id=None, ph=None, cot_ph=None):
+    """d(sum(out * cot) [+ sum(ph_out * cot_ph)]) / d(every state_dict parameter, c, ar): the reference runs the generator under PyTorch
+    autograd with weight norm in the graph (w = v * g / ||v||, hifigan.py:268-278); the restatement differentiates ``generator_forward``
+    on weights folded INSIDE the graph.  state_dict: reference-layout arrays (weight_g / weight_v / bias / Linear / Embedding).
+    spk_id / ph: the conditioning indices (use_spk_id / use_ph); cot_ph: cotangent of the phoneme-loss head's output (use_ph_loss).
+    Returns (out, {"c": .., "ar": .., state_dict key: ..}); out is the pair (out, ph_out) for a use_ph_loss model."""
     leaves = {k: torch.as_tensor(np.asarray(v)).to(dtype).clone().requires_grad_(True) for k, v in state_dict.items()}
     w = OrderedDict()
     for k, v in leaves.items():
@@ -249,13 +250,23 @@ def gradients(state_dict, params, c, ar, cot, dtype=torch.float32):
             w[k] = v
     c = torch.as_tensor(np.asarray(c)).to(dtype).clone().requires_grad_(True)
     ar_t = torch.as_tensor(np.asarray(ar)).to(dtype).clone().requires_grad_(True) if ar is not None else None
-    out = generator_forward(w, params, c, ar_t)
-    (out * torch.as_tensor(np.asarray(cot)).to(dtype)).sum().backward()
-    grads = {k: v.grad for k, v in leaves.items()}
+    spk_t = torch.as_tensor(np.asarray(spk_id)).long() if spk_id is not None else None
+    ph_t = torch.as_tensor(np.asarray(ph)).long() if ph is not None else None
+    out = generator_forward(w, params, c, ar_t, spk_id=spk_t, ph=ph_t)
+    if isinstance(out, tuple):
+        loss = (out[0] * torch.as_tensor(np.asarray(cot)).to(dtype)).sum()
+        if cot_ph is not None:
+            loss = loss + (out[1] * torch.as_tensor(np.asarray(cot_ph)).to(dtype)).sum()
+        out = (out[0].detach(), out[1].detach())
+    else:
+        loss = (out * torch.as_tensor(np.asarray(cot)).to(dtype)).sum()
+        out = out.detach()
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     grads["c"] = c.grad
     if ar_t is not None:
         grads["ar"] = ar_t.grad
-    return out.detach(), grads
+    return out, grads
 
 
 def check_packed(gold, name, arr, tol):

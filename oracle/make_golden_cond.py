@@ -62,6 +62,73 @@ def main():
     for fn in ("gold_fwd_spk.npz", "gold_fwd_ph.npz"):
         print(fn, os.path.getsize(os.path.join(outdir, fn)))
 
+    # (c) GRADIENTS of the conditioned variants under the reference's autograd, weight norm in the graph (train.py:276 passes spk_id= / ph=):
+    # loss = sum(out * cot) (+ sum(ph_out * cot_ph)); 2-stage width-128 generators (few activations: the script refuses a seed whose fp32 and
+    # fp64 reference gradients differ by more than 1e-4, i.e. one with an activation on a LeakyReLU kink — see oracle/make_golden_grad.py)
+    from articulatory_amd.utils.synth import uniform
+    from make_golden_grad import pack
+
+    small = dict(full, channels=128, upsample_scales=[5, 4], upsample_kernel_sizes=[10, 8])
+    cases = {
+        "spk": (dict(small, use_spk_id=True, num_spk=5, spk_emb_size=32), 3, 9),
+        "ph": (dict(small, in_channels=12 + 8, use_ar=False, use_ph=True, num_ph=11, ph_emb_size=8, use_ph_loss=True), 2, 11),
+        "ph_ar": (dict(small, in_channels=13 + 128 + 8, use_ph=True, num_ph=7, ph_emb_size=8, use_ph_loss=True), 2, 10),
+    }
+    for tag, (params, B, T) in cases.items():
+        hop = int(np.prod(params["upsample_scales"]))
+        dims = params["in_channels"] - (128 if params["use_ar"] else 0) - (params["ph_emb_size"] if params.get("use_ph") else 0)
+        for seed in range(870, 910):
+            sd = synth_state_dict(params, seed=seed)
+            c_np = synth_features(B, T, dims, seed=seed + 10).transpose(0, 2, 1).copy()
+            ar_np = (synth_features(B, 512, 1, seed=seed + 11)[:, :, 0] * 0.5 - 0.25).reshape(B, 1, 512).astype(np.float32) if params["use_ar"] else None
+            cot = uniform(seed + 12, "cotangent", (B, 1, hop * T), -1.0, 1.0)
+            kw_np = {}
+            if params.get("use_spk_id"):
+                kw_np["spk_id"] = np.random.Generator(np.random.PCG64(seed)).integers(0, params["num_spk"], size=(B,)).astype(np.int64)
+            if params.get("use_ph"):
+                kw_np["ph"] = np.random.Generator(np.random.PCG64(seed + 1)).integers(0, params["num_ph"], size=(B, T)).astype(np.int64)
+            cot_ph = uniform(seed + 13, "cot_ph", (B, params["num_ph"], T), -1.0, 1.0) if params.get("use_ph_loss") else None
+            res = {}
+            for dtype in (torch.float32, torch.float64):
+                g = ref_models.HiFiGANGenerator(**params)
+                g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+                g = g.to(dtype).train()
+                c = torch.from_numpy(c_np).to(dtype).requires_grad_(True)
+                ar = torch.from_numpy(ar_np).to(dtype).requires_grad_(True) if ar_np is not None else None
+                y = g(c, ar=ar, **{k: torch.from_numpy(v) for k, v in kw_np.items()})
+                if cot_ph is not None:
+                    y, ph_out = y
+                    loss = (y * torch.from_numpy(cot).to(dtype)).sum() + (ph_out * torch.from_numpy(cot_ph).to(dtype)).sum()
+                else:
+                    ph_out, loss = None, (y * torch.from_numpy(cot).to(dtype)).sum()
+                loss.backward()
+                gr = {k: p.grad.double().numpy() for k, p in g.named_parameters()}
+                gr["c"] = c.grad.double().numpy()
+                if ar is not None:
+                    gr["ar"] = ar.grad.double().numpy()
+                res[dtype] = (y.detach(), ph_out.detach() if ph_out is not None else None, gr)
+            worst = max(np.abs(res[torch.float32][2][k] - res[torch.float64][2][k]).max() / max(np.abs(res[torch.float64][2][k]).max(), 1e-30)
+                        for k in res[torch.float64][2])
+            if worst > 1e-4:
+                print(f"{tag}: seed {seed}: fp32 and fp64 reference gradients differ by {worst:.1e} (a LeakyReLU kink): next seed")
+                continue
+            y, ph_out, gr = res[torch.float32]
+            out = {"c": c_np, "cot": cot, "seed": np.array(seed), **kw_np}
+            if ar_np is not None:
+                out["ar"] = ar_np
+            if cot_ph is not None:
+                out["cot_ph"] = cot_ph
+                out["ph_out"] = ph_out.numpy()
+            pack("out", y.numpy(), out)
+            for k, v in gr.items():
+                pack("grad::" + k, v, out)
+            path = os.path.join(outdir, f"gold_grad_{tag}.npz")
+            np.savez_compressed(path, **out)
+            print(f"gold_grad_{tag}.npz", os.path.getsize(path), "seed", seed, f"fp32-vs-fp64 {worst:.1e}")
+            break
+        else:
+            raise SystemExit(f"{tag}: no kink-free seed found")
+
 
 if __name__ == "__main__":
     main()

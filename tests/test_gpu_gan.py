@@ -249,3 +249,38 @@ def test_train_cli_end_to_end_and_resume(tmp_path):
     assert state2["steps"] == 5
     k = next(iter(state["model"]["generator"]))
     assert not torch.equal(state["model"]["generator"][k], state2["model"]["generator"][k])
+
+
+def test_phoneme_conditioned_iteration_with_ph_loss_vs_oracle():
+    """A use_ph + use_ph_loss generator through Trainer.train_step (train.py:273-278, 327-331: y_, ph_ = generator(x, ph=ph);
+    gen_loss += lambda_ph * cross_entropy(ph_, ph)): the logged losses of the first iteration against the CPU oracle, and the
+    conditioning parameters move."""
+    config = make_config(True)
+    config["generator_params"] = dict(config["generator_params"], in_channels=13 + 128 + 8, use_ph=True, num_ph=9, ph_emb_size=8, use_ph_loss=True)
+    config["lambda_ph"] = 3.0
+    t = Trainer(config, torch.device("cuda:0"))
+    gp = config["generator_params"]
+    gsd = synth_state_dict(gp, seed=31)
+    dsd = synth_disc_state_dict(config["discriminator_params"], seed=32)
+    t.G.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()})
+    t.D.load_state_dict({k: torch.from_numpy(v) for k, v in dsd.items()})
+    data = SyntheticPairs(4, 60, 13, 20, seed=3)
+    batch = WindowCollater(400, 20, 512, np.random.default_rng(5))([data[i] for i in range(4)])
+    batch["ph"] = torch.from_numpy(np.random.default_rng(6).integers(0, 9, (4, 20)))
+    t.steps = 1
+    log = {k: float(v) for k, v in t.train_step(batch).items()}
+    with torch.no_grad():
+        y_, ph_ = O.generator_forward(O.fold_weight_norm(gsd), gp, batch["x"], batch["ar"], ph=batch["ph"])
+        mel = DO.mel_loss(y_, batch["y"], **config["mel_loss_params"])
+        ph_loss = torch.nn.functional.cross_entropy(ph_, batch["ph"])
+        dw = DO.fold_disc_weight_norm(dsd)
+        p_ = DO.disc_forward(dw, SMALL, torch.cat([batch["ar"], y_], 2))
+        p = DO.disc_forward(dw, SMALL, torch.cat([batch["ar"], batch["y"]], 2))
+        adv, fm = DO.gen_adv_loss(p_, False), DO.feat_match_loss(p_, p, False, False, False)
+    ref = {"train/mel_loss": float(mel), "train/ph_loss": float(ph_loss), "train/adversarial_loss": float(adv), "train/feature_matching_loss": float(fm),
+           "train/generator_loss": float(45.0 * mel + 3.0 * ph_loss + adv + 2.0 * fm)}
+    for k, v in ref.items():
+        assert abs(log[k] - v) < 1e-4 * max(abs(v), 1e-3), (k, log[k], v)
+    now = t.G.state_dict()
+    for k in ("ph_emb_mat.weight", "ph_fc.weight", "ph_fc.bias"):
+        assert not np.allclose(now[k].cpu().numpy(), gsd[k]), k

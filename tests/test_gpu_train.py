@@ -54,6 +54,41 @@ def test_gradients_vs_reference_golden(tag):
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
 
 
+@pytest.mark.parametrize("tag", ["spk", "ph", "ph_ar"])
+def test_conditioned_gradients_vs_reference_golden(tag):
+    """Autograd through the conditioned generator (train.py:276 passes spk_id= / ph= under autograd): the native node's
+    gradients of every parameter — spk_emb_mat / spk_fc (hifigan.py:176-178, 212-216), ph_emb_mat (:179-181, 217-220), ph_fc and the
+    ph_out cotangent path (:183-189, 232-237) included — and of c / ar, against the real reference (oracle/make_golden_cond.py, part c)."""
+    from test_oracle_golden import COND_GRAD_CASES
+
+    gold = np.load(os.path.join(GOLDEN, f"gold_grad_{tag}.npz"))
+    params = dict(E2W_PARAMS, **COND_GRAD_CASES[tag])
+    g, sd = build(params, int(gold["seed"]))
+    c = torch.from_numpy(gold["c"]).cuda().requires_grad_(True)
+    ar = torch.from_numpy(gold["ar"]).cuda().requires_grad_(True) if "ar" in gold.files else None
+    kw = {k: torch.from_numpy(gold[k]).cuda() for k in ("spk_id", "ph") if k in gold.files}
+    y = g(c, ar=ar, **kw)
+    loss = 0.0
+    if params.get("use_ph_loss"):
+        y, ph_out = y
+        assert rel_err(ph_out.detach().cpu().numpy(), gold["ph_out"]) < 2e-5
+        loss = (ph_out * torch.from_numpy(gold["cot_ph"]).cuda()).sum()
+    assert y.requires_grad and O.check_packed(gold, "out", y, 2e-5) < 2e-5
+    (loss + (y * torch.from_numpy(gold["cot"]).cuda()).sum()).backward()
+    worst = {}
+    for k, p in list(g.named_parameters()) + [("c", c)] + ([("ar", ar)] if ar is not None else []):
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+        worst[k] = O.check_packed(gold, "grad::" + k, p.grad, TOL)
+    assert any(k.startswith(("spk_", "ph_")) for k in worst)
+    bad = {k: v for k, v in worst.items() if v >= TOL}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    if params.get("use_ph_loss"):  # a loss without ph_out: the head's parameters get exact zeros, the rest still flows
+        g.zero_grad(set_to_none=True)
+        y2, _ = g(c.detach(), ar=ar.detach() if ar is not None else None, **kw)
+        (y2 * torch.from_numpy(gold["cot"]).cuda()).sum().backward()
+        assert float(g.ph_fc.weight.grad.abs().max()) == 0.0 and float(g.input_conv.weight_v.grad.abs().max()) > 0.0
+
+
 def test_full_model_real_slope_vs_fp64_oracle():
     """The full e2w_hifigan.yaml generator with its real slope 0.1, B = 2, T = 25, against the oracle's autograd in FLOAT64.
     LeakyReLU makes gradients discontinuous where a pre-activation is within rounding distance of zero; with ~10^7 activations some

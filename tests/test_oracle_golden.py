@@ -231,3 +231,30 @@ def test_oracle_gradients_vs_reference(tag):
     worst = max(O.check_packed(gold, "grad::" + k, v, 1e-4) for k, v in grads.items())
     assert len(grads) == len(sd) + 2
     assert worst < 2e-4, worst
+
+
+_SMALL2 = dict(channels=128, upsample_scales=[5, 4], upsample_kernel_sizes=[10, 8])
+COND_GRAD_CASES = {
+    "spk": dict(_SMALL2, use_spk_id=True, num_spk=5, spk_emb_size=32),
+    "ph": dict(_SMALL2, in_channels=12 + 8, use_ar=False, use_ph=True, num_ph=11, ph_emb_size=8, use_ph_loss=True),
+    "ph_ar": dict(_SMALL2, in_channels=13 + 128 + 8, use_ph=True, num_ph=7, ph_emb_size=8, use_ph_loss=True),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(COND_GRAD_CASES))
+def test_oracle_conditioned_gradients_vs_reference(tag):
+    """Autograd through the speaker / phoneme conditioned generator and the phoneme-loss head (train.py:276 passes spk_id= / ph= under
+    autograd; hifigan.py:176-189, 212-220, 232-237): gradients of every parameter — spk_emb_mat, spk_fc, ph_emb_mat, ph_fc included — and of
+    c / ar against the real reference (oracle/make_golden_cond.py, part c)."""
+    gold = np.load(os.path.join(GOLDEN, f"gold_grad_{tag}.npz"))
+    params = dict(E2W_PARAMS, **COND_GRAD_CASES[tag])
+    sd = synth_state_dict(params, seed=int(gold["seed"]))
+    kw = {k: gold[k] for k in ("spk_id", "ph", "cot_ph") if k in gold.files}
+    out, grads = O.gradients(sd, params, gold["c"], gold["ar"] if "ar" in gold.files else None, gold["cot"], **kw)
+    if isinstance(out, tuple):
+        assert rel_err(out[1].numpy(), gold["ph_out"]) < 2e-6
+        out = out[0]
+    assert O.check_packed(gold, "out", out, 1e-5) < 1e-5
+    assert sorted(grads) == sorted(k[6:].rsplit("::", 1)[0] for k in gold.files if k.startswith("grad::") and k.endswith(("::full", "::sum")))
+    worst = max(O.check_packed(gold, "grad::" + k, v, 1e-4) for k, v in grads.items())
+    assert worst < 2e-4, worst
