@@ -76,6 +76,15 @@ SYMBOLS = (
     "hificar_backward",
     "hificar_forward_train_cond",
     "hificar_backward_cond",
+    "hificar_grad_bucket_count",
+    "hificar_raw_param_bucket",
+    "hificar_set_bucket_callback",
+    "hificar_weight_norm_backward_bucket",
+    "hificar_disc_grad_bucket_count",
+    "hificar_disc_raw_param_bucket",
+    "hificar_disc_bucket_folded_range",
+    "hificar_disc_set_bucket_callback",
+    "hificar_disc_weight_norm_backward_bucket",
     "hificar_destroy",
     "hificar_last_error",
     "hificar_version",
@@ -185,6 +194,10 @@ class HificarDiscOutput(ctypes.Structure):
         ("pitch", ctypes.c_int32),
         ("channels", ctypes.c_int32),
     ]
+
+
+# hificar_bucket_fn (include/hificar.h): void (*)(int bucket, void* stream, void* user)
+BUCKET_FN = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 
 
 class HificarKernelStat(ctypes.Structure):
@@ -322,6 +335,24 @@ def load_library():
     lib.hificar_forward_train_cond.restype = ctypes.c_int
     lib.hificar_backward_cond.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.hificar_backward_cond.restype = ctypes.c_int
+    lib.hificar_grad_bucket_count.argtypes = [vp]
+    lib.hificar_grad_bucket_count.restype = ctypes.c_int
+    lib.hificar_raw_param_bucket.argtypes = [vp, ctypes.c_int]
+    lib.hificar_raw_param_bucket.restype = ctypes.c_int
+    lib.hificar_set_bucket_callback.argtypes = [vp, BUCKET_FN, vp]
+    lib.hificar_set_bucket_callback.restype = ctypes.c_int
+    lib.hificar_weight_norm_backward_bucket.argtypes = [vp, vp, vp, ctypes.c_int, vp]
+    lib.hificar_weight_norm_backward_bucket.restype = ctypes.c_int
+    lib.hificar_disc_grad_bucket_count.argtypes = [vp]
+    lib.hificar_disc_grad_bucket_count.restype = ctypes.c_int
+    lib.hificar_disc_raw_param_bucket.argtypes = [vp, ctypes.c_int]
+    lib.hificar_disc_raw_param_bucket.restype = ctypes.c_int
+    lib.hificar_disc_bucket_folded_range.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    lib.hificar_disc_bucket_folded_range.restype = ctypes.c_int
+    lib.hificar_disc_set_bucket_callback.argtypes = [vp, BUCKET_FN, vp]
+    lib.hificar_disc_set_bucket_callback.restype = ctypes.c_int
+    lib.hificar_disc_weight_norm_backward_bucket.argtypes = [vp, vp, vp, ctypes.c_int, vp]
+    lib.hificar_disc_weight_norm_backward_bucket.restype = ctypes.c_int
     lib.hificar_destroy.argtypes = [vp]
     lib.hificar_destroy.restype = None
     lib.hificar_last_error.argtypes = []

@@ -1119,11 +1119,13 @@ __global__ __launch_bounds__(256) void param_gather_kernel(const ParamJob* jobs,
     for (int c = threadIdx.x; c < q.cols; c += 256) dst[(size_t)r * q.cols + c] = v[c] * sc;
 }
 
-__global__ __launch_bounds__(256) void wn_backward_kernel(const ParamJob* jobs, const int* start, int njobs, const float* grads, float* raw) {
+// (wg0: first workgroup of the table this launch covers — a bucket of jobs launches start[lo] .. start[hi] - 1 only)
+__global__ __launch_bounds__(256) void wn_backward_kernel(const ParamJob* jobs, const int* start, int njobs, const float* grads, float* raw, int wg0) {
     __shared__ float red[4];
-    const int j = find_job(start, njobs, blockIdx.x);
+    const int wg = (int)blockIdx.x + wg0;
+    const int j = find_job(start, njobs, wg);
     const ParamJob q = jobs[j];
-    const int r = blockIdx.x - start[j];
+    const int r = wg - start[j];
     const float* dw = grads + q.dst;
     if (!q.g) {
         const int i = r * 1024 + threadIdx.x;

@@ -251,24 +251,56 @@ class _DiscriminatorLossFunction(torch.autograd.Function):
             wsb = int(lib.hificar_disc_backward_workspace_bytes(handle, B, T))
             ws, woff = _aligned(wsb // 4, dev)
             nfold = int(lib.hificar_disc_grad_floats(handle))
-            folded = []
+            raw = torch.zeros(int(lib.hificar_disc_raw_grad_floats(handle)), dtype=torch.float32, device=dev)
+            folded, reducer, cb, errors = [], None, None, []
             for mode, ps, (d, doff) in zip((1, 2), ctx.passes, ctx.douts):
                 g = torch.zeros(nfold, dtype=torch.float32, device=dev)
-                rc = lib.hificar_disc_backward_flat(handle, d.data_ptr() + 4 * doff, mode, 0, 0, B, T, ps.ptr, ps.nbytes, g.data_ptr(), None,
-                                                    ws.data_ptr() + 4 * woff, wsb, stream)
-                _native.check(rc, "hificar_disc_backward_flat")
                 folded.append(g)
-            grads = folded[0].add_(folded[1])
-            raw = torch.zeros(int(lib.hificar_disc_raw_grad_floats(handle)), dtype=torch.float32, device=dev)
-            _native.check(lib.hificar_disc_weight_norm_backward(handle, grads.data_ptr(), raw.data_ptr(), stream), "hificar_disc_weight_norm_backward")
-            raw.mul_(g_total)
-            if module._grad_sync is not None:
-                import torch.distributed as dist
+                if mode == 2 and module._grad_sync is not None:
+                    # data-parallel training: one gradient bucket per sub-discriminator.  During the SECOND pass libhificar calls back as
+                    # each sub-network's gradients are enqueued on its side stream: there the first pass's share is added, the weight-norm
+                    # chain rule runs, and the bucket's all-reduce (RCCL over xGMI) starts while the other sub-networks still compute.
+                    from ..utils.buckets import BucketReducer, bucket_ranges
 
-                group, average = module._grad_sync
-                dist.all_reduce(raw, group=group)
-                if average:
-                    raw.div_(dist.get_world_size(group))
+                    group, average = module._grad_sync
+                    nb = int(lib.hificar_disc_grad_bucket_count(handle))
+                    ids = [int(lib.hificar_disc_raw_param_bucket(handle, i)) for i in range(len(ctx.shapes))]
+                    ranges, total = bucket_ranges(ids, [int(np.prod(sh)) for sh in ctx.shapes], nb)
+                    assert total == raw.numel()
+                    reducer = BucketReducer(raw, ranges, group, average)
+                    g_fake, g_real = folded
+
+                    def on_bucket(bucket, bstream, _user):
+                        try:
+                            o, n = ctypes.c_int64(), ctypes.c_int64()
+                            _native.check(lib.hificar_disc_bucket_folded_range(handle, bucket, ctypes.byref(o), ctypes.byref(n)), "hificar_disc_bucket_folded_range")
+                            with torch.cuda.stream(torch.cuda.ExternalStream(bstream, device=dev)):
+                                g_real[o.value:o.value + n.value].add_(g_fake[o.value:o.value + n.value])
+                                _native.check(lib.hificar_disc_weight_norm_backward_bucket(handle, g_real.data_ptr(), raw.data_ptr(), bucket,
+                                                                                           ctypes.c_void_p(bstream)), "hificar_disc_weight_norm_backward_bucket")
+                                for off_, n_ in ranges[bucket]:
+                                    raw[off_:off_ + n_].mul_(g_total)
+                                reducer.reduce(bucket)
+                        except BaseException as e:  # an exception must not cross the C frames: re-raised below
+                            errors.append(e)
+
+                    cb = _native.BUCKET_FN(on_bucket)
+                    _native.check(lib.hificar_disc_set_bucket_callback(handle, cb, None), "hificar_disc_set_bucket_callback")
+                try:
+                    rc = lib.hificar_disc_backward_flat(handle, d.data_ptr() + 4 * doff, mode, 0, 0, B, T, ps.ptr, ps.nbytes, g.data_ptr(), None,
+                                                        ws.data_ptr() + 4 * woff, wsb, stream)
+                finally:
+                    if cb is not None:
+                        lib.hificar_disc_set_bucket_callback(handle, _native.BUCKET_FN(), None)
+                _native.check(rc, "hificar_disc_backward_flat")
+                if errors:
+                    raise errors[0]
+            if reducer is not None:
+                reducer.finish()
+            else:
+                grads = folded[0].add_(folded[1])
+                _native.check(lib.hificar_disc_weight_norm_backward(handle, grads.data_ptr(), raw.data_ptr(), stream), "hificar_disc_weight_norm_backward")
+                raw.mul_(g_total)
         gw, off = [], 0
         for shape in ctx.shapes:
             n = int(np.prod(shape))

@@ -182,23 +182,48 @@ class _GeneratorFunction(torch.autograd.Function):
             ws = torch.empty(lib.hificar_backward_workspace_bytes(handle, B, T) + 256, dtype=torch.uint8, device=dev)
             woff = (-ws.data_ptr()) % 256
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            rc = lib.hificar_backward_cond(handle, dout.data_ptr(), dph_out.data_ptr() if dph_out is not None else None, out.data_ptr(),
-                                           spk_id.data_ptr() if spk_id is not None else None, ph.data_ptr() if ph is not None else None,
-                                           B, T, ctx.tape.data_ptr() + ctx.toff, ctx.tape.numel() - ctx.toff, grads.data_ptr(),
-                                           dc.data_ptr() if dc is not None else None, dar.data_ptr() if dar is not None else None,
-                                           ws.data_ptr() + woff, ws.numel() - woff, stream)
-            _native.check(rc, "hificar_backward")
             raw = torch.zeros(int(lib.hificar_raw_grad_floats(handle)), dtype=torch.float32, device=dev)
-            _native.check(lib.hificar_weight_norm_backward(handle, grads.data_ptr(), raw.data_ptr(), stream), "hificar_weight_norm_backward")
-        if module._grad_sync is not None:
-            # data-parallel training: ONE all-reduce (RCCL over xGMI under the "nccl" backend) of the flat buffer that holds every
-            # parameter's gradient — the whole generator is a single 54-MB bucket.
-            import torch.distributed as dist
+            reducer = cb = None
+            errors = []
+            if module._grad_sync is not None:
+                # data-parallel training: the gradients are all-reduced bucket by bucket (RCCL over xGMI under the "nccl" backend) WHILE
+                # the backward pass still runs — libhificar calls back when a bucket's gradient kernels are enqueued (last stage first),
+                # the bucket's weight-norm chain rule runs right behind them and its collective starts on the communication stream
+                from ..utils.buckets import BucketReducer, bucket_ranges
 
-            group, average = module._grad_sync
-            dist.all_reduce(raw, group=group)
-            if average:
-                raw.div_(dist.get_world_size(group))
+                group, average = module._grad_sync
+                nb = int(lib.hificar_grad_bucket_count(handle))
+                ids = [int(lib.hificar_raw_param_bucket(handle, i)) for i in range(len(ctx.shapes))]
+                ranges, total = bucket_ranges(ids, [int(np.prod(sh)) for sh in ctx.shapes], nb)
+                assert total == raw.numel()
+                reducer = BucketReducer(raw, ranges, group, average)
+
+                def on_bucket(bucket, bstream, _user):
+                    try:
+                        _native.check(lib.hificar_weight_norm_backward_bucket(handle, grads.data_ptr(), raw.data_ptr(), bucket, ctypes.c_void_p(bstream)),
+                                      "hificar_weight_norm_backward_bucket")
+                        reducer.reduce(bucket)  # (bstream is the current stream: the collective waits for what is enqueued so far)
+                    except BaseException as e:  # an exception must not cross the C frames: re-raised below
+                        errors.append(e)
+
+                cb = _native.BUCKET_FN(on_bucket)
+                _native.check(lib.hificar_set_bucket_callback(handle, cb, None), "hificar_set_bucket_callback")
+            try:
+                rc = lib.hificar_backward_cond(handle, dout.data_ptr(), dph_out.data_ptr() if dph_out is not None else None, out.data_ptr(),
+                                               spk_id.data_ptr() if spk_id is not None else None, ph.data_ptr() if ph is not None else None,
+                                               B, T, ctx.tape.data_ptr() + ctx.toff, ctx.tape.numel() - ctx.toff, grads.data_ptr(),
+                                               dc.data_ptr() if dc is not None else None, dar.data_ptr() if dar is not None else None,
+                                               ws.data_ptr() + woff, ws.numel() - woff, stream)
+            finally:
+                if cb is not None:
+                    lib.hificar_set_bucket_callback(handle, _native.BUCKET_FN(), None)
+            _native.check(rc, "hificar_backward")
+            if errors:
+                raise errors[0]
+            if reducer is not None:
+                reducer.finish()
+            else:
+                _native.check(lib.hificar_weight_norm_backward(handle, grads.data_ptr(), raw.data_ptr(), stream), "hificar_weight_norm_backward")
         gw, off = [], 0
         for shape in ctx.shapes:
             n = int(np.prod(shape))

@@ -233,6 +233,21 @@ int hificar_grad_info(hificar_handle* h, int i, char* name96, int64_t* offset, i
 int64_t hificar_grad_floats(hificar_handle* h);
 int hificar_backward(hificar_handle* h, const float* dout, const float* out, int B, int T, const void* tape, size_t tape_bytes,
                      float* grads, float* dc, float* dar, void* workspace, size_t workspace_bytes, void* stream);
+/* Data-parallel training: gradient BUCKETS.  The reference meant to wrap both networks in DistributedDataParallel (articulatory/bin/
+ * train.py:1790-1801), which all-reduces buckets of gradients while the backward pass still runs.  Here a bucket is a group of parameters
+ * whose gradients are complete at a known point of hificar_backward(_cond) / hificar_disc_backward:
+ *   generator      bucket b < n_stages: the ResBlocks of stage n_stages - 1 - b (bucket 0 also the output conv and the phoneme head);
+ *                  bucket n_stages: everything else (input conv, upsamplers, PastFCEncoder, conditioning tensors) — hificar_grad_bucket_count
+ *   discriminator  one bucket per sub-discriminator (scales first, then periods) — hificar_disc_grad_bucket_count
+ * hificar_raw_param_bucket(h, i) is the bucket of raw parameter i of the last hificar_set_parameters_device call.  With a callback set,
+ * the backward calls fn(bucket, stream, user) on the host right after the bucket's last gradient kernel has been enqueued on `stream`
+ * (the call's stream, or the sub-discriminator's side stream): the callee runs hificar_weight_norm_backward_bucket on that stream and
+ * starts its collective behind it, while the backward goes on enqueueing.  The bucket variants add no cross-stream ordering. */
+typedef void (*hificar_bucket_fn)(int bucket, void* stream, void* user);
+int hificar_grad_bucket_count(hificar_handle* h);
+int hificar_raw_param_bucket(const hificar_handle* h, int i);
+int hificar_set_bucket_callback(hificar_handle* h, hificar_bucket_fn fn, void* user);
+int hificar_weight_norm_backward_bucket(hificar_handle* h, const float* grads, float* raw_grads, int bucket, void* stream);
 int hificar_forward_train_cond(hificar_handle* h, const float* c, const float* ar, const int32_t* spk_id, const int32_t* ph, float* out,
                                float* ph_out, int B, int T, void* workspace, size_t workspace_bytes, void* tape, size_t tape_bytes, void* stream);
 int hificar_backward_cond(hificar_handle* h, const float* dout, const float* dph_out, const float* out, const int32_t* spk_id,
@@ -341,6 +356,12 @@ size_t hificar_disc_tape_bytes(const hificar_disc* d, int B, int T);
 /* Algorithmic multiply-accumulates of one discriminator forward over (B, 1, T) (every Conv1d / Conv2d of hifigan.py:317-825: output
  * positions x cout x cin / groups x k) — the training roofline's work unit, as hificar_macs is the generator's. */
 double hificar_disc_macs(const hificar_disc* d, int B, int T);
+/* gradient buckets of the discriminators (see hificar_bucket_fn above): one per sub-discriminator */
+int hificar_disc_grad_bucket_count(const hificar_disc* d);
+int hificar_disc_raw_param_bucket(const hificar_disc* d, int i);
+int hificar_disc_bucket_folded_range(const hificar_disc* d, int bucket, int64_t* offset, int64_t* numel);
+int hificar_disc_set_bucket_callback(hificar_disc* d, hificar_bucket_fn fn, void* user);
+int hificar_disc_weight_norm_backward_bucket(hificar_disc* d, const float* grads, float* raw_grads, int bucket, void* stream);
 size_t hificar_disc_backward_workspace_bytes(const hificar_disc* d, int B, int T);
 int hificar_disc_output_count(const hificar_disc* d);
 int hificar_disc_output_info(const hificar_disc* d, int B, int T, int i, hificar_disc_output* out);

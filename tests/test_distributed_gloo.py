@@ -120,3 +120,75 @@ def test_shard_items_deals_by_length():
 def test_unsharded_passthrough():
     x = torch.arange(6.0).reshape(3, 2)
     assert torch.equal(synthesize_sharded(lambda t: t * 2, x), x * 2)
+
+
+# ---------------------------------------------------------------- bucketed, overlapped gradient all-reduce (articulatory_amd/utils/buckets.py)
+def test_bucket_ranges_merge_adjacent_slots():
+    from articulatory_amd.utils.buckets import bucket_ranges
+
+    # raw order of a tiny generator: input conv (g, v, bias) | upsampler | block of stage 0 | block of stage 1 | output conv | MLP
+    ids = [2, 2, 2, 2, 1, 1, 0, 0, 0, 2]
+    numels = [5, 40, 5, 13, 8, 3, 16, 2, 7, 9]
+    ranges, total = bucket_ranges(ids, numels, 3)
+    assert total == 8 + 40 + 8 + 16 + 8 + 4 + 16 + 4 + 8 + 12
+    assert ranges[2] == [(0, 72), (112, 12)]          # front: the head of the buffer and the MLP at its end
+    assert ranges[1] == [(72, 12)] and ranges[0] == [(84, 28)]
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from articulatory_amd.utils.buckets import BucketReducer, bucket_ranges
+
+        rng = np.random.default_rng(5)
+        n_buckets = 5
+        numels = [int(v) for v in rng.integers(1, 3000, size=40)]
+        ids = sorted(int(v) for v in rng.integers(0, n_buckets, size=40))[::-1]        # completion order differs from memory order
+        ids[3], ids[-2] = ids[-2], ids[3]                                             # ... and one bucket is split into two ranges
+        ranges, total = bucket_ranges(ids, numels, n_buckets)
+        grads = torch.from_numpy(np.random.default_rng(100 + rank).standard_normal(total).astype(np.float32))  # this rank's gradients
+        want = grads.clone()
+        dist.all_reduce(want)                                                          # the single-collective result
+        want /= world
+        raw = torch.zeros(total)
+        red = BucketReducer(raw, ranges, None, True)
+        for b in (3, 0, 4, 1, 2):                                                      # buckets complete in "backward" order
+            for off, n in ranges[b]:
+                raw[off:off + n] = grads[off:off + n]                                  # the bucket's gradients land ...
+            red.reduce(b)                                                              # ... and its collective starts at once
+        with pytest.raises(RuntimeError):
+            red.reduce(1)
+        out = red.finish()
+        assert out is raw and torch.equal(raw, want), float((raw - want).abs().max())
+        red2 = BucketReducer(torch.zeros(total), ranges, None, True)
+        red2.reduce(0)
+        with pytest.raises(RuntimeError, match="never reduced"):
+            red2.finish()
+        for w in red2.pending:
+            w.wait()
+        if rank == 0:
+            q.put(("ok", None, None))
+    except Exception as e:  # pragma: no cover
+        if rank == 0:
+            q.put(("err", repr(e), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_equals_single_collective_world2():
+    """BucketReducer at world size 2 over gloo: gradients injected bucket by bucket in backward order, every bucket's all-reduce started
+    as it completes — bit-identical to ONE all-reduce of the whole buffer followed by the average (what sync_gradients did before)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status, msg, _ = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+    assert status == "ok", msg
+    assert all(p.exitcode == 0 for p in procs)

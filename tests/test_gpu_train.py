@@ -179,8 +179,10 @@ def test_training_step_updates_weights_and_eval_follows():
 
 
 def test_gradient_all_reduce_over_rccl_world1():
-    """sync_gradients(): the backward pass all-reduces the flat gradient buffer over the "nccl" (RCCL) backend.  One GPU here, so a
-    world of one rank: the collective runs for real and must leave the gradients unchanged (averaging by 1)."""
+    """sync_gradients(): the backward pass all-reduces the gradients bucket by bucket over the "nccl" (RCCL) backend — libhificar reports
+    each bucket (last stage first, "front" last) through the bucket callback while the backward still enqueues, the bucket's weight-norm
+    chain rule and its collective start right there (articulatory_amd/utils/buckets.py).  One GPU here, so a world of one rank: the
+    collectives run for real and must leave the gradients bit-identical to the unsynchronised run (averaging by 1)."""
     import socket
     import torch.distributed as dist
 
@@ -189,11 +191,21 @@ def test_gradient_all_reduce_over_rccl_world1():
     ar = torch.zeros(2, 1, 512, device="cuda:0")
     cot = torch.from_numpy(uniform(4, "cot", (2, 1, 180), -1.0, 1.0)).cuda()
 
+    seen = []
+
     def grads(sync):
         g, _ = build(params, 21)
         if sync:
             g.sync_gradients()
-        (g(c, ar=ar) * cot).sum().backward()
+            from articulatory_amd.utils import buckets
+
+            real = buckets.BucketReducer.reduce
+            buckets.BucketReducer.reduce = lambda self, b: (seen.append((b, [r for r in self.ranges[b]])), real(self, b))[1]
+        try:
+            (g(c, ar=ar) * cot).sum().backward()
+        finally:
+            if sync:
+                buckets.BucketReducer.reduce = real
         return {k: p.grad.clone() for k, p in g.named_parameters()}
 
     ref = grads(False)
@@ -208,3 +220,8 @@ def test_gradient_all_reduce_over_rccl_world1():
     assert sorted(got) == sorted(ref)
     for k in ref:
         assert torch.equal(got[k], ref[k]), k
+    # two stages -> buckets 0 (stage 1 + output conv), 1 (stage 0), 2 (front), reported in that order; their ranges tile the raw buffer
+    assert [b for b, _ in seen] == [0, 1, 2]
+    spans = sorted(r for _, rs in seen for r in rs)
+    assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert spans[-1][0] + spans[-1][1] == sum((p.numel() + 3) & ~3 for p in ref.values())
