@@ -66,5 +66,5 @@ if a.profile:
     st = d.profile_end()
     tot = sum(s["total_ms"] for s in st)
     print(f"discriminator step kernel time {tot:.2f} ms")
-    for s in st[:16]:
+    for s in st[: int(os.environ.get("DISC_BENCH_ROWS", "16"))]:
         print(f"  {s['name']:44s} {s['launches']:4d} launches {s['total_ms']:8.3f} ms  {s['flops'] / max(s['total_ms'], 1e-9) / 1e9:7.1f} TF-alg")
