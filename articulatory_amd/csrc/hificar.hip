@@ -933,6 +933,7 @@ struct ConvIO {
     float mask_slope = 0.f;
     long long x_seq_bytes = 0;        // input row addressing (ConvParams::x_seq_bytes / x_row_bytes); 0: packed rows
     int x_row_bytes = 0;
+    int x_rows = 0;                   // input rows per sequence when they differ from the launch's rows (ConvParams::x_rows)
 };
 
 // Replicas of every branch at regular strides (the groups of a grouped conv): see MultiConvParams::zrep
@@ -1014,6 +1015,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         mp.p[b].mask_slope = io[b].mask_slope;
         mp.p[b].x_seq_bytes = io[b].x_seq_bytes;
         mp.p[b].x_row_bytes = io[b].x_row_bytes;
+        mp.p[b].x_rows = io[b].x_rows;
         mp.p[b].zeros = h->d_zeros;
         mp.p[b].slope_out = slope_out;
         mp.p[b].cout_real = Lb.cout_pad;

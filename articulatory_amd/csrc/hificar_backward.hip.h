@@ -164,6 +164,7 @@ struct WgradTapsParams {
     // (a_seq_pitch = L * apitch, acols = apitch); a pitch shorter than the row = the sliding-window view of ConvParams::x_row_bytes
     long long a_seq_pitch = 0;
     int acols = 0;
+    int a_rows = 0;  // A rows that exist per sequence (0: L, as G): the polyphase-input form of a strided conv reads ntaps - 1 rows past L
     WgradParams w;
     const char* zeros;  // >= 16 zero bytes (rows outside the sequence)
     int off_min;        // smallest tap offset of the layer (over all phases), halo = largest - smallest
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
             const int ach = at * 64 + c4;
             // an A row is only ever multiplied with G rows of the same chunk: rows whose G partner lies beyond the sequence need no masking
             // (those G rows are zero), but A rows outside [0, L) are the conv's zero padding
-            if (r < a_rows && ta >= 0 && ta < p.L && ach < a_cols)
+            if (r < a_rows && ta >= 0 && ta < (q.a_rows ? q.a_rows : p.L) && ach < a_cols)
                 src = reinterpret_cast<const char*>(a_base + (size_t)seq * a_seq_pitch + (size_t)ta * p.apitch + ach);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + g_bytes + i * 1024), 16, 0, 0);
@@ -455,6 +456,8 @@ struct WreduceParams {
     int tap_k[kMaxPhase][kMaxTaps];
     int flip;  // 0
     int gemm_cin;  // > 0: GEMM form of a conv (discriminators): a = tap * gemm_cin + c -> dst[(co * gemm_cin + c) * K + tap]
+    int poly_s, poly_cin;  // poly_s > 0: polyphase-input form of a strided conv (cout, poly_cin, K): (tap q, a = r * poly_cin + c) -> kernel index
+                           // poly_s * q + r, dst[(co * poly_cin + c) * K + poly_s * q + r] (indices >= K carry zero weights: skipped)
 };
 
 struct WreducePair {
@@ -514,6 +517,12 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
                 const int tap = (a + j) / p.gemm_cin, c = (a + j) - tap * p.gemm_cin;
                 if (tap >= p.K) break;
                 d = ((size_t)co * p.gemm_cin + c) * p.K + tap;
+            }
+            if (p.poly_s > 0) {
+                const int rr = (a + j) / p.poly_cin, c = (a + j) - rr * p.poly_cin;
+                const int kk = p.poly_s * k + rr;
+                if (rr >= p.poly_s || kk >= p.K) continue;
+                d = ((size_t)co * p.poly_cin + c) * p.K + kk;
             }
             dst_p[d] = o[j];
         }
@@ -992,6 +1001,10 @@ struct PackParams {
 //   mode 7  plain copy
 //   modes 8 / 9  GEMM form of a (grouped, strided) conv and of its data gradient, src (cout_g, cin_g, k) of one group: the im2col
 //           column j = tap * cin_g + c is the packed layer's input channel (8) / output channel (9)   (hificar_disc_kernels.hip.h)
+//   modes 10 / 11  polyphase-input form of a strided conv, src (cout_g, cin_g = p.cin, k = p.K), stride p.stride: rows of `stride` input
+//           positions are the packed layer's channels r * cin_g + c, tap q holds kernel index stride * q + r (zero past k).
+//           10: the forward conv (cin' = stride * cin_g -> cout_g, taps 0 .. ntaps - 1);  11: its data gradient (cout_g -> cin', the taps
+//           reversed: a Conv1d with padding ntaps - 1)
 __device__ __forceinline__ void pack_w32_body(const PackParams& p, long long first, long long step) {
     for (long long i = first; i < p.total; i += step) {
         if (p.mode >= 4 && p.mode <= 7) {
@@ -1042,6 +1055,14 @@ __device__ __forceinline__ void pack_w32_body(const PackParams& p, long long fir
                 } else if (p.mode == 9) {  // its data gradient: output column j = tap * cin + c, input channel = the conv's output channel
                     const int tap = co / p.cin, c = co - tap * p.cin;
                     val = p.src[((size_t)ci * p.cin + c) * p.K + tap];
+                } else if (p.mode == 10) {
+                    const int rr = ci / p.cin, c = ci - rr * p.cin;
+                    const int kk = p.stride * t + rr;
+                    if (kk < p.K) val = p.src[((size_t)co * p.cin + c) * p.K + kk];
+                } else if (p.mode == 11) {
+                    const int rr = co / p.cin, c = co - rr * p.cin;
+                    const int kk = p.stride * (p.ntaps - 1 - t) + rr;
+                    if (kk < p.K) val = p.src[((size_t)ci * p.cin + c) * p.K + kk];
                 } else {
                     const int rr = ci / p.cout_pad, cc = ci - rr * p.cout_pad;  // virtual input channel -> (phase r, real co)
                     const int k = rr + p.stride * (p.jmin + t) + p.pad;

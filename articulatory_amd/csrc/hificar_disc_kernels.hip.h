@@ -96,7 +96,7 @@ struct Col2imParams {
     float slope;
     // sliding-window layers: dA holds the data gradient itself, dX [group][seq][win_rows][win_pitch] (the transposed conv's output), not
     // the gradient of an im2col matrix: one read instead of the tap sum
-    int win, win_rows, win_pitch;
+    int win, win_rows, win_pitch, win_off;  // (win_off: dX rows are PADDED positions, t + win_off)
 };
 
 __global__ __launch_bounds__(256) void col2im_mask_kernel(const Col2imParams p) {
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void col2im_mask_kernel(const Col2imParams p) 
             const int g = ca / p.cin_g, c = ca - g * p.cin_g;
             const float* da = p.dA + (size_t)g * p.da_gstride;
             float s = dyg ? dyg[i] : 0.f;
-            if (p.win) s += da[((size_t)seq * p.win_rows + t) * p.win_pitch + c];
+            if (p.win) s += da[((size_t)seq * p.win_rows + t + p.win_off) * p.win_pitch + c];
             // taps with (t + pad - tap) divisible by the stride and the output position in range, ascending tap order
             for (int tap = p.win ? p.kt : (t + p.pad) % p.stride; tap < p.kt; tap += p.stride) {
                 const int num = t + p.pad - tap;

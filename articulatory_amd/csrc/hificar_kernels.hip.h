@@ -78,6 +78,10 @@ struct ConvParams {
     // A[t] = x_flat[t * stride * cin_g .. + k * cin_g) straight from the activations (hificar_disc.hip.inc), no im2col copy.
     long long x_seq_bytes;
     int x_row_bytes;
+    // input rows that exist per sequence when that differs from the output rows (0: the same, L / seq_rows): a strided conv run as a
+    // multi-tap conv over rows of `stride` input positions (hificar_disc.hip.inc, polyphase-input form) reads ntaps - 1 rows past its
+    // last output row, and its data gradient writes more rows than it reads.  Rows in [0, x_rows) are staged, the rest read as zeros.
+    int x_rows;
 };
 
 __device__ __forceinline__ bool is_ragged(const ConvParams& p) { return p.seq_len != nullptr || p.len_const >= 0; }
@@ -393,7 +397,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             const ConvParams& p = mp.p[T.b];
             const int R = TM + p.halo;
             const int ninstr = (R * SPR + 63) >> 6;  // 1 KiB of LDS per wave-instruction
-            const int Ls = seq_rows(p, T.seq);
+            const int Ls = p.x_rows ? p.x_rows : seq_rows(p, T.seq);
             const int row_bytes = p.x_row_bytes ? p.x_row_bytes : p.cin * 4;
             const char* const xs_z = p.xs + (size_t)T.z * mp.zs_x + (size_t)T.seq * (p.x_seq_bytes ? (size_t)p.x_seq_bytes : (size_t)p.L * p.cin * 4);
             char* dst = smem_b + (jj & 1) * buf_bytes;
