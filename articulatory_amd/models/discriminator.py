@@ -450,18 +450,33 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         return self._info_cache[key]
 
     def invalidate_parameters(self):
-        """Force the next call to hand the parameters over again.  In-place updates through autograd-visible ops (optimizer.step(),
+        """Force the next call to hand the parameters over again.  In-place updates through autograd-visible ops (foreach optimizer.step(),
         load_state_dict, p.copy_ under no_grad) are noticed by themselves through the tensors' version counters; writes through
-        ``p.data`` are not."""
+        ``p.data`` and torch's FUSED optimizers (``Adam(fused=True)`` does not bump ``_version``) are not — the Trainer calls this from an
+        optimizer post-step hook."""
         self.__dict__.pop("_sent_sig", None)
         self.__dict__["_real_cache"] = None
 
     def _raw_parameters(self):
-        names, tensors = [], []
-        for name, p in self.named_parameters():
-            names.append(self._name_prefix + name)  # the engine's names are the combined discriminator's
-            tensors.append(p)
-        return tuple(names), tensors
+        cached = self.__dict__.get("_raw_cache")  # (walking the module tree costs ~1 ms per call; the criterion needs it every pass)
+        if cached is None:
+            names, tensors = [], []
+            for name, p in self.named_parameters():
+                names.append(self._name_prefix + name)  # the engine's names are the combined discriminator's
+                tensors.append(p)
+            cached = self.__dict__["_raw_cache"] = (tuple(names), tensors)
+        return cached
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self.__dict__["_raw_cache"] = None
+        self.invalidate_parameters()
+        return out
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.__dict__["_raw_cache"] = None
+        return out
 
     def sync_gradients(self, group=None, average=True, enabled=True):
         """Data-parallel training: all-reduce the discriminator's gradients inside backward (one flat bucket), see

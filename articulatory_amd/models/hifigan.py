@@ -112,7 +112,8 @@ def _send_parameters(module, names, tensors, stream):
     """Hand every RAW parameter over in one call (hificar_set_parameters_device: weight norm folded and every pack refreshed on the
     device, two launches).  Returns the tensors actually read (kept alive by the caller until the stream has consumed them)."""
     lib, handle = module._lib, module._handle
-    held = [t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous() for t in tensors]
+    # (the parameters themselves are read when they are fp32 and contiguous — the normal case; a converted copy otherwise)
+    held = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous() for t in tensors]
     cnames = getattr(module, "_raw_cnames", None)
     if cnames is None or cnames[0] != names:
         arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
@@ -426,6 +427,7 @@ class HiFiGANGenerator(torch.nn.Module):
         self._handle = None
         self._workspaces = {}
         self._grad_slots = None
+        self.__dict__["_plist_cache"] = None
 
     def __del__(self):
         try:
@@ -437,6 +439,12 @@ class HiFiGANGenerator(torch.nn.Module):
         """Re-upload weights after an in-place parameter edit (e.g. ``p.data.copy_``)."""
         self._invalidate()
 
+    def invalidate_parameters(self):
+        """The parameters were updated in a way their version counters do not show — ``p.data`` writes, and torch's FUSED optimizers
+        (``torch.optim.Adam(fused=True)`` updates in place without bumping ``_version``): the next forward hands them over again.
+        ``articulatory_amd.bin.train.Trainer`` calls this from an optimizer post-step hook."""
+        self._param_sig = None
+
     def set_precision(self, precision):
         if precision not in _native.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_native.PRECISIONS)}")
@@ -447,8 +455,17 @@ class HiFiGANGenerator(torch.nn.Module):
     def _device(self):
         return next(self.parameters()).device
 
+    def _plist(self):
+        """The parameters as a flat list, cached: walking the module tree (self.parameters()) costs ~1 ms per call on this model, and the
+        training forward needs the list three times.  Rebuilt whenever a parameter OBJECT may have changed (_invalidate: .to(), weight
+        norm applied / removed, load_state_dict) and checked against the cheap count of registered parameters."""
+        lst = self.__dict__.get("_plist_cache")
+        if lst is None:
+            lst = self.__dict__["_plist_cache"] = list(self.parameters())
+        return lst
+
     def _param_signature(self):
-        return tuple(p._version for p in self.parameters())
+        return tuple(p._version for p in self._plist())
 
     def _native_handle(self):
         if self._handle is not None:
@@ -679,7 +696,7 @@ class HiFiGANGenerator(torch.nn.Module):
         # the autograd node (and its full-utterance tape) only when a gradient can be asked for: an input that requires grad, or a
         # module in training mode with trainable parameters — model.eval() inference without torch.no_grad() stays on the inference kernels
         if torch.is_grad_enabled() and (c.requires_grad or (ar is not None and ar.requires_grad)
-                                        or (self.training and any(p.requires_grad for p in self.parameters()))):
+                                        or (self.training and any(p.requires_grad for p in self._plist()))):
             if lengths is not None:
                 raise NotImplementedError("autograd with ragged lengths is not built")
             return self._forward_autograd(c, ar, spk_id if self.use_spk_id else None, ph if self.use_ph else None)

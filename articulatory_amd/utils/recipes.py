@@ -22,7 +22,7 @@ _RECIPES = {
 STFT_DEFAULTS = {"fft_sizes": [1024, 2048, 512], "hop_sizes": [120, 240, 50], "win_lengths": [600, 1200, 240], "window": "hann_window"}  # stft_loss.py:131-137
 
 
-def recipe_train_config(recipe="car", aux="mel", batch=None, fused_optimizers=False):
+def recipe_train_config(recipe="car", aux="mel", batch=None, fused_optimizers=True):
     """aux: "mel" (what the YAMLs ship) or "stft" (BASELINE config 5's multi-resolution STFT loss with the reference's default resolutions)."""
     g_over, r_batch, r_steps, fs, mel_hop, milestones = _RECIPES[recipe]
     adam = {"lr": 1.0e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}

@@ -284,3 +284,21 @@ def test_phoneme_conditioned_iteration_with_ph_loss_vs_oracle():
     now = t.G.state_dict()
     for k in ("ph_emb_mat.weight", "ph_fc.weight", "ph_fc.bias"):
         assert not np.allclose(now[k].cpu().numpy(), gsd[k]), k
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_fused_and_foreach_optimizers_give_the_same_iterations(fused):
+    """torch's fused Adam updates the parameters WITHOUT bumping their version counters, which is how the modules notice updates: the
+    Trainer's optimizer post-step hooks tell them.  Three iterations with either optimizer form must log the same losses (round-3 defect:
+    with fused_optimizers the second forward of an iteration ran on the weights of the step before)."""
+    config = dict(make_config(True), fused_optimizers=fused)
+    t, gsd, dsd, batch = build(config)
+    t.steps = 1
+    logs = [{k: float(v) for k, v in t.train_step(batch).items()} for _ in range(3)]
+    ref_t, _, _, _ = build(dict(make_config(True), fused_optimizers=False))
+    ref_t.steps = 1
+    want = [{k: float(v) for k, v in ref_t.train_step(batch).items()} for _ in range(3)]
+    for a, b in zip(logs, want):
+        for k in b:
+            assert abs(a[k] - b[k]) <= 2e-4 * max(abs(b[k]), 1e-3), (fused, k, a[k], b[k])
+    assert logs[2]["train/fake_loss"] != logs[0]["train/fake_loss"]
