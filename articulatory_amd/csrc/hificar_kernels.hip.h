@@ -297,10 +297,65 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         const size_t seq_base = (size_t)T.seq * p.L;
         const float slope_out = p.slope_out;
         const int rows = min(TM, seq_rows(p, T.seq) - T.t0);
-        const int vc = vc_base + c8;
         const float* const bias_z = p.bias + (size_t)T.z * mp.zs_b;
         float* const y_z = p.y ? p.y + (size_t)T.z * mp.zs_y : nullptr;
         char* const ys_z = p.ys ? p.ys + (size_t)T.z * mp.zs_y * 4 : nullptr;
+#ifndef HIFICAR_WO4
+#define HIFICAR_WO4 0  // (A/B: measured equal to the 8-channel units within run-to-run noise on every stage shape, so the one tested path stays)
+#endif
+        if constexpr (F32 && KS == 1 && HIFICAR_WO4) {
+            // dev variant (-DHIFICAR_WO4=1): a thread owns FOUR adjacent channels, so the 16 lanes of a row segment write 256 contiguous
+            // bytes per store instruction (with 8-channel units every 128-byte line is written in halves by two instructions).  The
+            // stores — not the arithmetic, not the residual loads — are what the output pass costs (tools/conv_bench.hip with
+            // -DHIFICAR_WO_EXP=1..3: dropping them is worth 8 % at C = 64 / 128 and 24 % at C = 32), but their layout is not: no gain.
+            const int w4 = width >> 2;                             // 8, 16, 24 or 32 units per row
+            const int rpp4 = nthr / w4;
+            const int rr4 = ltid / w4;
+            const int c4 = (ltid - rr4 * w4) * 4;
+            const bool on4 = rr4 < rpp4;
+            const int vc4 = vc_base + c4;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_z + vc4);
+            constexpr int UB4 = 8;
+            for (int r0 = 0; r0 < rows; r0 += rpp4 * UB4) {
+                f32x4 v[UB4], rs[UB4], mk[UB4];
+#pragma unroll
+                for (int q = 0; q < UB4; ++q) {
+                    const int row_l = r0 + q * rpp4 + rr4;
+                    v[q] = rs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mk[q] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (on4 && row_l < rows) {
+                        v[q] = *reinterpret_cast<const f32x4*>(&O[row_l * OP + c4]);
+                        const size_t off = (seq_base + T.t0 + row_l) * p.cout_total + vc4;
+                        if (p.mask_src) mk[q] = *reinterpret_cast<const f32x4*>(p.mask_src + off);
+                        if (p.res) rs[q] = *reinterpret_cast<const f32x4*>(p.res + off);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < UB4; ++q) {
+                    const int row_l = r0 + q * rpp4 + rr4;
+                    if (on4 && row_l < rows) {
+                        const size_t off = (seq_base + T.t0 + row_l) * p.cout_total + vc4;
+                        f32x4 o;
+                        if (p.mask_src) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (v[q][e] + bv[e]) * (mk[q][e] > 0.f ? 1.f : p.mask_slope) + rs[q][e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (v[q][e] + bv[e]) + rs[q][e];
+                        }
+                        if (y_z) *reinterpret_cast<f32x4*>(y_z + off) = o;
+                        if (ys_z) {
+                            f32x4 a;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a[e] = fmaxf(o[e], o[e] * slope_out);  // LeakyReLU, 0 <= slope <= 1
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ys_z) + off) = a;
+                        }
+                    }
+                }
+            }
+            return;
+        }
+        const int vc = vc_base + c8;
         const f32x4 bv0 = *reinterpret_cast<const f32x4*>(bias_z + vc);
         const f32x4 bv1 = *reinterpret_cast<const f32x4*>(bias_z + vc + 4);
         // split rows: virtual channel -> (real row within the virtual row, channel); 8 | cout_real
@@ -332,7 +387,11 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                         v0[q] = (v0[q] + a0) + (b0 + d0);
                         v1[q] = (v1[q] + a1) + (b1 + d1);
                     }
+#if defined(HIFICAR_WO_EXP) && HIFICAR_WO_EXP >= 2
+                    if (false) {
+#else
                     if (p.res) {
+#endif
                         const float* rp = p.res + (seq_base + T.t0 + row_l) * p.cout_total + vc;
                         q0[q] = *reinterpret_cast<const f32x4*>(rp);
                         q1[q] = *reinterpret_cast<const f32x4*>(rp + 4);
@@ -352,22 +411,43 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                             o[4 + e] = (v1[q][e] + bv1[e]) * (m1[q][e] > 0.f ? 1.f : p.mask_slope) + q1[q][e];
                         }
                     } else {
+#if defined(HIFICAR_WO_EXP) && HIFICAR_WO_EXP >= 1  // dev experiment (tools/conv_bench.hip): no output-pass arithmetic
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = v0[q][e];
+                            o[4 + e] = v1[q][e];
+                        }
+#else
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             o[e] = (v0[q][e] + bv0[e]) + q0[q][e];
                             o[4 + e] = (v1[q][e] + bv1[e]) + q1[q][e];
                         }
+#endif
                     }
+#if defined(HIFICAR_WO_EXP) && HIFICAR_WO_EXP >= 3
+                    if (o[0] == 12345.678f) {  // (never: keeps the reads alive)
+#else
                     if (y_z) {
+#endif
                         float* yp = y_z + row * p.cout_total + vc;
                         *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
                         *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
                     }
+#if defined(HIFICAR_WO_EXP) && HIFICAR_WO_EXP >= 3
+                    if (o[1] == 12345.678f) {
+#else
                     if (ys_z) {
+#endif
                         if constexpr (F32) {
                             float a[8];
+#if defined(HIFICAR_WO_EXP) && HIFICAR_WO_EXP >= 1
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) a[e] = o[e];
+#else
 #pragma unroll
                             for (int e = 0; e < 8; ++e) a[e] = fmaxf(o[e], o[e] * slope_out);  // LeakyReLU, 0 <= slope <= 1
+#endif
                             float* orow = reinterpret_cast<float*>(ys_z) + row * (size_t)p.cout_total + vc;
                             *reinterpret_cast<f32x4*>(orow) = f32x4{a[0], a[1], a[2], a[3]};
                             *reinterpret_cast<f32x4*>(orow + 4) = f32x4{a[4], a[5], a[6], a[7]};
