@@ -644,7 +644,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                     w1h = wc[512];
                     w1l = wc[512 + 64];
                 }
+                HIFICAR_STAMP(1 + 3 * j);
                 __syncthreads();  // item j is staged
+                HIFICAR_STAMP(2 + 3 * j);
                 const int buf_off = (j & 1) * buf_bytes;
                 frag_t x0h[MI], x0l[MI], x1h[MI], x1l[MI];
                 int ad[2];
@@ -692,8 +694,11 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                     }
             }
         }
+        HIFICAR_STAMP(3 * j);
         __syncthreads();  // matches the loader waves' final barrier
+        HIFICAR_STAMP(62);
         if (last >= 0) write_out(decode(tile_of(last)), tid, NTHR);
+        HIFICAR_STAMP(63);
         return;
     }
     for (int it = nxt(0), itn; it < my_rounds; it = itn) {

@@ -34,7 +34,7 @@ static void summarize(const std::vector<unsigned long long>& ht, int G) {
     stat("WG end (abs)", wg_end);
 }
 
-template <int MI, int WM, int WN, int NC16, bool F32 = false>
+template <int MI, int WM, int WN, int NC16, bool F32 = false, int KS = 1>
 void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int dil, bool residual, int mode = 0) {
     constexpr int TM = WM * MI * 32;
     const int CH = NC16 * 16;
@@ -105,15 +105,18 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
     hipMalloc(&trace, (size_t)G * 2 * 64 * 8);
     hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
     mp.trace = trace;
-    void (*kern)(const MultiConvParams) = conv_bf16x3_kernel<MI, WM, WN, NC16>;
-    if (F32) kern = conv_f32_kernel<MI, WM, WN, NC16>;
+    void (*kern)(const MultiConvParams) = nullptr;
+    if constexpr (KS == 4) kern = F32 ? conv_sk_f32_kernel<MI, NC16> : conv_sk_bf16x3_kernel<MI, NC16>;  // split-K form (WM = WN = 1)
+    else kern = F32 ? conv_f32_kernel<MI, WM, WN, NC16> : conv_bf16x3_kernel<MI, WM, WN, NC16>;
+    const size_t lds_bytes = 2 * (size_t)mp.buf_bytes + (size_t)KS * TM * (WN * 32 + 4) * 4;
+    const int nthreads = KS == 4 ? 512 : (WM * WN + 4) * 64;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0, ms1 = 0;
     for (int it = 0; it < 3; ++it) {
         hipEventRecord(e0);
-        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3((WM * WN + 4) * 64), 2 * mp.buf_bytes + TM * (WN * 32 + 4) * 4, 0, mp);
+        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3(nthreads), lds_bytes, 0, mp);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
@@ -121,7 +124,7 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
     hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(G), dim3((WM * WN + 4) * 64), 2 * mp.buf_bytes + TM * (WN * 32 + 4) * 4, 0, mp);  // the traced launch: alone
+    hipLaunchKernelGGL(kern, dim3(G), dim3(nthreads), lds_bytes, 0, mp);  // the traced launch: alone
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms1, e0, e1);
@@ -222,6 +225,21 @@ int main(int argc, char** argv) {
         run_pair<4, 4, 1, 2>("PAIR stage3 C32 L2000", 64, 2000, 32, 3, k3, 1);
     }
     const int k3[3] = {11, 7, 3};
+    if (argc > 1 && !strcmp(argv[1], "small")) {  // the small-batch launches of the AR loop: split-K form, exact fp32
+        for (int B : {1, 8}) {
+            printf("---- batch %d\n", B);
+            run<1, 1, 1, 4, true, 4>("stage0 sk<1,4> conv1", B, 125, 256, 3, k3, 1, false);
+            run<1, 1, 1, 4, true, 4>("stage0 sk<1,4> conv2+res", B, 125, 256, 3, k3, 1, true);
+            run<2, 1, 1, 4, true, 4>("stage0 sk<2,4> conv1", B, 125, 256, 3, k3, 1, false);
+            run<1, 1, 1, 4, true, 4>("stage1 sk<1,4> conv1", B, 500, 128, 3, k3, 1, false);
+            run<1, 1, 4, 4, true>("stage1 <1,1,4,4> conv1", B, 500, 128, 3, k3, 1, false);
+            run<1, 1, 1, 2, true, 4>("stage2 sk<1,2> conv1", B, 1000, 64, 3, k3, 1, false);
+            run<1, 2, 2, 2, true>("stage2 <1,2,2,2> conv1", B, 1000, 64, 3, k3, 1, false);
+            run<1, 1, 1, 1, true, 4>("stage3 sk<1,1> conv1", B, 2000, 32, 3, k3, 1, false);
+            run<1, 4, 1, 1, true>("stage3 <1,4,1,1> conv1", B, 2000, 32, 3, k3, 1, false);
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "f32")) {
         run<2, 2, 4, 4, true>("stage0 8w (2,2,4) conv1", 64, 125, 256, 3, k3, 1, false);
         run<2, 2, 4, 4, true>("stage0 8w (2,2,4) conv2+res", 64, 125, 256, 3, k3, 1, true);
