@@ -210,6 +210,10 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     static_assert(KS == 1 || (KS == 4 && WM == 1 && WN == 1), "split-K: four waves share one 32-channel block");
     static_assert(KS == 4 || WM * WN == 4 || WM * WN == 8, "4 or 8 MFMA waves per workgroup");
     constexpr int NW = KS == 4 ? 4 : WM * WN;  // MFMA waves; waves NW .. NW+3 are the loaders
+#ifndef HIFICAR_SPLIT_PASS
+#define HIFICAR_SPLIT_PASS 0  // (A/B: measured equal on every stage shape — the loader waves' work per tile, not its placement, is the co-bottleneck)
+#endif
+    constexpr bool kSplitPass = KS == 1 && HIFICAR_SPLIT_PASS != 0;  // the previous tile's output pass spread over all items (one more barrier per tile)
     constexpr int NTHR = (NW + 4) * 64;
     constexpr int kFirstLoader = NW;
     (void)kFirstLoader;
@@ -283,7 +287,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     // Output pass of a finished tile: the MFMA waves left the raw accumulators in the LDS out-buffer as
     // O[time row][channel]; the participating threads (the 256 loader threads, or all 512 for the last tile) walk it row-major (a wave-instruction covers whole 512-byte
     // row segments), add bias and residual, and write the fp32 rows and/or the activated split rows.
-    auto write_out = [&](const Tile& T, int ltid, int nthr) {
+    auto write_out = [&](const Tile& T, int ltid, int nthr, int part = 0, int nparts = 1) {
         // A CU retires roughly one vector-store wave-instruction per ~70 cycles whatever its width, so every store
         // here is 16 bytes per lane: a thread owns 8 adjacent channels of a row (2 x float4 in, 16 B hi + 16 B lo out).
         const ConvParams& p = mp.p[T.b];
@@ -296,7 +300,10 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         const bool lane_on = rr < rpp;                            // w8 = 12 leaves a few threads idle
         const size_t seq_base = (size_t)T.seq * p.L;
         const float slope_out = p.slope_out;
-        const int rows = min(TM, seq_rows(p, T.seq) - T.t0);
+        const int rows_all = min(TM, seq_rows(p, T.seq) - T.t0);
+        // part `part` of `nparts`: a contiguous share of the tile's rows (whole passes of the participating threads)
+        const int rows_lo = nparts > 1 ? min(rows_all, part * (((rows_all + nparts - 1) / nparts + (nthr / (width >> 3)) - 1) / (nthr / (width >> 3)) * (nthr / (width >> 3)))) : 0;
+        const int rows = nparts > 1 ? min(rows_all, (part + 1) * (((rows_all + nparts - 1) / nparts + (nthr / (width >> 3)) - 1) / (nthr / (width >> 3)) * (nthr / (width >> 3)))) : rows_all;
         const float* const bias_z = p.bias + (size_t)T.z * mp.zs_b;
         float* const y_z = p.y ? p.y + (size_t)T.z * mp.zs_y : nullptr;
         char* const ys_z = p.ys ? p.ys + (size_t)T.z * mp.zs_y * 4 : nullptr;
@@ -316,7 +323,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             const int vc4 = vc_base + c4;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_z + vc4);
             constexpr int UB4 = 8;
-            for (int r0 = 0; r0 < rows; r0 += rpp4 * UB4) {
+            for (int r0 = rows_lo; r0 < rows; r0 += rpp4 * UB4) {
                 f32x4 v[UB4], rs[UB4], mk[UB4];
 #pragma unroll
                 for (int q = 0; q < UB4; ++q) {
@@ -362,7 +369,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         const int ph_row = vc / p.cout_real;
         const int split_off = ph_row * p.cout_real * 4 + (vc - ph_row * p.cout_real) * 2;
         constexpr int UB = 4;  // rows in flight per thread: LDS reads and residual loads are issued before any is used
-        for (int r0 = 0; r0 < rows; r0 += rpp * UB) {
+        for (int r0 = rows_lo; r0 < rows; r0 += rpp * UB) {
             f32x4 v0[UB], v1[UB], q0[UB], q1[UB], m0[UB], m1[UB];
 #pragma unroll
             for (int q = 0; q < UB; ++q) {
@@ -502,19 +509,46 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         HIFICAR_STAMP(0);
         bool have_prev = false;
         Tile Tprev;
-        for (int it = nxt(0); it < my_rounds; it = nxt(it + 1)) {
-            const Tile T = decode(tile_of(it));
-            for (int c = 0; c < nchunks; ++c, ++j) {
-                dma_item(T, c, j);
-                // the tile that finished with item j-2 published its accumulators at barrier j-1 (nchunks >= 2, so the
-                // MFMA waves cannot overwrite the out-buffer before barrier j+1)
-                if (c == 1 && have_prev) write_out(Tprev, ltid, 256);
-                HIFICAR_STAMP(1 + 2 * j);
-                __syncthreads();  // item j landed (hipcc drains vmcnt before the barrier); MFMA waves are done with item j-1's buffer
-                HIFICAR_STAMP(2 + 2 * j);
+        if constexpr (kSplitPass) {
+            // The previous tile's output pass is spread over ALL items of the current tile: the out-buffer holds the previous tile from this
+            // tile's first barrier until the MFMA waves overwrite it after this tile's last item — which they only do behind the extra
+            // barrier X.  (Round 2 ran the whole pass inside the second item: at C = 64 / 128 the MFMA waves then waited 15–18 k cycles per
+            // tile for it — the stores are slow next to a busy matrix pipe — while the loader waves idled through the other items.)
+            bool pre_issued = false;
+            for (int it = nxt(0); it < my_rounds;) {
+                const Tile T = decode(tile_of(it));
+                const int itn = nxt(it + 1);
+                for (int c = 0; c < nchunks; ++c, ++j) {
+                    if (!(c == 0 && pre_issued)) dma_item(T, c, j);
+                    if (c >= 1 && have_prev) write_out(Tprev, ltid, 256, c - 1, nchunks);
+                    HIFICAR_STAMP(1 + 2 * j);
+                    __syncthreads();  // item j landed; the MFMA waves are done with item j-1's buffer
+                    HIFICAR_STAMP(2 + 2 * j);
+                }
+                // the MFMA waves compute this tile's last item now: stage the next tile's first item, finish the previous tile's pass
+                pre_issued = itn < my_rounds;
+                if (pre_issued) dma_item(decode(tile_of(itn)), 0, j);
+                if (have_prev) write_out(Tprev, ltid, 256, nchunks - 1, nchunks);
+                __syncthreads();  // X: the out-buffer is free for this tile's accumulators
+                Tprev = T;
+                have_prev = true;
+                it = itn;
             }
-            Tprev = T;
-            have_prev = true;
+        } else {
+            for (int it = nxt(0); it < my_rounds; it = nxt(it + 1)) {
+                const Tile T = decode(tile_of(it));
+                for (int c = 0; c < nchunks; ++c, ++j) {
+                    dma_item(T, c, j);
+                    // the tile that finished with item j-2 published its accumulators at barrier j-1 (nchunks >= 2, so the
+                    // MFMA waves cannot overwrite the out-buffer before barrier j+1)
+                    if (c == 1 && have_prev) write_out(Tprev, ltid, 256);
+                    HIFICAR_STAMP(1 + 2 * j);
+                    __syncthreads();  // item j landed (hipcc drains vmcnt before the barrier); MFMA waves are done with item j-1's buffer
+                    HIFICAR_STAMP(2 + 2 * j);
+                }
+                Tprev = T;
+                have_prev = true;
+            }
         }
         __syncthreads();  // the last tile's accumulators are in the out-buffer
         if (have_prev) write_out(Tprev, tid, NTHR);  // all waves share the final output pass (nothing left to hide it behind)
@@ -812,6 +846,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         }
         HIFICAR_STAMP(3 * j);
         primed = active;  // an active tile ends with the ring holding the next tile's head
+        if constexpr (kSplitPass) __syncthreads();  // X: the loader waves have finished the previous tile's output pass
         if (active) {
             // hand the raw accumulators to the loader waves through the LDS out-buffer O[time row][channel]:
             // lane (li, g) holds time column li and channels 8q + 4g + {0..3} in acc[mi][4q..4q+3]
