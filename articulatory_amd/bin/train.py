@@ -244,7 +244,7 @@ class Trainer:
             if adv_on:
                 disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
                 use_fm = cfg.get("use_feat_match_loss", False)
-                total, adv, fml = self.D.generator_loss(
+                total, adv, fml = self._generator_criterion(
                     disc_y_, disc_y if use_fm else None, loss_type=ga.get("loss_type", "mse"),
                     average_by_discriminators=ga.get("average_by_discriminators", True), lambda_adv=cfg["lambda_adv"],
                     lambda_feat_match=cfg.get("lambda_feat_match", 0.0) if use_fm else 0.0,
@@ -270,8 +270,8 @@ class Trainer:
                 if self.use_ph_loss:
                     y_, _ = y_
             disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
-            dis_loss, real_loss, fake_loss = self.D.discriminator_loss(disc_y_, disc_y, loss_type=da.get("loss_type", "mse"),
-                                                                       average_by_discriminators=da.get("average_by_discriminators", True))
+            dis_loss, real_loss, fake_loss = self._discriminator_criterion(disc_y_, disc_y, loss_type=da.get("loss_type", "mse"),
+                                                                           average_by_discriminators=da.get("average_by_discriminators", True))
             log.update({"train/real_loss": real_loss, "train/fake_loss": fake_loss, "train/discriminator_loss": dis_loss.detach()})
             self.optimizer["discriminator"].zero_grad(set_to_none=True)
             dis_loss.backward()
@@ -281,6 +281,36 @@ class Trainer:
             self._scheduler_step("discriminator", dis_loss)
         self.steps += 1
         return log
+
+    # The GAN criterion: one fused native node per side (D.generator_loss / D.discriminator_loss).  A spectrally normalised discriminator
+    # advances its power iteration at every D(x) of the reference's step (train.py:347,356,421-422: three or four different weight sets per
+    # iteration), which one fused node cannot mirror: those run forward(x, native=True) per call + the reductions of articulatory_amd.losses.
+    def _generator_criterion(self, disc_y_, disc_y, loss_type, average_by_discriminators, lambda_adv, lambda_feat_match, fm_average_by_layers,
+                             fm_average_by_discriminators, fm_include_final_outputs):
+        if not getattr(self.D, "_spectral", False):
+            return self.D.generator_loss(disc_y_, disc_y, loss_type=loss_type, average_by_discriminators=average_by_discriminators, lambda_adv=lambda_adv,
+                                         lambda_feat_match=lambda_feat_match, fm_average_by_layers=fm_average_by_layers,
+                                         fm_average_by_discriminators=fm_average_by_discriminators, fm_include_final_outputs=fm_include_final_outputs)
+        from articulatory_amd import losses as NL
+
+        p_ = self.D(disc_y_, native=True)
+        adv = NL.generator_adversarial_loss(p_, average_by_discriminators, loss_type)
+        fm = torch.zeros((), device=disc_y_.device)
+        if disc_y is not None:
+            with torch.no_grad():
+                p = self.D(disc_y, native=True)
+            fm = NL.feature_match_loss(p_, p, fm_average_by_layers, fm_average_by_discriminators, fm_include_final_outputs)
+        return lambda_adv * (adv + lambda_feat_match * fm), adv.detach(), fm.detach()
+
+    def _discriminator_criterion(self, disc_y_, disc_y, loss_type, average_by_discriminators):
+        if not getattr(self.D, "_spectral", False):
+            return self.D.discriminator_loss(disc_y_, disc_y, loss_type=loss_type, average_by_discriminators=average_by_discriminators)
+        from articulatory_amd import losses as NL
+
+        p = self.D(disc_y, native=True)
+        p_ = self.D(disc_y_.detach(), native=True)
+        real, fake = NL.discriminator_adversarial_loss(p_, p, average_by_discriminators, loss_type)
+        return real + fake, real.detach(), fake.detach()
 
     def _scheduler_step(self, which, loss):
         if self.config.get(f"{which}_scheduler_type", "StepLR") == "ReduceLROnPlateau":  # train.py:380-383,432-435
@@ -321,13 +351,13 @@ class Trainer:
         disc_y = torch.cat([ar, y], dim=2) if self.use_ar else y
         disc_y_ = torch.cat([ar, y_], dim=2) if self.use_ar else y_
         use_fm = cfg.get("use_feat_match_loss", False)
-        total, adv, fml = self.D.generator_loss(
+        total, adv, fml = self._generator_criterion(
             disc_y_, disc_y if use_fm else None, loss_type=ga.get("loss_type", "mse"), average_by_discriminators=ga.get("average_by_discriminators", True),
             lambda_adv=cfg["lambda_adv"], lambda_feat_match=cfg.get("lambda_feat_match", 0.0) if use_fm else 0.0,
             fm_average_by_layers=fm.get("average_by_layers", True), fm_average_by_discriminators=fm.get("average_by_discriminators", True),
             fm_include_final_outputs=fm.get("include_final_outputs", False))
-        dis_loss, real_loss, fake_loss = self.D.discriminator_loss(disc_y_, disc_y, loss_type=da.get("loss_type", "mse"),
-                                                                   average_by_discriminators=da.get("average_by_discriminators", True))
+        dis_loss, real_loss, fake_loss = self._discriminator_criterion(disc_y_, disc_y, loss_type=da.get("loss_type", "mse"),
+                                                                       average_by_discriminators=da.get("average_by_discriminators", True))
         log.update({"eval/adversarial_loss": adv, "eval/generator_loss": aux_loss + total, "eval/real_loss": real_loss, "eval/fake_loss": fake_loss,
                     "eval/discriminator_loss": dis_loss})
         if use_fm:

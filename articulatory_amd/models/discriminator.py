@@ -314,6 +314,36 @@ class _SubDisc(torch.nn.Module):
     pass
 
 
+def _apply_spectral_norm(conv, eps=1e-12):
+    """torch.nn.utils.spectral_norm on a parameter holder (hifigan.py:440-448): ``weight`` becomes the parameter ``weight_orig`` plus the
+    power-iteration buffers ``weight_u`` (cout) / ``weight_v`` (cin * k), registered in torch's order (bias, weight_orig | weight_u, weight_v)."""
+    w = conv._parameters.pop("weight").detach()
+    conv.weight_orig = torch.nn.Parameter(w)
+    mat = w.reshape(w.shape[0], -1)
+    u = torch.nn.functional.normalize(torch.randn(mat.shape[0]), dim=0, eps=eps)
+    v = torch.nn.functional.normalize(torch.randn(mat.shape[1]), dim=0, eps=eps)
+    conv.register_buffer("weight_u", u)
+    conv.register_buffer("weight_v", v)
+    conv.sn_eps = eps
+
+
+def _spectral_weight(conv, training):
+    """The weight a spectrally normalised conv uses in THIS forward (torch.nn.utils.spectral_norm.SpectralNorm.compute_weight, one power
+    iteration): in training mode u, v are advanced in place first (under no_grad), then sigma = u . (W v) and weight = weight_orig / sigma,
+    differentiable with respect to weight_orig with u, v held constant.  A handful of tiny torch ops per layer; the result is handed to the
+    engine as a plain weight."""
+    w = conv.weight_orig
+    mat = w.reshape(w.shape[0], -1)
+    u, v = conv.weight_u, conv.weight_v
+    if training:
+        with torch.no_grad():
+            v.copy_(torch.nn.functional.normalize(torch.mv(mat.t(), u), dim=0, eps=conv.sn_eps))
+            u.copy_(torch.nn.functional.normalize(torch.mv(mat, v), dim=0, eps=conv.sn_eps))
+        u, v = u.clone(), v.clone()
+    sigma = torch.dot(u, torch.mv(mat, v))
+    return w / sigma
+
+
 def _slope(sub_params):
     """LeakyReLU slope of a scale / period discriminator's parameter dict.  A dict WITHOUT the key gets the sub-discriminator class's own
     default {"negative_slope": 0.1} (hifigan.py:331,517: the user's sub-dict replaces the multi-discriminator's default dict as a whole);
@@ -337,8 +367,9 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
                 raise NotImplementedError("discriminator activations: only LeakyReLU is built")
             if q.get("in_channels", 1) != 1 or q.get("out_channels", 1) != 1:
                 raise NotImplementedError("discriminators with in_channels / out_channels other than 1 are not built")
-        if pp.get("use_spectral_norm", False):
-            raise NotImplementedError("spectral norm on the period discriminators is not built")
+        self._spectral = bool(pp.get("use_spectral_norm", False))
+        if self._spectral and pp.get("use_weight_norm", True):
+            raise ValueError("Either use use_weight_norm or use_spectral_norm.")  # hifigan.py:390-391
         self._s_layers = scale_disc_layers(**sp)
         self._p_layers = period_disc_layers(**pp)
         if max(len(self._s_layers), len(self._p_layers)) > _native.DISC_MAX_LAYERS:
@@ -365,7 +396,9 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
             slope = _slope(pp)
             for L in self._p_layers:
                 conv = _ConvParams((L["cout"], L["cin"], L["k"], 1), L["cout"], bias=True)
-                if pp.get("use_weight_norm", True):
+                if self._spectral:
+                    _apply_spectral_norm(conv)
+                elif pp.get("use_weight_norm", True):
                     conv.apply_weight_norm()
                 else:
                     conv._parameters["bias"] = conv._parameters.pop("bias")
@@ -467,6 +500,27 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
             cached = self.__dict__["_raw_cache"] = (tuple(names), tensors)
         return cached
 
+    def _effective_parameters(self):
+        """(names, tensors) handed to the engine.  Without spectral norm: the raw parameters.  With it (period discriminators,
+        use_spectral_norm): every normalised conv contributes "<conv>.weight" = weight_orig / sigma, recomputed — and, in training mode, its
+        power iteration advanced — at EVERY call, as torch's forward pre-hook does for every ``D(x)`` of the reference."""
+        if not self._spectral:
+            return self._raw_parameters()
+        names, tensors = [], []
+        for mname, m in self.named_modules():
+            if not isinstance(m, _ConvParams):
+                continue
+            base = self._name_prefix + mname
+            if "weight_orig" in m._parameters:
+                names += [base + ".bias", base + ".weight"]
+                tensors += [m.bias, _spectral_weight(m, self.training)]
+            else:
+                for k in m._parameters:
+                    if m._parameters[k] is not None:
+                        names.append(base + "." + k)
+                        tensors.append(m._parameters[k])
+        return tuple(names), tensors
+
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
         self.__dict__["_raw_cache"] = None
@@ -507,6 +561,7 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         y_real is given, FeatureMatchLoss(D(y_fake), D(y_real)) -> (lambda_adv * (adv + lambda_feat_match * fm), adv, fm).  Defaults as
         the reference's loss modules (adversarial_loss.py:15-19, feat_match_loss.py:15-20)."""
         self._check(y_fake)
+        self._no_fused_spectral()
         self._native_handle()
         cfg = _loss_cfg(loss_type, average_by_discriminators, fm_average_by_layers, fm_average_by_discriminators, fm_include_final_outputs,
                         lambda_adv, lambda_feat_match)
@@ -517,10 +572,16 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         """DiscriminatorAdversarialLoss(D(y_fake), D(y_real)) in one autograd node (train.py:421-424) -> (real + fake, real, fake)."""
         self._check(y_fake)
         self._check(y_real)
+        self._no_fused_spectral()
         self._native_handle()
         cfg = _loss_cfg(loss_type, average_by_discriminators, True, True, False, 1.0, 0.0)
         names, tensors = self._raw_parameters()
         return _DiscriminatorLossFunction.apply(self, y_fake.detach(), y_real.detach(), cfg, names, *tensors)
+
+    def _no_fused_spectral(self):
+        if self._spectral:
+            raise NotImplementedError("spectral norm advances its power iteration at every D(x) of the reference (two different weight sets inside "
+                                      "one criterion): use forward(x, native=True) with articulatory_amd.losses (the Trainer does)")
 
     def _real_pass(self, y_real, params, stream):
         """D(y_real) of the generator step and of the discriminator step that follows it are the same computation (same batch, the
@@ -550,7 +611,7 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
             raise RuntimeError(f"Expected input of shape (B, 1, T), got {tuple(x.shape)}")
         self._native_handle()
         B, _, T = x.shape
-        names, tensors = self._raw_parameters()
+        names, tensors = self._effective_parameters()
         bufs = _DiscFunction.apply(self, x, names, *tensors)
         infos = self._output_infos(B, T)
         outs, i = [], 0

@@ -310,15 +310,21 @@ def disc_param_spec(**kw):
             if L["bias"]:
                 spec[base + ".bias"] = (L["cout"],)
     pp = p["period_discriminator_params"]
+    sn = pp.get("use_spectral_norm", False)
     wn = pp.get("use_weight_norm", True)
-    if pp.get("use_spectral_norm", False):
-        raise NotImplementedError("spectral norm on the period discriminators is not built")
+    if sn and wn:
+        raise ValueError("Either use use_weight_norm or use_spectral_norm.")  # hifigan.py:390-391
     for i, _period in enumerate(p["periods"]):
         layers = period_disc_layers(**pp)
         for l, L in enumerate(layers):
             base = f"mpd.discriminators.{i}." + (f"convs.{l}.0" if L["act"] else "output_conv")
             shape = (L["cout"], L["cin"], L["k"], 1)
-            if wn:  # a weight-normed module lists bias first (bias, weight_g, weight_v), a plain one weight, bias
+            if sn:  # torch.nn.utils.spectral_norm: bias, weight_orig (parameters), weight_u, weight_v (buffers: power-iteration vectors)
+                spec[base + ".bias"] = (L["cout"],)
+                spec[base + ".weight_orig"] = shape
+                spec[base + ".weight_u"] = (L["cout"],)
+                spec[base + ".weight_v"] = (L["cin"] * L["k"],)
+            elif wn:  # a weight-normed module lists bias first (bias, weight_g, weight_v), a plain one weight, bias
                 spec[base + ".bias"] = (L["cout"],)
                 spec[base + ".weight_g"] = (L["cout"], 1, 1, 1)
                 spec[base + ".weight_v"] = shape
@@ -333,7 +339,10 @@ def synth_disc_state_dict(discriminator_params: dict, seed: int = 4321, gain: fl
     spec = disc_param_spec(**discriminator_params)
     out = OrderedDict()
     for name, shape in spec.items():
-        if name.endswith(".weight_v") or name.endswith(".weight"):
+        if len(shape) == 1 and (name.endswith(".weight_u") or name.endswith(".weight_v")):  # spectral norm's unit vectors
+            v = uniform(seed, name, shape, -1.0, 1.0).astype(np.float64)
+            out[name] = (v / np.sqrt((v * v).sum())).astype(np.float32)
+        elif name.endswith(".weight_v") or name.endswith(".weight") or name.endswith(".weight_orig"):
             b = gain * np.sqrt(3.0 / int(np.prod(shape[1:])))
             out[name] = uniform(seed, name, shape, -b, b)
         elif name.endswith(".bias"):

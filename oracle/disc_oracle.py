@@ -45,6 +45,32 @@ def fold_disc_weight_norm(sd, dtype=torch.float32):
     return out
 
 
+def fold_disc_spectral_norm(sd, training=True, dtype=torch.float32, eps=1e-12):
+    """torch.nn.utils.spectral_norm (hifigan.py:440-448; one power iteration per forward in training mode): every "<conv>.weight_orig" with
+    its "<conv>.weight_u" / "<conv>.weight_v" becomes "<conv>.weight" = weight_orig / sigma.  Returns (folded tensors, {key: advanced u / v}).
+    weight_orig tensors that require grad stay in the graph (u, v are constants, as in torch)."""
+    out, state = OrderedDict(), {}
+    for k, v in sd.items():
+        t = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+        t = t.to(dtype) if not t.requires_grad else t
+        if k.endswith(".weight_u") or (k.endswith(".weight_v") and k[:-1] + "u" in sd):
+            continue
+        if k.endswith(".weight_orig"):
+            base = k[: -len("weight_orig")]
+            as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).detach().to(t.dtype)  # noqa: E731
+            u, vv = as_t(sd[base + "weight_u"]), as_t(sd[base + "weight_v"])
+            mat = t.reshape(t.shape[0], -1)
+            if training:
+                with torch.no_grad():
+                    vv = F.normalize(torch.mv(mat.t(), u), dim=0, eps=eps)
+                    u = F.normalize(torch.mv(mat, vv), dim=0, eps=eps)
+            state[base + "weight_u"], state[base + "weight_v"] = u, vv
+            out[base + "weight"] = t / torch.dot(u, torch.mv(mat, vv))
+        else:
+            out[k] = t
+    return out, state
+
+
 def scale_disc_forward(w, prefix, layers, x, slope):
     outs = []
     for l, L in enumerate(layers):

@@ -232,3 +232,39 @@ def test_mel_loss_oracle_vs_reference_golden(tag, mname):
     ref = float(gold[f"{tag}::mel::{mname}::loss::f32"])
     assert abs(float(loss.detach()) - ref) < 2e-6 * abs(ref)
     assert kinked_gradient_close(yh.grad.numpy(), gold[f"{tag}::mel::{mname}::dloss::f32"])
+
+
+# ---------------------------------------------------------------- spectral norm on the period discriminators (gold_disc_sn.npz)
+def test_spectral_norm_period_discriminators_oracle_vs_reference_golden():
+    """use_spectral_norm (hifigan.py:390-399, 440-448; torch.nn.utils.spectral_norm, one power iteration per training-mode forward): two
+    consecutive forwards — the power iteration advances between them —, the second one's gradients and the u / v buffers after each,
+    against the real reference (oracle/make_golden_disc_sn.py)."""
+    from oracle.make_golden_disc_sn import PERIODS, SN_PERIOD
+
+    gold = np.load(os.path.join(GOLDEN, "gold_disc_sn.npz"))
+    params = dict(scales=0, periods=PERIODS, period_discriminator_params=SN_PERIOD)
+    seed, B, T = int(gold["seed"]), int(gold["B"]), int(gold["T"])
+    sd = synth_disc_state_dict(params, seed=seed)
+    assert [k[4:] for k in sd] == [str(k) for k in gold["keys"]]
+    x = torch.from_numpy(uniform(seed, "x", (B, 1, T), -0.6, 0.6)).requires_grad_(True)
+    leaves = {k: torch.from_numpy(v).clone().requires_grad_(k.endswith(("weight_orig", "bias"))) for k, v in sd.items()}
+    for tag in ("1", "2"):
+        w, state = DO.fold_disc_spectral_norm(leaves, training=True)
+        for k, v in state.items():  # the advanced vectors are what the next forward starts from
+            leaves[k] = v
+            assert np.abs(v.numpy() - gold[f"state{tag}::{k[4:]}"]).max() < 2e-6, k
+        outs = DO.disc_forward(w, params, x)
+        for i, o in enumerate(outs):
+            for l, t in enumerate(o):
+                ref = gold[f"out{tag}::{i}.{l}"]
+                assert np.abs(t.detach().numpy() - ref).max() < 2e-6 * max(np.abs(ref).max(), 1e-3), (tag, i, l)
+    loss = 0.0
+    for i, o in enumerate(outs):
+        for l, t in enumerate(o):
+            loss = loss + (t * torch.from_numpy(uniform(seed, f"cot.{i}.{l}", tuple(t.shape), -1.0, 1.0) / np.sqrt(t[0].numel()))).sum()
+    loss.backward()
+    got = {k[4:]: v.grad for k, v in leaves.items() if v.requires_grad}
+    got["x"] = x.grad
+    for k, g in got.items():
+        ref = gold["grad::" + k]
+        assert np.abs(g.numpy() - ref).max() < 2e-5 * np.abs(ref).max(), k

@@ -336,6 +336,48 @@ def test_stand_alone_multi_scale_and_multi_period_classes(which):
         assert err < 2e-4 or cos < 1e-5, (k, err, cos)
 
 
+def test_spectral_norm_period_discriminators_vs_reference_golden():
+    """HiFiGANMultiPeriodDiscriminator with use_spectral_norm (hifigan.py:390-399, 440-448): the reference's state_dict layout (bias,
+    weight_orig, weight_u, weight_v), two training-mode forwards (one power iteration each), the second one's gradients with respect to
+    weight_orig / bias / the input, and the advanced u / v buffers, against the real reference (oracle/make_golden_disc_sn.py)."""
+    from articulatory_amd.models import HiFiGANMultiPeriodDiscriminator
+    from oracle.make_golden_disc_sn import PERIODS, SN_PERIOD
+
+    gold = np.load(os.path.join(GOLDEN, "gold_disc_sn.npz"))
+    params = dict(scales=0, periods=PERIODS, period_discriminator_params=SN_PERIOD)
+    seed, B, T = int(gold["seed"]), int(gold["B"]), int(gold["T"])
+    sd = {k[4:]: v for k, v in synth_disc_state_dict(params, seed=seed).items()}
+    d = HiFiGANMultiPeriodDiscriminator(periods=PERIODS, discriminator_params=SN_PERIOD)
+    assert list(d.state_dict()) == [str(k) for k in gold["keys"]]
+    d.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    d = d.cuda().train()
+    x = torch.from_numpy(uniform(seed, "x", (B, 1, T), -0.6, 0.6)).cuda().requires_grad_(True)
+    for tag in ("1", "2"):
+        outs = d(x)
+        for i, o in enumerate(outs):
+            for l, t in enumerate(o):
+                ref = gold[f"out{tag}::{i}.{l}"]
+                assert tuple(t.shape) == ref.shape and np.abs(t.detach().cpu().numpy() - ref).max() < 2e-5 * max(np.abs(ref).max(), 1e-3), (tag, i, l)
+        for k, v in d.state_dict().items():
+            if k.endswith(("weight_u", "weight_v")):
+                assert np.abs(v.cpu().numpy() - gold[f"state{tag}::{k}"]).max() < 2e-6, (tag, k)
+    loss = 0.0
+    for i, o in enumerate(outs):
+        for l, t in enumerate(o):
+            loss = loss + (t * torch.from_numpy(uniform(seed, f"cot.{i}.{l}", tuple(t.shape), -1.0, 1.0) / np.sqrt(t[0].numel())).cuda()).sum()
+    loss.backward()
+    for k, p in list(d.named_parameters()) + [("x", x)]:
+        ref = gold["grad::" + k]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() < TOL * np.abs(ref).max(), k
+    d.eval()  # eval mode: no power iteration, the buffers stay
+    before = {k: v.clone() for k, v in d.state_dict().items() if k.endswith("weight_u")}
+    with torch.no_grad():
+        d(x)
+    assert all(torch.equal(v, d.state_dict()[k]) for k, v in before.items())
+    with pytest.raises(NotImplementedError, match="spectral norm"):
+        d.discriminator_loss(x.detach(), x.detach())
+
+
 SMALL_SCALE = {"in_channels": 1, "out_channels": 1, "kernel_sizes": [15, 41, 5, 3], "channels": 16, "max_downsample_channels": 64, "max_groups": 4,
                "bias": True, "downsample_scales": [4, 4, 1], "nonlinear_activation": "LeakyReLU", "nonlinear_activation_params": {"negative_slope": 0.1}}
 SMALL_PERIOD = {"in_channels": 1, "out_channels": 1, "kernel_sizes": [5, 3], "channels": 8, "downsample_scales": [3, 3, 1], "max_downsample_channels": 64,

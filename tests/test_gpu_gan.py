@@ -302,3 +302,37 @@ def test_fused_and_foreach_optimizers_give_the_same_iterations(fused):
         for k in b:
             assert abs(a[k] - b[k]) <= 2e-4 * max(abs(b[k]), 1e-3), (fused, k, a[k], b[k])
     assert logs[2]["train/fake_loss"] != logs[0]["train/fake_loss"]
+
+
+def test_iteration_with_spectrally_normalised_period_discriminators():
+    """A discriminator with use_spectral_norm on its period sub-networks through Trainer.train_step: the criterion falls back from the
+    fused nodes to one native forward per D(x) (the reference advances the power iteration at each of them) — the first iteration's
+    generator-side losses against the CPU oracle, and both networks move."""
+    from oracle.make_golden_disc_sn import SN_PERIOD
+
+    config = make_config(True)
+    config["discriminator_params"] = dict(SMALL, period_discriminator_params=SN_PERIOD)
+    t = Trainer(config, torch.device("cuda:0"))
+    gp, dp = config["generator_params"], config["discriminator_params"]
+    gsd, dsd = synth_state_dict(gp, seed=31), synth_disc_state_dict(dp, seed=32)
+    t.G.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()})
+    t.D.load_state_dict({k: torch.from_numpy(v) for k, v in dsd.items()})
+    data = SyntheticPairs(4, 60, 13, 20, seed=3)
+    batch = WindowCollater(400, 20, 512, np.random.default_rng(5))([data[i] for i in range(4)])
+    t.steps = 1
+    log = {k: float(v) for k, v in t.train_step(batch).items()}
+    with torch.no_grad():
+        y_ = O.generator_forward(O.fold_weight_norm(gsd), gp, batch["x"], batch["ar"])
+        state = {k: torch.from_numpy(v) for k, v in dsd.items()}
+        w1, st = DO.fold_disc_spectral_norm(state, training=True)       # D(fake): first power iteration
+        p_ = DO.disc_forward(w1, dp, torch.cat([batch["ar"], y_], 2))
+        state.update(st)
+        w2, st = DO.fold_disc_spectral_norm(state, training=True)       # D(real): second
+        p = DO.disc_forward(w2, dp, torch.cat([batch["ar"], batch["y"]], 2))
+        adv, fm = DO.gen_adv_loss(p_, False), DO.feat_match_loss(p_, p, False, False, False)
+    assert abs(log["train/adversarial_loss"] - float(adv)) < 1e-4 * abs(float(adv))
+    assert abs(log["train/feature_matching_loss"] - float(fm)) < 1e-4 * abs(float(fm))
+    assert all(np.isfinite(v) for v in log.values())
+    now = t.D.state_dict()
+    k = "mpd.discriminators.0.convs.0.0.weight_orig"
+    assert not np.allclose(now[k].cpu().numpy(), dsd[k]) and not np.allclose(now[k[:-4] + "u"].cpu().numpy(), dsd[k[:-4] + "u"])
