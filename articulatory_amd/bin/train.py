@@ -472,13 +472,19 @@ def main(argv=None):
         logging.info(f"Successfully resumed from {a.resume}.")
     max_steps = a.max_steps if a.max_steps is not None else config["train_max_steps"]
     t0, n0 = time.time(), trainer.steps
+    pending = []
     while trainer.steps < max_steps:
         if sampler is not None:
             sampler.set_epoch(trainer.epochs)
         for batch in loader:
-            log = trainer.train_step(batch)
-            for k, v in log.items():
-                trainer.total_train_loss[k] += float(v)
+            # the step's losses stay device scalars until the log line needs them: no host synchronisation per step (the reference's
+            # ``.item()`` per loss per step, train.py:286-437, is one), so the host keeps enqueueing ahead of the GPU across iterations
+            pending.append(trainer.train_step(batch))
+            if trainer.steps % config.get("log_interval_steps", 100) == 0 or trainer.steps >= max_steps:
+                for log in pending:
+                    for k, v in log.items():
+                        trainer.total_train_loss[k] += float(v)
+                pending = []
             if trainer.steps % config.get("log_interval_steps", 100) == 0 and rank == 0:
                 n = config.get("log_interval_steps", 100)
                 logging.info(f"(Steps: {trainer.steps}) " + ", ".join(f"{k} = {v / n:.4f}" for k, v in sorted(trainer.total_train_loss.items()))

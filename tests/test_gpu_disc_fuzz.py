@@ -1,5 +1,8 @@
 """Random discriminator configurations (kernel sizes, strides, groups incl. group widths that are no multiple of 4, pooling, periods,
-weight norm on / off, odd lengths) on a MI355X against the CPU oracle: every layer output and every gradient.  ``pytest -m gpu``."""
+weight norm on / off, odd lengths) on a MI355X against the CPU oracle: every layer output and every gradient.  ``pytest -m gpu``;
+HIFICAR_FUZZ_CASES raises the number of cases (default 16)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,7 +12,7 @@ from articulatory_amd.utils.synth import synth_disc_state_dict, uniform
 from oracle import disc_oracle as DO
 
 pytestmark = pytest.mark.gpu
-N_CASES = 16
+N_CASES = max(16, int(os.environ.get("HIFICAR_FUZZ_CASES", "16")))
 
 
 def random_case(i):
