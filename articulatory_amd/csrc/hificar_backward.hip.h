@@ -529,6 +529,53 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
     }
 }
 
+// The same reduction for the GEMM form of a conv with KT taps (discriminators: partial [split][g][a = tap * gemm_cin + c], gemm_cin % 4 == 0):
+// a thread owns 4 consecutive c of one g for ALL taps, so its 4 * KT results are CONTIGUOUS in dst[(co * gemm_cin + c) * KT + tap] — whole
+// 16-byte stores, a wave writes one contiguous run — where the generic kernel above scatters 4-byte stores KT floats apart (measured 1.8 TB/s
+// on the 1024 x 5120 layers, which this form is for).  Same summation order per element as the generic kernel: bit-identical results.
+template <int KT>
+__global__ __launch_bounds__(256) void wreduce_gemm_kernel(const WreducePair pair) {
+    const int zi = blockIdx.y % pair.zg;  // (one entry per launch in this form)
+    const WreduceParams& p = pair.r[0];
+    const float* const partial_p = p.partial + (size_t)zi * pair.zs_partial[0];
+    float* const dst_p = p.dst + (size_t)zi * pair.zs_dst[0];
+    const int c4n = p.gemm_cin >> 2;
+    const int total = p.cout * c4n;
+    const size_t stride4 = ((size_t)p.gpad * p.apad) >> 2;  // one split's partial, in float4
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c4 = (i % c4n) * 4, co = i / c4n;
+        const float4* src = reinterpret_cast<const float4*>(partial_p + (size_t)co * p.apad + c4);
+        float o[4][KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const float4* st = src + ((t * p.gemm_cin) >> 2);
+            float4 s[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int sp = 0;
+            for (; sp + 4 <= p.nsplit; sp += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = st[(size_t)(sp + j) * stride4];
+                    s[j].x += v.x, s[j].y += v.y, s[j].z += v.z, s[j].w += v.w;
+                }
+            }
+            for (int j = 0; sp < p.nsplit; ++sp, ++j) {
+                const float4 v = st[(size_t)sp * stride4];
+                s[j].x += v.x, s[j].y += v.y, s[j].z += v.z, s[j].w += v.w;
+            }
+            o[0][t] = (s[0].x + s[1].x) + (s[2].x + s[3].x);
+            o[1][t] = (s[0].y + s[1].y) + (s[2].y + s[3].y);
+            o[2][t] = (s[0].z + s[1].z) + (s[2].z + s[3].z);
+            o[3][t] = (s[0].w + s[1].w) + (s[2].w + s[3].w);
+        }
+        float4* d4 = reinterpret_cast<float4*>(dst_p + ((size_t)co * p.gemm_cin + c4) * KT);  // 16 * KT-byte aligned
+        const float* of = &o[0][0];
+#pragma unroll
+        for (int q = 0; q < KT; ++q) d4[q] = make_float4(of[4 * q], of[4 * q + 1], of[4 * q + 2], of[4 * q + 3]);
+    }
+}
+
 // db[co] = sum over splits (and over the phases of a ConvTranspose1d) of the column sums
 struct BreduceParams {
     const float* partial;
