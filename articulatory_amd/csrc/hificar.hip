@@ -80,6 +80,7 @@ struct hificar_handle {
     double mi1_penalty = 1.05;     // cost factor of 32-row tiles in the exact-fp32 tile choice (they re-stream the weights most often: L2-bound when
                                    // K is long).  The discriminator engine raises it: its launches overlap on several streams, so a nearly
                                    // empty last round of taller tiles costs little there, while the L2 traffic of short tiles is shared by all
+    bool pair_small = true;        // HIFICAR_PAIR_SMALL: 128-row fused pair tiles at C = 32 for mid-size launches (pair_small_tiles)
     int ksplit = 1;                // HIFICAR_KSPLIT: 0 = never use the split-K conv form, 1 = when it is estimated faster (default), 2 = always
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
     int cin_pad = 0;  // padded input-conv channels
@@ -262,6 +263,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     h->cfg = c;
     if (const char* e = getenv("HIFICAR_PROFILE_DETAIL")) h->profile_detail = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_PAIR")) h->use_pair = atoi(e) != 0;
+    if (const char* e = getenv("HIFICAR_PAIR_SMALL")) h->pair_small = atoi(e) != 0;  // (A/B runs)
     if (const char* e = getenv("HIFICAR_LPT")) h->use_lpt = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_KSPLIT")) h->ksplit = atoi(e);
     {
@@ -587,6 +589,8 @@ static int engine_setup(hificar_handle* h) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<4, 2, 2, 4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<4, 4, 1, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<1, 4, 1, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define HIFICAR_SET_ATTR(mi, wm, wn, nc)         \
     HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>())); \
@@ -1083,6 +1087,17 @@ struct PairIOB {
     char* ys;         // split copy of LeakyReLU(y) for the next pair (must NOT alias xs: neighbouring tiles read xs halos), or null
 };
 
+// Launches with too few 512-row tiles to fill the chip at C = 32 in exact fp32 (batch 8 with chunks of 25 frames): 128-row tiles (MI = 1)
+// — a tile's serial MFMA chain is a quarter as long and four times as many workgroups have work, so the fused pair beats two dependent
+// launches there (measured batch 8: +2.7 % end to end).  Below ~8000 rows (batch 1: 2000) the split-K layer-by-layer launches, whose chains
+// are shorter still, stay ahead (measured batch 1: -3.6 % with the fused form), so those keep running layer by layer.
+static bool pair_small_tiles(const hificar_handle* h, int C, int k2, int nseq, int rows) {
+    // (HIFICAR_KSPLIT=0, the batch-invariant mode: no launch-size-dependent forms at small sizes)
+    if (!h->pair_small || h->ksplit == 0 || C != 32 || h->precision != HIFICAR_PREC_F32 || nseq <= 0 || (long long)nseq * rows < 8000) return false;
+    const int tmo = 4 * 4 * 32 - (k2 - 1);
+    return 3LL * nseq * ((rows + tmo - 1) / tmo) < h->num_cus;
+}
+
 // nseq / rows: the launch the pair would run in (0 / 0: only the static conditions)
 static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const ConvLayer& b, int nseq = 0, int rows = 0) {
     if (!(h->use_pair && a.d_w16c && b.d_w16c && a.d_w32c && b.d_w32c && a.cin == b.cin && a.ntaps >= 2 &&
@@ -1098,6 +1113,7 @@ static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const Con
         // CUs idle behind long serial tiles: small batches run layer by layer.  (ii) Tile quantisation: 1000 rows at k = 11 need 5
         // tiles of 256 (28 % extra conv1 work); the exact-fp32 arithmetic gains little from fusion (its layer-by-layer kernels are
         // matrix-pipe-bound already), so it only fuses when the waste is small; the bf16x3 ones are memory-path-bound and gain more.
+        if (pair_small_tiles(h, C, b.ntaps, nseq, rows)) return true;
         const int tmo = TMc - (b.ntaps - 1);
         const long long tiles = (long long)nseq * ((rows + tmo - 1) / tmo);
         if (3 * tiles < h->num_cus) return false;
@@ -1110,7 +1126,9 @@ static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const Con
 static int launch_pair(hificar_handle* h, const ConvLayer* const* l1, const ConvLayer* const* l2, int nbr, int nseq, int rows,
                               const PairIOB* io, float slope, const Ragged& rg, hipStream_t stream) {
     const int C = l1[0]->cin;
-    const int MI = 4, WM = C == 64 ? 2 : 4;
+    bool small = true;
+    for (int b = 0; b < nbr; ++b) small = small && pair_small_tiles(h, C, l2[b]->ntaps, nseq, rows);
+    const int MI = small ? 1 : 4, WM = C == 64 ? 2 : 4;
     const int TMc = WM * MI * 32, RB = C * 4;
     const bool f32 = h->precision == HIFICAR_PREC_F32;
     PairParams pp;
@@ -1172,6 +1190,7 @@ static int launch_pair(hificar_handle* h, const ConvLayer* const* l1, const Conv
     ProfScope prof(h, stream, kname, flops, bytes);
     if (f32) {
         if (C == 64) hipLaunchKernelGGL((conv_pair_f32_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
+        else if (small) hipLaunchKernelGGL((conv_pair_f32_kernel<1, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
         else hipLaunchKernelGGL((conv_pair_f32_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
     } else {
         if (C == 64) hipLaunchKernelGGL((conv_pair_bf16x3_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);

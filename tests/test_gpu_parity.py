@@ -492,6 +492,38 @@ def test_fused_pair_kernel_matches_layer_by_layer(monkeypatch, prec):
         assert not any(s["name"].startswith("conv_pair") for s in g.profile_end())
 
 
+def test_small_tile_fused_pair_at_mid_size_launches(monkeypatch):
+    """Exact fp32, C = 32, a launch too small for 512-row fused tiles but above ~8000 rows (batch 8 x 25 frames = 16000): the 128-row
+    fused pair (conv_pair_f32_kernel<1,4,1,2>) runs; HIFICAR_PAIR_SMALL=0 runs the same launches layer by layer.  Both against the
+    oracle and each other; batch 1 (2000 rows) stays layer by layer (test above)."""
+    params = dict(E2W_PARAMS)
+    B, T = 8, 25
+    c = torch.from_numpy(synth_features(B, T, 13, seed=321)).permute(0, 2, 1).contiguous().cuda()
+    ar = torch.from_numpy(synth_features(B, 512, 1, seed=322)[:, :, 0] * 0.3).reshape(B, 1, 512).cuda()
+    lens = [T, 9, 1, 0, 25, 13, 24, 2]
+    outs, ragged = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HIFICAR_PAIR_SMALL", flag)  # read by hificar_create
+        g, w = make(params, "f32")
+        with torch.no_grad():
+            outs[flag] = g(c, ar=ar).cpu()
+            ragged[flag] = g(c, ar=ar, lengths=lens).cpu()
+            g.profile_begin()
+            g(c, ar=ar)
+            names = {s["name"] for s in g.profile_end()}
+        assert ("conv_pair_f32_kernel<1,4,1,2>" in names) == (flag == "1"), names
+    with torch.no_grad():
+        ref = O.generator_forward(w, params, c.cpu(), ar.cpu())
+    assert rel_err(outs["1"].numpy(), ref.numpy()) < TOLS["f32"]
+    assert rel_err(outs["1"].numpy(), outs["0"].numpy()) < TOLS["f32"]
+    assert rel_err(ragged["1"].numpy(), ragged["0"].numpy()) < TOLS["f32"]
+    for b, n in enumerate(lens):  # every utterance of the ragged batch as if it were alone in it (rounding: other tile shapes)
+        if n:
+            with torch.no_grad():
+                alone = O.generator_forward(w, params, c[b:b + 1, :, :n].cpu(), ar[b:b + 1].cpu())
+            assert rel_err(ragged["1"][b, :, :80 * n].numpy(), alone[0].numpy()) < TOLS["f32"], (b, n)
+
+
 def test_repeated_runs_are_bit_identical(car):
     """Race screen for the LDS ring / out-buffer hand-offs of the persistent kernels: 12 back-to-back syntheses of the
     same batch (different tile timing every time) must give bit-identical waveforms."""
