@@ -85,6 +85,8 @@ SYMBOLS = (
     "hificar_disc_bucket_folded_range",
     "hificar_disc_set_bucket_callback",
     "hificar_disc_weight_norm_backward_bucket",
+    "hificar_disc_set_grad_accumulate",
+    "hificar_disc_set_grad_scale",
     "hificar_destroy",
     "hificar_last_error",
     "hificar_version",
@@ -353,6 +355,10 @@ def load_library():
     lib.hificar_disc_set_bucket_callback.restype = ctypes.c_int
     lib.hificar_disc_weight_norm_backward_bucket.argtypes = [vp, vp, vp, ctypes.c_int, vp]
     lib.hificar_disc_weight_norm_backward_bucket.restype = ctypes.c_int
+    lib.hificar_disc_set_grad_accumulate.argtypes = [vp, ctypes.c_int]
+    lib.hificar_disc_set_grad_accumulate.restype = ctypes.c_int
+    lib.hificar_disc_set_grad_scale.argtypes = [vp, vp]
+    lib.hificar_disc_set_grad_scale.restype = ctypes.c_int
     lib.hificar_destroy.argtypes = [vp]
     lib.hificar_destroy.restype = None
     lib.hificar_last_error.argtypes = []

@@ -456,6 +456,7 @@ struct WreduceParams {
     int tap_k[kMaxPhase][kMaxTaps];
     int flip;  // 0
     int gemm_cin;  // > 0: GEMM form of a conv (discriminators): a = tap * gemm_cin + c -> dst[(co * gemm_cin + c) * K + tap]
+    int accumulate;  // 1: dst += the reduced gradient (a second backward pass into the same buffer) instead of dst = it
     int poly_s, poly_cin;  // poly_s > 0: polyphase-input form of a strided conv (cout, poly_cin, K): (tap q, a = r * poly_cin + c) -> kernel index
                            // poly_s * q + r, dst[(co * poly_cin + c) * K + poly_s * q + r] (indices >= K carry zero weights: skipped)
 };
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
                 if (rr >= p.poly_s || kk >= p.K) continue;
                 d = ((size_t)co * p.poly_cin + c) * p.K + kk;
             }
-            dst_p[d] = o[j];
+            dst_p[d] = p.accumulate ? dst_p[d] + o[j] : o[j];
         }
     }
 }
@@ -572,7 +573,14 @@ __global__ __launch_bounds__(256) void wreduce_gemm_kernel(const WreducePair pai
         float4* d4 = reinterpret_cast<float4*>(dst_p + ((size_t)co * p.gemm_cin + c4) * KT);  // 16 * KT-byte aligned
         const float* of = &o[0][0];
 #pragma unroll
-        for (int q = 0; q < KT; ++q) d4[q] = make_float4(of[4 * q], of[4 * q + 1], of[4 * q + 2], of[4 * q + 3]);
+        for (int q = 0; q < KT; ++q) {
+            float4 v = make_float4(of[4 * q], of[4 * q + 1], of[4 * q + 2], of[4 * q + 3]);
+            if (p.accumulate) {
+                const float4 u = d4[q];
+                v.x = u.x + v.x, v.y = u.y + v.y, v.z = u.z + v.z, v.w = u.w + v.w;
+            }
+            d4[q] = v;
+        }
     }
 }
 
@@ -581,6 +589,7 @@ struct BreduceParams {
     const float* partial;
     float* dst;
     int nsplit, pitch, cout, cout_pad, n_phase;
+    int accumulate;  // as WreduceParams::accumulate
 };
 
 // 16 channels x 16 strands per workgroup: strand j sums terms j, j + 16, ... (four loads in flight), the strands are added in a fixed order
@@ -620,7 +629,7 @@ __global__ __launch_bounds__(256) void breduce_kernel(const BreducePair pair) {
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) s += red[j][cl];
-        p.dst[co] = s;
+        p.dst[co] = p.accumulate ? p.dst[co] + s : s;
     }
 }
 
@@ -1188,8 +1197,11 @@ __global__ __launch_bounds__(256) void param_gather_kernel(const ParamJob* jobs,
 }
 
 // (wg0: first workgroup of the table this launch covers — a bucket of jobs launches start[lo] .. start[hi] - 1 only)
-__global__ __launch_bounds__(256) void wn_backward_kernel(const ParamJob* jobs, const int* start, int njobs, const float* grads, float* raw, int wg0) {
+// scale: device scalar every raw gradient is multiplied by (the upstream gradient of a scalar loss), or null
+__global__ __launch_bounds__(256) void wn_backward_kernel(const ParamJob* jobs, const int* start, int njobs, const float* grads, float* raw, int wg0,
+                                                          const float* scale) {
     __shared__ float red[4];
+    const float sc = scale ? *scale : 1.f;
     const int wg = (int)blockIdx.x + wg0;
     const int j = find_job(start, njobs, wg);
     const ParamJob q = jobs[j];
@@ -1199,7 +1211,7 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const ParamJob* jobs, 
         const int i = r * 1024 + threadIdx.x;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i + u * 256 < q.cols) raw[q.dv + i + u * 256] = dw[i + u * 256];
+            if (i + u * 256 < q.cols) raw[q.dv + i + u * 256] = scale ? dw[i + u * 256] * sc : dw[i + u * 256];
         return;
     }
     const float* v = q.v + (size_t)r * q.cols;
@@ -1214,9 +1226,13 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const ParamJob* jobs, 
     dot = wg_sum256(dot, red);
     const float n = sqrtf(ss), g = q.g[r];
     const float a = g / n, b = g * dot / (n * ss);
-    if (threadIdx.x == 0) raw[q.dg + r] = dot / n;
+    if (threadIdx.x == 0) raw[q.dg + r] = scale ? (dot / n) * sc : dot / n;
     float* dv = raw + q.dv + (size_t)r * q.cols;
-    for (int c = threadIdx.x; c < q.cols; c += 256) dv[c] = a * dw[c] - b * v[c];
+    if (scale) {
+        for (int c = threadIdx.x; c < q.cols; c += 256) dv[c] = (a * dw[c] - b * v[c]) * sc;
+    } else {
+        for (int c = threadIdx.x; c < q.cols; c += 256) dv[c] = a * dw[c] - b * v[c];
+    }
 }
 
 }  // namespace hificar

@@ -252,14 +252,16 @@ class _DiscriminatorLossFunction(torch.autograd.Function):
             ws, woff = _aligned(wsb // 4, dev)
             nfold = int(lib.hificar_disc_grad_floats(handle))
             raw = torch.zeros(int(lib.hificar_disc_raw_grad_floats(handle)), dtype=torch.float32, device=dev)
-            folded, reducer, cb, errors = [], None, None, []
+            reducer, cb, errors = None, None, []
+            # ONE folded-gradient buffer: the second pass adds to what the first left (hificar_disc_set_grad_accumulate), and the weight-norm
+            # chain rule multiplies by the upstream gradient while it writes (hificar_disc_set_grad_scale): no add pass, no scaling pass
+            g = torch.zeros(nfold, dtype=torch.float32, device=dev)
+            g_total = g_total.to(torch.float32).contiguous()
             for mode, ps, (d, doff) in zip((1, 2), ctx.passes, ctx.douts):
-                g = torch.zeros(nfold, dtype=torch.float32, device=dev)
-                folded.append(g)
                 if mode == 2 and module._grad_sync is not None:
                     # data-parallel training: one gradient bucket per sub-discriminator.  During the SECOND pass libhificar calls back as
-                    # each sub-network's gradients are enqueued on its side stream: there the first pass's share is added, the weight-norm
-                    # chain rule runs, and the bucket's all-reduce (RCCL over xGMI) starts while the other sub-networks still compute.
+                    # each sub-network's gradients (both passes' sum by then) are enqueued on its side stream: there the weight-norm chain
+                    # rule runs and the bucket's all-reduce (RCCL over xGMI) starts while the other sub-networks still compute.
                     from ..utils.buckets import BucketReducer, bucket_ranges
 
                     group, average = module._grad_sync
@@ -268,18 +270,12 @@ class _DiscriminatorLossFunction(torch.autograd.Function):
                     ranges, total = bucket_ranges(ids, [int(np.prod(sh)) for sh in ctx.shapes], nb)
                     assert total == raw.numel()
                     reducer = BucketReducer(raw, ranges, group, average)
-                    g_fake, g_real = folded
 
                     def on_bucket(bucket, bstream, _user):
                         try:
-                            o, n = ctypes.c_int64(), ctypes.c_int64()
-                            _native.check(lib.hificar_disc_bucket_folded_range(handle, bucket, ctypes.byref(o), ctypes.byref(n)), "hificar_disc_bucket_folded_range")
                             with torch.cuda.stream(torch.cuda.ExternalStream(bstream, device=dev)):
-                                g_real[o.value:o.value + n.value].add_(g_fake[o.value:o.value + n.value])
-                                _native.check(lib.hificar_disc_weight_norm_backward_bucket(handle, g_real.data_ptr(), raw.data_ptr(), bucket,
+                                _native.check(lib.hificar_disc_weight_norm_backward_bucket(handle, g.data_ptr(), raw.data_ptr(), bucket,
                                                                                            ctypes.c_void_p(bstream)), "hificar_disc_weight_norm_backward_bucket")
-                                for off_, n_ in ranges[bucket]:
-                                    raw[off_:off_ + n_].mul_(g_total)
                                 reducer.reduce(bucket)
                         except BaseException as e:  # an exception must not cross the C frames: re-raised below
                             errors.append(e)
@@ -287,20 +283,27 @@ class _DiscriminatorLossFunction(torch.autograd.Function):
                     cb = _native.BUCKET_FN(on_bucket)
                     _native.check(lib.hificar_disc_set_bucket_callback(handle, cb, None), "hificar_disc_set_bucket_callback")
                 try:
+                    _native.check(lib.hificar_disc_set_grad_accumulate(handle, 1 if mode == 2 else 0), "hificar_disc_set_grad_accumulate")
+                    if cb is not None:  # (the bucket callback runs the weight-norm chain rule during this pass)
+                        _native.check(lib.hificar_disc_set_grad_scale(handle, g_total.data_ptr()), "hificar_disc_set_grad_scale")
                     rc = lib.hificar_disc_backward_flat(handle, d.data_ptr() + 4 * doff, mode, 0, 0, B, T, ps.ptr, ps.nbytes, g.data_ptr(), None,
                                                         ws.data_ptr() + 4 * woff, wsb, stream)
                 finally:
+                    lib.hificar_disc_set_grad_accumulate(handle, 0)
                     if cb is not None:
                         lib.hificar_disc_set_bucket_callback(handle, _native.BUCKET_FN(), None)
+                        lib.hificar_disc_set_grad_scale(handle, None)
                 _native.check(rc, "hificar_disc_backward_flat")
                 if errors:
                     raise errors[0]
             if reducer is not None:
                 reducer.finish()
             else:
-                grads = folded[0].add_(folded[1])
-                _native.check(lib.hificar_disc_weight_norm_backward(handle, grads.data_ptr(), raw.data_ptr(), stream), "hificar_disc_weight_norm_backward")
-                raw.mul_(g_total)
+                try:
+                    _native.check(lib.hificar_disc_set_grad_scale(handle, g_total.data_ptr()), "hificar_disc_set_grad_scale")
+                    _native.check(lib.hificar_disc_weight_norm_backward(handle, g.data_ptr(), raw.data_ptr(), stream), "hificar_disc_weight_norm_backward")
+                finally:
+                    lib.hificar_disc_set_grad_scale(handle, None)
         gw, off = [], 0
         for shape in ctx.shapes:
             n = int(np.prod(shape))

@@ -362,6 +362,13 @@ int hificar_disc_raw_param_bucket(const hificar_disc* d, int i);
 int hificar_disc_bucket_folded_range(const hificar_disc* d, int bucket, int64_t* offset, int64_t* numel);
 int hificar_disc_set_bucket_callback(hificar_disc* d, hificar_bucket_fn fn, void* user);
 int hificar_disc_weight_norm_backward_bucket(hificar_disc* d, const float* grads, float* raw_grads, int bucket, void* stream);
+/* The discriminator update backpropagates two passes (real, fake: train.py:405-437 sums their losses).  on != 0: the following
+ * hificar_disc_backward* calls ADD their parameter gradients to what `grads` holds instead of overwriting it, so the second pass lands in
+ * the first pass's buffer (no second buffer, no add pass).  scale_device: device scalar (or NULL) that the following
+ * hificar_disc_weight_norm_backward[_bucket] calls multiply every raw gradient by while writing it — autograd's upstream gradient of the
+ * scalar loss.  Both are per-handle switches; the caller resets them (0 / NULL) after the step. */
+int hificar_disc_set_grad_accumulate(hificar_disc* d, int on);
+int hificar_disc_set_grad_scale(hificar_disc* d, const float* scale_device);
 size_t hificar_disc_backward_workspace_bytes(const hificar_disc* d, int B, int T);
 int hificar_disc_output_count(const hificar_disc* d);
 int hificar_disc_output_info(const hificar_disc* d, int B, int T, int i, hificar_disc_output* out);

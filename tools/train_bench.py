@@ -63,7 +63,7 @@ if a.profile:
     st = g.profile_end()
     tot = sum(s["total_ms"] for s in st)
     print(f"kernel time {tot:.2f} ms per step")
-    for s in st[:14]:
+    for s in st[: int(os.environ.get("TRAIN_BENCH_ROWS", "14"))]:
         print(f"  {s['name']:44s} {s['launches']:4d} launches {s['total_ms']:8.3f} ms  {s['flops'] / max(s['total_ms'], 1e-9) / 1e9:7.1f} TF-alg")
 if a.torch_profile:
     from torch.profiler import ProfilerActivity, profile
