@@ -158,13 +158,13 @@ def test_fused_criterion_vs_reference_values_and_unfused_gradients(tag, loss_typ
         close(r, f"loss::dis_real::{loss_type}::{int(avg)}")
         close(f, f"loss::dis_fake::{loss_type}::{int(avg)}")
         d.zero_grad(set_to_none=True)
-        tot.backward()
+        (0.75 * tot).backward()  # (an upstream gradient other than 1: applied inside the weight-norm chain rule, hificar_disc_set_grad_scale)
         got = {k: q.grad.clone() for k, q in d.named_parameters()}
         d.zero_grad(set_to_none=True)
         p = d(real, native=True)
         p_ = d(torch.from_numpy(xh_np).cuda(), native=True)
         rr, ff = NL.discriminator_adversarial_loss(p_, p, avg, loss_type)
-        (rr + ff).backward()
+        (0.75 * (rr + ff)).backward()
         bad = {k: rel_err_t(got[k], q.grad) for k, q in d.named_parameters()}
         bad = {k: v for k, v in bad.items() if not v < 5e-5}
         assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
