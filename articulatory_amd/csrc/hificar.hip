@@ -128,6 +128,19 @@ struct hificar_handle {
         size_t cap = 0, used = 0;
     };
     std::vector<Arena> arenas;
+    // device copies of the batched-reduction tables of the backward passes (flush_reduce, hificar_train.hip.inc), cached by content: in steady
+    // state a training iteration re-uses the tables of the iteration before (same buffers from the caller's caching allocator) without any upload
+    struct ReduceSlot {
+        char* d = nullptr;
+        char* h = nullptr;
+        size_t bytes = 0;
+        unsigned long long hash = 0, stamp = 0;
+        hipEvent_t ev = nullptr;  // recorded behind the last launch that reads the slot
+        hipEvent_t up = nullptr;  // recorded behind the upload
+        hipStream_t up_stream = nullptr;
+    };
+    std::vector<ReduceSlot> rslots;
+    unsigned long long rstamp = 0;
     // every call's work is ordered behind the previous call's even when the caller switches streams (the schedules, the packed
     // step table and the workspace are shared state of the handle)
     hipStream_t last_stream = nullptr;
@@ -411,6 +424,12 @@ extern "C" void hificar_destroy(hificar_handle* h) {
         (void)hipHostFree(a.h);
     }
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
+    for (auto& r : h->rslots) {
+        if (r.d) (void)hipFree(r.d);
+        if (r.h) (void)hipHostFree(r.h);
+        if (r.ev) (void)hipEventDestroy(r.ev);
+        if (r.up) (void)hipEventDestroy(r.up);
+    }
     delete h;
 }
 

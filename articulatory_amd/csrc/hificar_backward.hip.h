@@ -467,8 +467,9 @@ struct WreducePair {
     long long zs_partial[2], zs_dst[2];
 };
 
-__global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
-    const int e = blockIdx.y / pair.zg, zi = blockIdx.y % pair.zg;
+// (bx / gx / by: the workgroup's position in the launch's own grid, or in its share of a batched launch — reduce_multi_kernel)
+__device__ __forceinline__ void wreduce_body(const WreducePair& pair, int bx, int gx, int by) {
+    const int e = by / pair.zg, zi = by % pair.zg;
     const WreduceParams& p = pair.r[e];
     const float* const partial_p = p.partial + (size_t)zi * pair.zs_partial[e];
     float* const dst_p = p.dst + (size_t)zi * pair.zs_dst[e];
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
     const int a4n = p.apad >> 2;
     const int total4 = p.ntaps * p.gpad * a4n;
     const size_t total = (size_t)total4 * 4;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < total4; i += gx * 256) {
         const int a = (i % a4n) * 4;
         const int r = i / a4n;
         const int g = r % p.gpad, tap = r / p.gpad;
@@ -530,20 +531,22 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) {
     }
 }
 
+__global__ __launch_bounds__(256) void wreduce_kernel(const WreducePair pair) { wreduce_body(pair, blockIdx.x, gridDim.x, blockIdx.y); }
+
 // The same reduction for the GEMM form of a conv with KT taps (discriminators: partial [split][g][a = tap * gemm_cin + c], gemm_cin % 4 == 0):
 // a thread owns 4 consecutive c of one g for ALL taps, so its 4 * KT results are CONTIGUOUS in dst[(co * gemm_cin + c) * KT + tap] — whole
 // 16-byte stores, a wave writes one contiguous run — where the generic kernel above scatters 4-byte stores KT floats apart (measured 1.8 TB/s
 // on the 1024 x 5120 layers, which this form is for).  Same summation order per element as the generic kernel: bit-identical results.
 template <int KT>
-__global__ __launch_bounds__(256) void wreduce_gemm_kernel(const WreducePair pair) {
-    const int zi = blockIdx.y % pair.zg;  // (one entry per launch in this form)
+__device__ __forceinline__ void wreduce_gemm_body(const WreducePair& pair, int bx, int gx, int by) {
+    const int zi = by % pair.zg;  // (one entry per launch in this form)
     const WreduceParams& p = pair.r[0];
     const float* const partial_p = p.partial + (size_t)zi * pair.zs_partial[0];
     float* const dst_p = p.dst + (size_t)zi * pair.zs_dst[0];
     const int c4n = p.gemm_cin >> 2;
     const int total = p.cout * c4n;
     const size_t stride4 = ((size_t)p.gpad * p.apad) >> 2;  // one split's partial, in float4
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < total; i += gx * 256) {
         const int c4 = (i % c4n) * 4, co = i / c4n;
         const float4* src = reinterpret_cast<const float4*>(partial_p + (size_t)co * p.apad + c4);
         float o[4][KT];
@@ -584,6 +587,11 @@ __global__ __launch_bounds__(256) void wreduce_gemm_kernel(const WreducePair pai
     }
 }
 
+template <int KT>
+__global__ __launch_bounds__(256) void wreduce_gemm_kernel(const WreducePair pair) {
+    wreduce_gemm_body<KT>(pair, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
 // db[co] = sum over splits (and over the phases of a ConvTranspose1d) of the column sums
 struct BreduceParams {
     const float* partial;
@@ -599,17 +607,17 @@ struct BreducePair {
     long long zs_partial[2], zs_dst[2];
 };
 
-__global__ __launch_bounds__(256) void breduce_kernel(const BreducePair pair) {
-    BreduceParams p = pair.b[blockIdx.y / pair.zg];
+__device__ __forceinline__ void breduce_body(const BreducePair& pair, int bx, int by) {
+    BreduceParams p = pair.b[by / pair.zg];
     if (!p.dst) return;
     {
-        const int e = blockIdx.y / pair.zg, zi = blockIdx.y % pair.zg;
+        const int e = by / pair.zg, zi = by % pair.zg;
         p.partial += (size_t)zi * pair.zs_partial[e];
         p.dst += (size_t)zi * pair.zs_dst[e];
     }
     __shared__ float red[16][17];
     const int cl = threadIdx.x & 15, jl = threadIdx.x >> 4;
-    const int co = blockIdx.x * 16 + cl;
+    const int co = bx * 16 + cl;
     const int n = p.n_phase * p.nsplit;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (co < p.cout) {
@@ -631,6 +639,44 @@ __global__ __launch_bounds__(256) void breduce_kernel(const BreducePair pair) {
         for (int j = 0; j < 16; ++j) s += red[j][cl];
         p.dst[co] = p.accumulate ? p.dst[co] + s : s;
     }
+}
+
+__global__ __launch_bounds__(256) void breduce_kernel(const BreducePair pair) { breduce_body(pair, blockIdx.x, blockIdx.y); }
+
+// Every pending reduction of a backward pass (or of one gradient bucket of it) in ONE launch: the weight-gradient kernels of consecutive layers
+// then follow each other without a reduction — a launch that reads tens of MB with a handful of workgroups' worth of parallelism per layer —
+// in between, and the reductions of all layers share the chip.  The table lives in device memory; weight job j owns workgroups
+// wstart[j] .. wstart[j + 1] - 1 as a (wmeta[2 j] x rest) grid of form wmeta[2 j + 1] (0 generic, 3 / 5: GEMM form with that many taps), the
+// bias jobs follow from workgroup wstart[nw] on.
+__device__ __forceinline__ int find_job(const int* start, int njobs, int wg);  // (below)
+
+struct ReduceTable {
+    const WreducePair* w;
+    const int* wstart;
+    const int* wmeta;
+    int nw;
+    const BreducePair* b;
+    const int* bstart;
+    const int* bmeta;
+    int nb;
+};
+
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceTable t) {
+    int wg = blockIdx.x;
+    const int w_total = t.wstart[t.nw];
+    if (wg < w_total) {
+        const int j = find_job(t.wstart, t.nw, wg);
+        const int rel = wg - t.wstart[j], gx = t.wmeta[2 * j], kind = t.wmeta[2 * j + 1];
+        const int bx = rel % gx, by = rel / gx;
+        if (kind == 5) wreduce_gemm_body<5>(t.w[j], bx, gx, by);
+        else if (kind == 3) wreduce_gemm_body<3>(t.w[j], bx, gx, by);
+        else wreduce_body(t.w[j], bx, gx, by);
+        return;
+    }
+    wg -= w_total;
+    const int j = find_job(t.bstart, t.nb, wg);
+    const int rel = wg - t.bstart[j], gx = t.bmeta[j];
+    breduce_body(t.b[j], rel % gx, rel / gx);
 }
 
 // ------------------------------------------------------------------------------------------------
