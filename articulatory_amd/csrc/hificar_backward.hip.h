@@ -171,7 +171,7 @@ struct WgradTapsParams {
     int halo;
 };
 
-constexpr int kWgtR = 64;  // G rows per chunk
+constexpr int kWgtR = 64;  // G rows per chunk (default; wgrad_chunk_rows picks 32 / 64 / 128 per layer)
 
 // EXACT: the layer has exactly NT taps (no per-tap branch in the K loop: the operand reads of the next row pair are in flight while this
 // pair's MFMAs issue); otherwise ntaps < NT and the surplus taps are skipped.
@@ -184,7 +184,9 @@ struct WgradTapsPair {
     int zg;
 };
 
-template <int NT, bool EXACT>
+// R: G rows per chunk (wgrad_chunk_rows: 32 for sequences of at most 32 rows, 128 where few taps leave a 64-row chunk too little work per
+// barrier, else 64)
+template <int NT, bool EXACT, int R>
 __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pair) {
     extern __shared__ __attribute__((aligned(1024))) char wgt_smem[];
     const WgradTapsParams& q = pair.q[blockIdx.z / pair.zg];
@@ -208,9 +210,9 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
     const bool active = gl < gpt && gblk < p.n_gblk && ablk < p.n_ablk;
     const int phase = (gt * gpt) / p.nb32_per_phase;
     const int off0 = p.tap_off0[phase] - q.off_min;  // row shift of tap 0 inside the staged A tile (>= 0)
-    const int a_rows = kWgtR + q.halo;
-    const int g_bytes = kWgtR * 256, a_bytes = ((a_rows * 256 + 1023) >> 10) << 10, buf_bytes = g_bytes + a_bytes;
-    const int cps = (p.L + kWgtR - 1) / kWgtR;
+    const int a_rows = R + q.halo;
+    const int g_bytes = R * 256, a_bytes = ((a_rows * 256 + 1023) >> 10) << 10, buf_bytes = g_bytes + a_bytes;
+    const int cps = (p.L + R - 1) / R;
     const int nchunks = p.nseq * cps;
     const int a_cols = q.acols ? q.acols : p.apitch;
     const size_t a_seq_pitch = q.a_seq_pitch ? (size_t)q.a_seq_pitch : (size_t)p.L * p.apitch;
@@ -223,10 +225,10 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
     // LDS-DMA of one chunk: 1 KiB = 4 rows of 64 channels per wave-instruction, lane -> (row 4 i + lane / 16, channels 4 (lane % 16) ..)
     auto stage = [&](int c, int b) {
         const int seq = c / cps;
-        const int t0 = (c - seq * cps) * kWgtR;
+        const int t0 = (c - seq * cps) * R;
         char* dst = wgt_smem + b * buf_bytes;
         const int c4 = (lane & 15) * 4;
-        for (int i = wave; i < kWgtR / 4; i += 4) {
+        for (int i = wave; i < R / 4; i += 4) {
             const int tg = t0 + 4 * i + (lane >> 4);
             const char* src = q.zeros;
             const int gch = gt * gpt * 32 + c4;
@@ -259,11 +261,11 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
         const float* as = gs + g_bytes / 4;
         if (do_bias) {
 #pragma unroll 8
-            for (int r = tid >> 6; r < kWgtR; r += 4) bsum += gs[r * 64 + (tid & 63)];
+            for (int r = tid >> 6; r < R; r += 4) bsum += gs[r * 64 + (tid & 63)];
         }
         if (active) {
             const int gc = gl * 32 + li, ac = al * 32 + li;
-            const int k0 = part * (kWgtR / rs), kn = kWgtR / rs;  // kn: 64, 32 or 16 rows
+            const int k0 = part * (R / rs), kn = R / rs;  // kn: 64, 32 or 16 rows
             const int tstep = p.tap_step * 64;
             const float* gp = gs + (k0 + hf) * 64 + gc;
             const float* ap[NT];
