@@ -35,12 +35,19 @@ D_TENSORS = ["msd.discriminators.0.layers.0.0.weight", "msd.discriminators.1.lay
              "mpd.discriminators.3.convs.4.0.weight_v"]
 STFT_DEFAULTS = {"fft_sizes": [1024, 2048, 512], "hop_sizes": [120, 240, 50], "win_lengths": [600, 1200, 240], "window": "hann_window"}
 B, SEED_G, SEED_D, SEED_X = 8, 41, 42, 43
+# recipe -> (YAML under /root/reference, batch, fixture file, auxiliary-loss variants).  "car" is the fixture described above; the other two
+# shipped recipes (same Trainer, same checks) at a batch the CPU finishes in minutes:  --recipe e2w | mri
+#   e2w  egs/ema/voc1/conf/e2w_hifigan.yaml          the same networks on 8000-sample windows (100 frames: several row chunks per sequence)
+#   mri  egs/mri/voc1/conf/mri2w_hifigan_car.yaml    230-dim features, x240 upsampling (scales 8, 5, 3, 2), 30000-sample windows at 20 kHz
+RECIPES = {"car": ("egs/ema/voc1/conf/e2w_hifigan_car.yaml", 8, "gold_train_step.npz", ("mel", "stft")),
+           "e2w": ("egs/ema/voc1/conf/e2w_hifigan.yaml", 4, "gold_train_step_e2w.npz", ("mel",)),
+           "mri": ("egs/mri/voc1/conf/mri2w_hifigan_car.yaml", 2, "gold_train_step_mri.npz", ("mel",))}
 
 
-def recipe_config():
+def recipe_config(recipe="car"):
     import yaml
 
-    with open(os.path.join(REF, "egs/ema/voc1/conf/e2w_hifigan_car.yaml")) as f:
+    with open(os.path.join(REF, RECIPES[recipe][0])) as f:
         cfg = yaml.safe_load(f)
     cfg["generator_params"] = {k: v for k, v in cfg["generator_params"].items() if k not in ("final_scale", "extra_art")}
     return cfg
@@ -53,7 +60,14 @@ def make_batch(cfg, seed=SEED_X, batch=B):
 
 
 def main():
+    import argparse
+
     import torch
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--recipe", default="car", choices=sorted(RECIPES))
+    recipe = ap.parse_args().recipe
+    _, batch_size, fixture, auxes = RECIPES[recipe]
 
     from articulatory_amd.utils.synth import synth_disc_state_dict, synth_state_dict
     from disc_oracle import mel_filterbank
@@ -79,10 +93,10 @@ def main():
                                          MultiResolutionSTFTLoss)
 
         out = {}
-        for aux in ("mel", "stft"):
+        for aux in auxes:
             kept = {}
             for dtype in (torch.float32, torch.float64):  # float64: the same step again, a yardstick for the tests' tolerances only
-                cfg = recipe_config()
+                cfg = recipe_config(recipe)
                 cfg["outdir"] = "/tmp"
                 if aux == "stft":
                     cfg.update(use_stft_loss=True, use_mel_loss=False, stft_loss_params=dict(STFT_DEFAULTS))
@@ -110,7 +124,7 @@ def main():
                 trainer = ref_train.Trainer(steps=2, epochs=0, data_loader={}, sampler={}, model=model, criterion=criterion, optimizer=optimizer,
                                             scheduler=scheduler, config=cfg, device=torch.device("cpu"))
                 trainer.tqdm = types.SimpleNamespace(update=lambda n: None)
-                nb = make_batch(cfg)
+                nb = make_batch(cfg, batch=batch_size)
                 batch = {"x": (torch.from_numpy(nb["x"]).to(dtype),), "y": torch.from_numpy(nb["y"]).to(dtype), "ar": torch.from_numpy(nb["ar"]).to(dtype)}
                 model["generator"].train()
                 model["discriminator"].train()
@@ -133,8 +147,8 @@ def main():
                     print(f"    {net} {n}: reference fp32 vs fp64 gradient: median {np.median(e):.1e} max {e.max():.1e}")
     finally:
         torch.stft = real_stft
-    out["B"], out["seeds"] = np.array(B), np.array([SEED_G, SEED_D, SEED_X])
-    path = os.path.join(REPO, "tests", "golden", "gold_train_step.npz")
+    out["B"], out["seeds"] = np.array(batch_size), np.array([SEED_G, SEED_D, SEED_X])
+    path = os.path.join(REPO, "tests", "golden", fixture)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

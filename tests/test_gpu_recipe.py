@@ -31,12 +31,14 @@ def sampled(gold, name, arr):
     return flat[gold[name + "::idx"]], gold[name + "::vals"].astype(np.float64)
 
 
-@pytest.mark.parametrize("aux", ["mel", "stft"])
-def test_full_recipe_iteration_vs_reference_train_step(aux):
-    gold = np.load(os.path.join(GOLDEN, "gold_train_step.npz"))
+# (recipe, auxiliary loss): config 5's recipe with both losses; the other two shipped recipes — e2w_hifigan.yaml (8000-sample windows) and
+# mri2w_hifigan_car.yaml (230-dim features, x240, 30000-sample windows) — with the mel loss they ship with (oracle/make_golden_train.py --recipe)
+@pytest.mark.parametrize("recipe,aux", [("car", "mel"), ("car", "stft"), ("e2w", "mel"), ("mri", "mel")])
+def test_full_recipe_iteration_vs_reference_train_step(recipe, aux):
+    gold = np.load(os.path.join(GOLDEN, {"car": "gold_train_step.npz", "e2w": "gold_train_step_e2w.npz", "mri": "gold_train_step_mri.npz"}[recipe]))
     B = int(gold["B"])
     seed_g, seed_d, seed_x = (int(s) for s in gold["seeds"])
-    config = recipe_train_config("car", aux=aux, batch=B)
+    config = recipe_train_config(recipe, aux=aux, batch=B)
     t = Trainer(config, torch.device("cuda:0"))
     gsd = synth_state_dict(config["generator_params"], seed=seed_g)
     dsd = synth_disc_state_dict(config["discriminator_params"], seed=seed_d)
