@@ -152,6 +152,31 @@ def test_gradients_vs_oracle_every_element(weight_norm):
     assert not bad, bad  # (a LeakyReLU kink flip would show as percents in a few tensors: pick another input seed then)
 
 
+def test_batched_reduction_tables_survive_recycling():
+    """The weight / bias gradient reductions of a backward pass run as one launch from a job table cached on the device by content
+    (flush_reduce: 48 slots, least-recently-used recycling).  Ninety different launch shapes: the second walk over
+    them finds every table evicted and uploads it again into a recycled slot; gradients must be bit-identical to the first walk."""
+    params = dict(E2W_PARAMS, channels=64, upsample_scales=[4, 2], upsample_kernel_sizes=[8, 4], resblock_kernel_sizes=[3, 7],
+                  resblock_dilations=[[1, 3], [1, 3]], in_channels=13 + 128)
+    g, _ = build(params, 77)
+    ar3 = torch.from_numpy(synth_features(3, 512, 1, seed=6)[:, :, 0] * 0.3).reshape(3, 1, 512).cuda()
+    names = ["input_conv.weight_v", "upsamples.1.1.weight_g", "blocks.3.convs2.1.1.bias", "blocks.0.convs1.0.1.weight_v"]
+    walks = []
+    for _ in range(2):
+        seen = []
+        for B in (1, 2, 3):  # (row splits, scratch offsets and buffer addresses change with the shape: well over 48 distinct tables)
+            for T in range(4, 64, 2):
+                c = torch.from_numpy(synth_features(B, T, 13, seed=T)).permute(0, 2, 1).contiguous().cuda()
+                g.zero_grad(set_to_none=True)
+                g(c, ar=ar3[:B]).square().mean().backward()
+                p = dict(g.named_parameters())
+                seen.append([p[n].grad.clone() for n in names])
+        walks.append(seen)
+    for a, b in zip(*walks):
+        for x, y in zip(a, b):
+            assert torch.isfinite(x).all() and torch.equal(x, y)
+
+
 def test_training_step_updates_weights_and_eval_follows():
     """One SGD step on the native autograd node: the loss goes down, and an eval-mode forward afterwards uses the UPDATED weights
     (the handle is refreshed from the device-resident parameters) and matches the oracle on them."""
