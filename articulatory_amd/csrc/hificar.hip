@@ -80,6 +80,8 @@ struct hificar_handle {
     double mi1_penalty = 1.05;     // cost factor of 32-row tiles in the exact-fp32 tile choice (they re-stream the weights most often: L2-bound when
                                    // K is long).  The discriminator engine raises it: its launches overlap on several streams, so a nearly
                                    // empty last round of taller tiles costs little there, while the L2 traffic of short tiles is shared by all
+    int pick_throughput = 0;       // > 0: launches of at least this many tiles choose their tile shape by workgroup-time instead of makespan (set by
+                                   // the discriminator engine, whose sub-networks run on eight streams; HIFICAR_DISC_PICK overrides, 0 = off)
     bool pair_small = true;        // HIFICAR_PAIR_SMALL: 128-row fused pair tiles at C = 32 for mid-size launches (pair_small_tiles)
     int ksplit = 1;                // HIFICAR_KSPLIT: 0 = never use the split-K conv form, 1 = when it is estimated faster (default), 2 = always
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
@@ -1014,6 +1016,11 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         }
         double worst = std::max(heaviest, total_cost / G);
         if (total % G != 0) worst = std::max(worst, total_cost / G + 0.5 * lightest);
+        // An engine whose launches overlap with others on side streams (the discriminators): a launch's own makespan — a nearly empty
+        // last round, a chip half filled by tall tiles — is filled by the neighbours' workgroups, so what counts is the workgroup-time the
+        // shape costs, i.e. its efficiency per tile.  (Measured: discriminator step 20.6 -> 19.9 ms, generator-side pass 10.7 -> 10.0 ms;
+        // launches with fewer tiles than pick_throughput stay latency-driven.)
+        if (h->pick_throughput > 0 && total >= h->pick_throughput) worst = total_cost / h->num_cus;
         // shorter wave tiles re-read the weight stream more often per MFMA (MI = 2 measured ~10 % slower per flop)
         if (t.MI < 4) worst *= f32 ? (t.MI == 2 ? 1.02 : h->mi1_penalty) : (t.MI == 2 ? 1.10 : 1.25);
         if (t.KS == 4) worst *= 1.05;  // near-ties go to the dense form
