@@ -20,6 +20,7 @@ the window (zero padded on the left) as the AR context.
     python -m torch.distributed.run --nproc-per-node 8 -m articulatory_amd.bin.train --config ... --outdir ...
 """
 import argparse
+import contextlib
 import logging
 import os
 import time
@@ -227,16 +228,26 @@ class Trainer:
             if self.use_ph_loss:
                 y_, ph_ = y_
             gen_loss = 0.0
-            if self.stft is not None:  # train.py:288-297
-                sc_loss, mag_loss = self.stft(y_, y)
-                gen_loss = gen_loss + sc_loss + mag_loss
-                log["train/spectral_convergence_loss"] = sc_loss.detach()
-                log["train/log_stft_magnitude_loss"] = mag_loss.detach()
-            if self.mel is not None:
-                mel_loss = self.mel(y_, y)
-                gen_loss = gen_loss + mel_loss
-                log["train/mel_loss"] = mel_loss.detach()
-            gen_loss = gen_loss * cfg.get("lambda_aux", 1.0)
+            # The auxiliary losses and the adversarial criterion both depend on y_ only: with the adversarial part on, the auxiliary loss
+            # (a separate engine: framing + four GEMMs, value and gradient in one call) is enqueued on a side stream next to the
+            # discriminators' passes and joined before the sum below (same terms in the same order).
+            side = self._aux_side_stream() if adv_on and not self.use_ph_loss and cfg.get("overlap_aux_loss", True) else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                y_.record_stream(side)
+                y.record_stream(side)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                if self.stft is not None:  # train.py:288-297
+                    sc_loss, mag_loss = self.stft(y_, y)
+                    gen_loss = gen_loss + sc_loss + mag_loss
+                    log["train/spectral_convergence_loss"] = sc_loss.detach()
+                    log["train/log_stft_magnitude_loss"] = mag_loss.detach()
+                if self.mel is not None:
+                    mel_loss = self.mel(y_, y)
+                    gen_loss = gen_loss + mel_loss
+                    log["train/mel_loss"] = mel_loss.detach()
+                gen_loss = gen_loss * cfg.get("lambda_aux", 1.0)
+            aux_side = side if torch.is_tensor(gen_loss) else None
             if self.use_ph_loss:  # train.py:327-331: frame-rate phoneme logits (B, num_ph, T) against the phoneme indices
                 ph_loss = torch.nn.functional.cross_entropy(ph_, ph.long())
                 gen_loss = gen_loss + cfg["lambda_ph"] * ph_loss
@@ -250,6 +261,10 @@ class Trainer:
                     lambda_feat_match=cfg.get("lambda_feat_match", 0.0) if use_fm else 0.0,
                     fm_average_by_layers=fm.get("average_by_layers", True), fm_average_by_discriminators=fm.get("average_by_discriminators", True),
                     fm_include_final_outputs=fm.get("include_final_outputs", False))
+                if aux_side is not None:  # the auxiliary loss joins the main stream here
+                    torch.cuda.current_stream().wait_stream(aux_side)
+                    gen_loss.record_stream(torch.cuda.current_stream())
+                    aux_side = None
                 gen_loss = gen_loss + total
                 log["train/adversarial_loss"] = adv
                 if use_fm:
@@ -281,6 +296,11 @@ class Trainer:
             self._scheduler_step("discriminator", dis_loss)
         self.steps += 1
         return log
+
+    def _aux_side_stream(self):
+        if getattr(self, "_aux_stream", None) is None:
+            self._aux_stream = torch.cuda.Stream(device=self.device)
+        return self._aux_stream
 
     # The GAN criterion: one fused native node per side (D.generator_loss / D.discriminator_loss).  A spectrally normalised discriminator
     # advances its power iteration at every D(x) of the reference's step (train.py:347,356,421-422: three or four different weight sets per

@@ -304,6 +304,24 @@ def test_fused_and_foreach_optimizers_give_the_same_iterations(fused):
     assert logs[2]["train/fake_loss"] != logs[0]["train/fake_loss"]
 
 
+@pytest.mark.parametrize("aux", ["mel", "stft"])
+def test_auxiliary_loss_on_a_side_stream_gives_the_same_iterations(aux):
+    """The auxiliary loss runs next to the discriminators' passes on a side stream (``overlap_aux_loss``, default on) and joins before the
+    sum: three iterations log exactly what the serial order logs (same kernels, same summation order)."""
+    base = make_config(True)
+    if aux == "stft":
+        base.update(use_mel_loss=False, use_stft_loss=True,
+                    stft_loss_params={"fft_sizes": [256, 128], "hop_sizes": [64, 32], "win_lengths": [256, 100], "window": "hann_window"})
+    runs = []
+    for overlap in (True, False):
+        t, _, _, batch = build(dict(base, overlap_aux_loss=overlap))
+        t.steps = 1
+        runs.append([{k: float(v) for k, v in t.train_step(batch).items()} for _ in range(3)])
+    for a, b in zip(*runs):
+        assert a == b, (a, b)
+    assert ("train/mel_loss" in runs[0][0]) == (aux == "mel")
+
+
 def test_iteration_with_spectrally_normalised_period_discriminators():
     """A discriminator with use_spectral_norm on its period sub-networks through Trainer.train_step: the criterion falls back from the
     fused nodes to one native forward per D(x) (the reference advances the power iteration at each of them) — the first iteration's

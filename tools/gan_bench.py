@@ -26,10 +26,12 @@ ap.add_argument("--batch", type=int, default=None)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--torch-profile", action="store_true")
 ap.add_argument("--pageable", action="store_true", help="keep the batch in pageable host memory (every .to(device) then drains the stream)")
+ap.add_argument("--serial-aux", action="store_true", help="config key overlap_aux_loss: false — the auxiliary loss on the main stream (A/B)")
 a = ap.parse_args()
 from articulatory_amd.utils.recipes import recipe_train_config  # noqa: E402
 
 config = recipe_train_config(a.recipe, aux=a.aux, batch=a.batch, fused_optimizers=not a.foreach_adam)
+config["overlap_aux_loss"] = not a.serial_aux
 a.batch = config["batch_size"]
 r_steps = config["batch_max_steps"]
 r_hop = int(np.prod(config["generator_params"]["upsample_scales"]))
