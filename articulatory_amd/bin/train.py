@@ -272,6 +272,9 @@ class Trainer:
             log["train/generator_loss"] = gen_loss.detach()
             self.optimizer["generator"].zero_grad(set_to_none=True)
             gen_loss.backward()
+            if adv_on and cfg.get("early_real_gradient", True) and hasattr(self.D, "start_real_gradient"):
+                # the discriminator update's real pass does not wait for the generator update: its backward starts now, on a side stream
+                self.D.start_real_gradient(loss_type=da.get("loss_type", "mse"), average_by_discriminators=da.get("average_by_discriminators", True))
             if cfg.get("generator_grad_norm", -1) > 0:
                 torch.nn.utils.clip_grad_norm_(self.G.parameters(), cfg["generator_grad_norm"])
             self.optimizer["generator"].step()

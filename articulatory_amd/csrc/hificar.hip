@@ -148,6 +148,9 @@ struct hificar_handle {
     hipStream_t last_stream = nullptr;
     bool have_last_stream = false;
     hipEvent_t xstream_ev = nullptr;
+    hipEvent_t done_ev = nullptr;  // recorded at the END of the last call on done_stream (calls that mark their end: the discriminators' backward)
+    bool done_valid = false;
+    hipStream_t done_stream = nullptr;
     // debug taps (hificar_debug_tap): name -> (destination, capacity in floats); scratch for pre-activation copies
     struct Tap {
         float* dst;
@@ -426,6 +429,7 @@ extern "C" void hificar_destroy(hificar_handle* h) {
         (void)hipHostFree(a.h);
     }
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
+    if (h->done_ev) (void)hipEventDestroy(h->done_ev);
     for (auto& r : h->rslots) {
         if (r.d) (void)hipFree(r.d);
         if (r.h) (void)hipHostFree(r.h);
@@ -915,10 +919,15 @@ static int get_schedule(hificar_handle* h, const std::string& key, const std::ve
 // table, workspace).  Same stream: nothing to do.
 static int enter_stream(hificar_handle* h, hipStream_t stream) {
     if (h->have_last_stream && h->last_stream != stream) {
-        if (!h->xstream_ev) HIP_TRY(hipEventCreateWithFlags(&h->xstream_ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(h->xstream_ev, h->last_stream));
-        HIP_TRY(hipStreamWaitEvent(stream, h->xstream_ev, 0));
+        if (h->done_valid && h->done_stream == h->last_stream) {  // the previous call marked its own end: wait for that, not for later work
+            HIP_TRY(hipStreamWaitEvent(stream, h->done_ev, 0));
+        } else {
+            if (!h->xstream_ev) HIP_TRY(hipEventCreateWithFlags(&h->xstream_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(h->xstream_ev, h->last_stream));
+            HIP_TRY(hipStreamWaitEvent(stream, h->xstream_ev, 0));
+        }
     }
+    h->done_valid = false;
     h->last_stream = stream;
     h->have_last_stream = true;
     return HIFICAR_OK;

@@ -204,6 +204,9 @@ class _GeneratorLossFunction(torch.autograd.Function):
                                                 ctx.fake.ptr, ctx.fake.nbytes, None, dx.data_ptr(), ws.data_ptr() + 4 * woff, wsb, stream)
         _native.check(rc, "hificar_disc_backward_flat")
         ctx.fake = ctx.douts = None
+        done = torch.cuda.Event()
+        done.record()
+        module.__dict__["_gside_done"] = done  # (start_real_gradient's side stream starts behind this point, not behind the generator's backward)
         return (None, dx * g_total, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
 
 
@@ -255,11 +258,23 @@ class _DiscriminatorLossFunction(torch.autograd.Function):
             reducer, cb, errors = None, None, []
             # ONE folded-gradient buffer: the second pass adds to what the first left (hificar_disc_set_grad_accumulate), and the weight-norm
             # chain rule multiplies by the upstream gradient while it writes (hificar_disc_set_grad_scale): no add pass, no scaling pass
-            g = torch.zeros(nfold, dtype=torch.float32, device=dev)
             g_total = g_total.to(torch.float32).contiguous()
-            for mode, ps, (d, doff) in zip((1, 2), ctx.passes, ctx.douts):
-                if mode == 2 and module._grad_sync is not None:
-                    # data-parallel training: one gradient bucket per sub-discriminator.  During the SECOND pass libhificar calls back as
+            plan = list(zip((1, 2), ctx.passes, ctx.douts))
+            early = module.__dict__.pop("_early_real", None)
+            if early is not None and early["pass"] is ctx.passes[1] and early["cfg"] == (ctx.cfg.loss_type, ctx.cfg.average_by_discriminators):
+                # the real pass's parameter gradients were computed next to the generator's backward (start_real_gradient): only the fake
+                # pass is left, and it adds to them
+                g = early["g"]
+                torch.cuda.current_stream().wait_event(early["done"])
+                g.record_stream(torch.cuda.current_stream())
+                plan, first_accumulates = plan[:1], True
+            else:
+                g = torch.zeros(nfold, dtype=torch.float32, device=dev)
+                first_accumulates = False
+            early = None
+            for step, (mode, ps, (d, doff)) in enumerate(plan):
+                if step == len(plan) - 1 and module._grad_sync is not None:
+                    # data-parallel training: one gradient bucket per sub-discriminator.  During the LAST pass libhificar calls back as
                     # each sub-network's gradients (both passes' sum by then) are enqueued on its side stream: there the weight-norm chain
                     # rule runs and the bucket's all-reduce (RCCL over xGMI) starts while the other sub-networks still compute.
                     from ..utils.buckets import BucketReducer, bucket_ranges
@@ -283,7 +298,7 @@ class _DiscriminatorLossFunction(torch.autograd.Function):
                     cb = _native.BUCKET_FN(on_bucket)
                     _native.check(lib.hificar_disc_set_bucket_callback(handle, cb, None), "hificar_disc_set_bucket_callback")
                 try:
-                    _native.check(lib.hificar_disc_set_grad_accumulate(handle, 1 if mode == 2 else 0), "hificar_disc_set_grad_accumulate")
+                    _native.check(lib.hificar_disc_set_grad_accumulate(handle, 1 if (step > 0 or first_accumulates) else 0), "hificar_disc_set_grad_accumulate")
                     if cb is not None:  # (the bucket callback runs the weight-norm chain rule during this pass)
                         _native.check(lib.hificar_disc_set_grad_scale(handle, g_total.data_ptr()), "hificar_disc_set_grad_scale")
                     rc = lib.hificar_disc_backward_flat(handle, d.data_ptr() + 4 * doff, mode, 0, 0, B, T, ps.ptr, ps.nbytes, g.data_ptr(), None,
@@ -492,6 +507,7 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         optimizer post-step hook."""
         self.__dict__.pop("_sent_sig", None)
         self.__dict__["_real_cache"] = None
+        self.__dict__.pop("_early_real", None)
 
     def _raw_parameters(self):
         cached = self.__dict__.get("_raw_cache")  # (walking the module tree costs ~1 ms per call; the criterion needs it every pass)
@@ -580,6 +596,50 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         cfg = _loss_cfg(loss_type, average_by_discriminators, True, True, False, 1.0, 0.0)
         names, tensors = self._raw_parameters()
         return _DiscriminatorLossFunction.apply(self, y_fake.detach(), y_real.detach(), cfg, names, *tensors)
+
+    def start_real_gradient(self, loss_type="mse", average_by_discriminators=True):
+        """The real half of the NEXT discriminator_loss(y_fake, y_real) backward, started now on a side stream.
+
+        In a GAN iteration (train.py:341-437) D(y_real) is computed in the generator part (feature matching) and its parameter gradients
+        depend neither on the generator update nor on the re-computed fake batch that the discriminator part waits for: called right after
+        the generator loss's backward, the real pass's backward (one of the two backward passes of the discriminator update) runs next to
+        the generator's own backward / optimizer step / re-computed forward — another engine, single-stream — instead of behind them.
+        discriminator_loss's backward then finds the gradients, runs the fake pass only and adds (same sum: bit-identical gradients).
+        Returns False (and does nothing) when there is no cached D(y_real) pass to start from."""
+        cached = self.__dict__.get("_real_cache")
+        if cached is None or self._spectral or self._handle is None:
+            return False
+        _, ps, y_real = cached
+        lib, handle = self._lib, self._handle
+        B, _, T = y_real.shape
+        dev = y_real.device
+        cfg = _loss_cfg(loss_type, average_by_discriminators, True, True, False, 1.0, 0.0)
+        with torch.cuda.device(dev):
+            side = self.__dict__.get("_early_stream")
+            if side is None:
+                side = self.__dict__["_early_stream"] = torch.cuda.Stream(device=dev)
+            after = self.__dict__.pop("_gside_done", None)
+            if after is not None:
+                side.wait_event(after)
+            else:
+                side.wait_stream(torch.cuda.current_stream())
+            ps.tape.record_stream(side)
+            with torch.cuda.stream(side):
+                stream = ctypes.c_void_p(side.cuda_stream)
+                d, doff = _aligned(int(lib.hificar_disc_dout_floats(handle, B, T)), dev)
+                v = torch.empty(3, dtype=torch.float32, device=dev)
+                _native.check(lib.hificar_disc_loss(handle, ctypes.byref(cfg), 2, ps.ptr, None, B, T, v.data_ptr(), d.data_ptr() + 4 * doff, stream),
+                              "hificar_disc_loss")
+                g = torch.zeros(int(lib.hificar_disc_grad_floats(handle)), dtype=torch.float32, device=dev)
+                wsb = int(lib.hificar_disc_backward_workspace_bytes(handle, B, T))
+                ws, woff = _aligned(wsb // 4, dev)
+                _native.check(lib.hificar_disc_set_grad_accumulate(handle, 0), "hificar_disc_set_grad_accumulate")
+                _native.check(lib.hificar_disc_backward_flat(handle, d.data_ptr() + 4 * doff, 2, 0, 0, B, T, ps.ptr, ps.nbytes, g.data_ptr(), None,
+                                                             ws.data_ptr() + 4 * woff, wsb, stream), "hificar_disc_backward_flat")
+                done = torch.cuda.Event()
+                done.record(side)
+        self.__dict__["_early_real"] = {"pass": ps, "cfg": (cfg.loss_type, cfg.average_by_discriminators), "g": g, "done": done}
+        return True
 
     def _no_fused_spectral(self):
         if self._spectral:

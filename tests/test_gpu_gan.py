@@ -322,6 +322,40 @@ def test_auxiliary_loss_on_a_side_stream_gives_the_same_iterations(aux):
     assert ("train/mel_loss" in runs[0][0]) == (aux == "mel")
 
 
+def test_early_real_gradient_gives_the_same_iterations():
+    """The real pass of the discriminator update does not depend on the generator update: its backward starts on a side stream right after
+    the generator loss's backward (``early_real_gradient``, default on; discriminator.py::start_real_gradient) and the update itself only
+    adds the fake pass.  real + fake instead of fake + real: the same sums, so three iterations log exactly the same losses either way."""
+    runs = []
+    for early in (True, False):
+        t, _, _, batch = build(dict(make_config(True), early_real_gradient=early))
+        t.steps = 1
+        logs = []
+        for _ in range(3):
+            logs.append({k: float(v) for k, v in t.train_step(batch).items()})
+            assert t.D.__dict__.get("_early_real") is None  # consumed by the discriminator update (or never started)
+        runs.append(logs)
+    for a, b in zip(*runs):
+        assert a == b, (a, b)
+    # and it really ran early: the hook leaves its result behind until the discriminator loss's backward takes it
+    t, _, _, batch = build(make_config(True))
+    assert t.D.start_real_gradient() is False  # (nothing cached yet)
+    real = torch.rand(2, 1, 600, device="cuda") - 0.5
+    fake = (torch.rand(2, 1, 600, device="cuda") - 0.5).requires_grad_(True)
+    total, _, _ = t.D.generator_loss(fake, real, lambda_adv=1.0, lambda_feat_match=2.0)
+    total.backward()
+    assert t.D.start_real_gradient() is True and "_early_real" in t.D.__dict__
+    tot, _, _ = t.D.discriminator_loss(fake.detach(), real)
+    tot.backward()
+    assert "_early_real" not in t.D.__dict__
+    early_grads = [p.grad.clone() for p in t.D.parameters()]
+    t.D.zero_grad(set_to_none=True)
+    tot, _, _ = t.D.discriminator_loss(fake.detach(), real)
+    tot.backward()
+    for a, p in zip(early_grads, t.D.parameters()):
+        assert torch.equal(a, p.grad)
+
+
 def test_iteration_with_spectrally_normalised_period_discriminators():
     """A discriminator with use_spectral_norm on its period sub-networks through Trainer.train_step: the criterion falls back from the
     fused nodes to one native forward per D(x) (the reference advances the power iteration at each of them) — the first iteration's

@@ -27,11 +27,13 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--torch-profile", action="store_true")
 ap.add_argument("--pageable", action="store_true", help="keep the batch in pageable host memory (every .to(device) then drains the stream)")
 ap.add_argument("--serial-aux", action="store_true", help="config key overlap_aux_loss: false — the auxiliary loss on the main stream (A/B)")
+ap.add_argument("--late-real", action="store_true", help="config key early_real_gradient: false — both backward passes of the discriminator update inside it (A/B)")
 a = ap.parse_args()
 from articulatory_amd.utils.recipes import recipe_train_config  # noqa: E402
 
 config = recipe_train_config(a.recipe, aux=a.aux, batch=a.batch, fused_optimizers=not a.foreach_adam)
 config["overlap_aux_loss"] = not a.serial_aux
+config["early_real_gradient"] = not a.late_real
 a.batch = config["batch_size"]
 r_steps = config["batch_max_steps"]
 r_hop = int(np.prod(config["generator_params"]["upsample_scales"]))
