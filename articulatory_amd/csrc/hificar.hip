@@ -82,6 +82,7 @@ struct hificar_handle {
                                    // empty last round of taller tiles costs little there, while the L2 traffic of short tiles is shared by all
     int pick_throughput = 0;       // > 0: launches of at least this many tiles choose their tile shape by workgroup-time instead of makespan (set by
                                    // the discriminator engine, whose sub-networks run on eight streams; HIFICAR_DISC_PICK overrides, 0 = off)
+    bool xcd_order = true;         // HIFICAR_XCD_ORDER: XCD-contiguous tile order for one-round launches that stream more weights than activations
     bool pair_small = true;        // HIFICAR_PAIR_SMALL: 128-row fused pair tiles at C = 32 for mid-size launches (pair_small_tiles)
     int ksplit = 1;                // HIFICAR_KSPLIT: 0 = never use the split-K conv form, 1 = when it is estimated faster (default), 2 = always
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
@@ -282,6 +283,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (const char* e = getenv("HIFICAR_PROFILE_DETAIL")) h->profile_detail = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_PAIR")) h->use_pair = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_PAIR_SMALL")) h->pair_small = atoi(e) != 0;  // (A/B runs)
+    if (const char* e = getenv("HIFICAR_XCD_ORDER")) h->xcd_order = atoi(e) != 0;    // (A/B runs)
     if (const char* e = getenv("HIFICAR_LPT")) h->use_lpt = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_KSPLIT")) h->ksplit = atoi(e);
     {
@@ -1078,6 +1080,12 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     mp.zs_y = zr.zs_y;
     mp.zs_b = zr.zs_b;
     dim3 grid((unsigned)std::min(mp.total_tiles, h->num_cus), 1, 1);  // persistent: one workgroup per CU walks its tile list
+    {   // one round of tiles and at least twice the activations in weight bytes (batch 8 measured neutral at 1.8 x): XCD-contiguous tile order (MultiConvParams::xcd_order)
+        double wbytes = 0.0;
+        for (int b = 0; b < nbr; ++b) wbytes += 4.0 * layers[b]->cin_pad * layers[b]->cout_total * layers[b]->ntaps * zr.n;
+        const double abytes = 4.0 * nseq * rows * L0.cin_pad * nbr * zr.n;
+        mp.xcd_order = (h->xcd_order && mp.total_tiles <= h->num_cus && mp.total_tiles >= 16 && wbytes > 2.0 * abytes) ? 1 : 0;
+    }
     if (h->use_lpt && mp.total_tiles > (int)grid.x) {
         std::vector<double> costs((size_t)mp.total_tiles);
         const int tpb = mp.ngroups * mp.nseq_tiles;

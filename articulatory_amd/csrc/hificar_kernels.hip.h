@@ -111,6 +111,7 @@ struct MultiConvParams {
     int zrep;
     long long zs_x, zs_w, zs_y, zs_b;
     unsigned long long* trace;  // dev tool only (tools/conv_bench.hip, -DHIFICAR_TRACE): per-workgroup timeline
+    int xcd_order;  // 1 (gridDim.x == total_tiles, no schedule): XCD-contiguous tile order, see tile_of
 };
 
 #ifdef HIFICAR_TRACE
@@ -270,6 +271,14 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         int i = it;
         if ((blockIdx.x & 1) && my_rounds >= 3 && it >= my_rounds - 2) i = it == my_rounds - 1 ? my_rounds - 2 : my_rounds - 1;
         if (mp.sched_start) return mp.sched_tiles[sched_lo + i];
+        if (mp.xcd_order) {
+            // one tile per workgroup, weights outweigh activations (small batches, the discriminators' few-row GEMMs): workgroups are
+            // dispatched to the 8 XCDs round-robin, so workgroup w = 8 l + x takes tile l of XCD x's CONTIGUOUS share of the tile list —
+            // tiles are numbered (branch, channel group)-major, i.e. an XCD's L2 then streams an eighth of the weights instead of all
+            const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
+            const int base = mp.total_tiles >> 3, rem = mp.total_tiles & 7;
+            return x * base + min(x, rem) + l;
+        }
         return (int)blockIdx.x + (my_rounds - 1 - i) * (int)gridDim.x;
     };
     // ragged batches: tiles past the end of their sequence are skipped by both roles (same predicate, so the barrier
