@@ -999,10 +999,15 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     static const char* force = getenv("HIFICAR_TILE");
     int fc = 0, fmi = 0, fwm = 0, fwn = 0;
     if (force) sscanf(force, "%d,%d,%d,%d", &fc, &fmi, &fwm, &fwn);
+    // HIFICAR_TILE1: the same for single-layer launches (input conv, upsamplers)
+    static const char* force1 = getenv("HIFICAR_TILE1");
+    int fc1 = 0, fmi1 = 0, fwm1 = 0, fwn1 = 0;
+    if (force1) sscanf(force1, "%d,%d,%d,%d", &fc1, &fmi1, &fwm1, &fwn1);
     for (const TileCfg& t : kTileCfgs) {
         const int TM = t.WM * t.MI * 32;
         if (2 * round_up_sz((size_t)(TM + halo_all) * RB, 1024) + out_buf_bytes(t) > 160 * 1024) continue;
         if (fc == L0.cin_pad && nbr == 3 && !(t.MI == fmi && t.WM == fwm && t.WN == fwn)) continue;
+        if (fc1 == L0.cin_pad && nbr == 1 && zr.n == 1 && !(t.KS == 1 && t.MI == fmi1 && t.WM == fwm1 && t.WN == fwn1)) continue;
         if (t.KS == 4 && (h->ksplit == 0 || nsteps_min < 2)) continue;
         if (t.KS == 1 && h->ksplit == 2 && nsteps_min >= 2) continue;
         const long long tiles_per_branch = (long long)nseq * ((rows + TM - 1) / TM) * ((L0.n_blocks32 + t.WN - 1) / t.WN);
