@@ -1156,6 +1156,8 @@ static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const Con
     const size_t in_bytes = round_up_sz((size_t)(TMc + a.off_max - a.off_min) * C * 4, 1024);
     const size_t ts_bytes = std::max<size_t>((size_t)(TMc + 16) * C * 4, (size_t)TMc * (C + 4) * sizeof(float));
     if (in_bytes + ts_bytes > 160 * 1024) return false;
+    static const bool c64_f32 = !getenv("HIFICAR_PAIR_C64_F32") || atoi(getenv("HIFICAR_PAIR_C64_F32")) != 0;  // (A/B runs)
+    if (C == 64 && h->precision == HIFICAR_PREC_F32 && !c64_f32) return false;
     if (nseq > 0) {
         // The fused kernel's tiles are tall (TMc conv1 rows for TMc - (k-1) output rows).  (i) A launch with few tiles leaves most
         // CUs idle behind long serial tiles: small batches run layer by layer.  (ii) Tile quantisation: 1000 rows at k = 11 need 5
@@ -1166,7 +1168,8 @@ static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const Con
         const long long tiles = (long long)nseq * ((rows + tmo - 1) / tmo);
         if (3 * tiles < h->num_cus) return false;
         const double waste = (double)((rows + tmo - 1) / tmo) * TMc / rows;
-        if (waste > (h->precision == HIFICAR_PREC_F32 ? 1.12 : 1.35)) return false;
+        static const double waste_f32 = getenv("HIFICAR_PAIR_WASTE") ? atof(getenv("HIFICAR_PAIR_WASTE")) : 1.12;  // (A/B runs)
+        if (waste > (h->precision == HIFICAR_PREC_F32 ? waste_f32 : 1.35)) return false;
     }
     return true;
 }
