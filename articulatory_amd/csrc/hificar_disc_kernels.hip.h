@@ -127,6 +127,43 @@ __global__ __launch_bounds__(256) void col2im_mask_kernel(const Col2imParams p) 
     }
 }
 
+// The same on four adjacent channels per thread (16-byte loads and stores, one row / group decode per four elements, 32-bit index
+// arithmetic inside a group): blockIdx.y = previous-layer group.  Needs 4 | np, cout_g_prev, cin_g, Kg_pad, every stride and 16-byte aligned
+// bases (checked by the launcher, which otherwise takes the scalar kernel).  Each element's sum runs in the scalar kernel's order (loss
+// gradient, window read, taps ascending): bit-identical results.
+__global__ __launch_bounds__(256) void col2im_mask4_kernel(const Col2imParams p) {
+    const int gp = blockIdx.y;
+    const int nvec = (int)(p.per_group >> 2);
+    const float* dyg = p.dy[gp];
+    const float* yg = p.y + (size_t)gp * p.y_gstride;
+    float* dzg = p.dz + (size_t)gp * p.y_gstride;
+    const int np4 = p.np >> 2;
+    for (int iv = blockIdx.x * 256 + threadIdx.x; iv < nvec; iv += gridDim.x * 256) {
+        const int mp = iv / np4, n = (iv - mp * np4) << 2;
+        const size_t i = (size_t)iv << 2;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.cout_g_prev) {
+            const int seq = mp / p.L_in, t = mp - seq * p.L_in;
+            const int ca = gp * p.cout_g_prev + n;
+            const int g = ca / p.cin_g, c = ca - g * p.cin_g;
+            const float* da = p.dA + (size_t)g * p.da_gstride;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (dyg) s = *reinterpret_cast<const f32x4*>(dyg + i);
+            if (p.win) s += *reinterpret_cast<const f32x4*>(da + ((size_t)seq * p.win_rows + t + p.win_off) * p.win_pitch + c);
+            for (int tap = p.win ? p.kt : (t + p.pad) % p.stride; tap < p.kt; tap += p.stride) {
+                const int num = t + p.pad - tap;
+                if (num < 0) break;
+                const int to = num / p.stride;
+                if (to < p.L_out) s += *reinterpret_cast<const f32x4*>(da + ((size_t)seq * p.L_out + to) * p.Kg_pad + tap * p.cin_g + c);
+            }
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(yg + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = yv[e] > 0.f ? s[e] : s[e] * p.slope;
+        }
+        *reinterpret_cast<f32x4*>(dzg + i) = r;
+    }
+}
+
 // Gradient of the raw signal from a first layer's dA ([M][Kg_pad], cin = 1): dx[b][i] (+)= sum over the positions that read sample i.
 struct SignalGradParams {
     const float* dA;

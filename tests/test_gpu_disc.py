@@ -64,6 +64,27 @@ def test_outputs_and_gradients_vs_reference_golden(tag):
 
 
 @pytest.mark.parametrize("tag", ["small", "default"])
+def test_vectorised_layer_gradient_gather_is_bit_identical(monkeypatch, tag):
+    """col2im_mask4_kernel (four channels per thread, 16-byte accesses; taken where the layer's widths and strides are multiples of 4)
+    sums every element in the scalar kernel's order: parameter and input gradients are bit-identical with HIFICAR_COL2IM_VEC4=0."""
+    _, params, seed, x_np, _ = load(tag)
+    grads = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HIFICAR_COL2IM_VEC4", flag)  # read when the engine is created
+        d, _ = build(params, seed)
+        x = torch.from_numpy(x_np).cuda().requires_grad_(True)
+        loss = 0.0
+        for i, o in enumerate(d(x)):
+            for l, t in enumerate(o):
+                cot = uniform(seed, f"cot.{i}.{l}", tuple(t.shape), -1.0, 1.0) / np.sqrt(np.prod(t.shape[1:]))
+                loss = loss + (t * torch.from_numpy(cot.astype(np.float32)).cuda()).sum()
+        loss.backward()
+        grads[flag] = {k: p.grad.detach().cpu().clone() for k, p in list(d.named_parameters()) + [("x", x)]}
+    for k in grads["1"]:
+        assert torch.equal(grads["1"][k], grads["0"][k]), k
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
 def test_losses_vs_reference_golden(tag):
     """The reference's loss modules' values (adversarial mse / hinge, feature matching) from the engine's own buffers."""
     gold, params, seed, x_np, xh_np = load(tag)
