@@ -80,6 +80,31 @@ __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams q) {
     }
 }
 
+// The previous-layer gather of im2col_kernel (src_mode 2, 4 | cin_g and 4 | prev_cout_g) with blockIdx.y = group and 32-bit index arithmetic
+// inside a group: no 64-bit divisions, the group decode is free.  Pure copies: the same matrix.
+__global__ __launch_bounds__(256) void im2col4_kernel(const Im2colParams p) {
+    const int grp = blockIdx.y;
+    const int k4 = p.Kg_pad >> 2;
+    const int n4 = (int)p.per_group4;
+    const int ci0 = grp * p.cin_g;
+    f32x4* const dst = reinterpret_cast<f32x4*>(p.dst + (size_t)grp * p.dst_gstride);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const int m = i / k4, j = (i - m * k4) * 4;
+        const int seq = m / p.L_out, to = m - seq * p.L_out;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j < p.Kg) {
+            const int tap = j / p.cin_g, c = j - tap * p.cin_g;
+            const int t = to * p.stride + tap - p.pad;
+            if (t >= 0 && t < p.L_in) {
+                const int ca = ci0 + c;
+                const int g = ca / p.prev_cout_g, n = ca - g * p.prev_cout_g;
+                v = *reinterpret_cast<const f32x4*>(p.src + (size_t)g * p.prev_gstride + ((size_t)seq * p.L_in + t) * p.prev_np + n);
+            }
+        }
+        dst[i] = v;
+    }
+}
+
 // dZ of the PREVIOUS layer (one launch per previous-layer group buffer) from this layer's dA buffers.
 struct Col2imParams {
     const float* dA;        // this layer's dA buffers: group g at dA + g * da_gstride, [M][Kg_pad]

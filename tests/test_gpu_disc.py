@@ -65,8 +65,9 @@ def test_outputs_and_gradients_vs_reference_golden(tag):
 
 @pytest.mark.parametrize("tag", ["small", "default"])
 def test_vectorised_layer_gradient_gather_is_bit_identical(monkeypatch, tag):
-    """col2im_mask4_kernel (four channels per thread, 16-byte accesses; taken where the layer's widths and strides are multiples of 4)
-    sums every element in the scalar kernel's order: parameter and input gradients are bit-identical with HIFICAR_COL2IM_VEC4=0."""
+    """col2im_mask4_kernel / im2col4_kernel (four channels per thread, 16-byte accesses, one group per blockIdx.y; taken where the layer's
+    widths and strides are multiples of 4) copy / sum every element in the scalar kernels' order: every layer output, parameter gradient
+    and the input gradient are bit-identical with HIFICAR_COL2IM_VEC4=0."""
     _, params, seed, x_np, _ = load(tag)
     grads = {}
     for flag in ("1", "0"):
@@ -74,7 +75,9 @@ def test_vectorised_layer_gradient_gather_is_bit_identical(monkeypatch, tag):
         d, _ = build(params, seed)
         x = torch.from_numpy(x_np).cuda().requires_grad_(True)
         loss = 0.0
-        for i, o in enumerate(d(x)):
+        outs = d(x)
+        grads["out" + flag] = [t.detach().cpu().clone() for o in outs for t in o]
+        for i, o in enumerate(outs):
             for l, t in enumerate(o):
                 cot = uniform(seed, f"cot.{i}.{l}", tuple(t.shape), -1.0, 1.0) / np.sqrt(np.prod(t.shape[1:]))
                 loss = loss + (t * torch.from_numpy(cot.astype(np.float32)).cuda()).sum()
@@ -82,6 +85,8 @@ def test_vectorised_layer_gradient_gather_is_bit_identical(monkeypatch, tag):
         grads[flag] = {k: p.grad.detach().cpu().clone() for k, p in list(d.named_parameters()) + [("x", x)]}
     for k in grads["1"]:
         assert torch.equal(grads["1"][k], grads["0"][k]), k
+    for a, b in zip(grads["out1"], grads["out0"]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("tag", ["small", "default"])
