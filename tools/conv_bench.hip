@@ -77,7 +77,12 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
         uint16_t* w16;
         hipMalloc(&w16, wel * 2);
         std::vector<uint16_t> hw(wel);
-        for (size_t i = 0; i < wel; ++i) hw[i] = 0x3c00 + (uint16_t)((i * 40503u) & 0xff);  // small bf16 values
+        for (size_t i = 0; i < wel; ++i) hw[i] = 0x3c00 + (uint16_t)((i * 40503u) & 0xff);
+        if (F32) {  // fp32 fragments: small random values in the same buffer
+            float* hf = reinterpret_cast<float*>(hw.data());
+            unsigned s = 777u + b;
+            for (size_t i = 0; i < wel / 2; ++i) { s = s * 1664525u + 1013904223u; hf[i] = ((int)(s >> 9) - (1 << 22)) * (0.05f / (1 << 22)); }
+        }  // small bf16 values
         if (zero_data) std::fill(hw.begin(), hw.end(), 0);
         if (rand_data) {
             unsigned st = 777u + b;
@@ -145,7 +150,7 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
     }
 }
 
-template <int MI, int WM, int WN, int NC16>
+template <int MI, int WM, int WN, int NC16, bool F32 = false>
 void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks, int dil) {
     constexpr int TMc = WM * MI * 32;
     float *x, *y[3], *bias;
@@ -153,6 +158,14 @@ void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks,
     const size_t n = (size_t)nseq * L * C;
     hipMalloc(&x, n * 4); hipMemset(x, 0, n * 4);
     hipMalloc(&xs, n * 4); hipMemset(xs, 0x3c, n * 4);
+    if (F32) {  // exact-fp32 form: random fp32 rows (the clock follows the operands' entropy)
+        std::vector<float> hx(n);
+        unsigned s = 12345u;
+        for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; hx[i] = ((int)(s >> 9) - (1 << 22)) * (1.0f / (1 << 22)); }
+        if (getenv("CONV_BENCH_PAIR_ZERO")) std::fill(hx.begin(), hx.end(), 0.f);  // all-zero activations: same instruction stream, same cycle count
+        hipMemcpy(xs, hx.data(), n * 4, hipMemcpyHostToDevice);
+        hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice);
+    }
     hipMalloc(&zeros, 256); hipMemset(zeros, 0, 256);
     hipMalloc(&bias, C * 4); hipMemset(bias, 0, C * 4);
     PairParams pp;
@@ -167,6 +180,11 @@ void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks,
         hipMalloc(&w1, wel * 2); hipMalloc(&w2, wel * 2);
         std::vector<uint16_t> hw(wel);
         for (size_t i = 0; i < wel; ++i) hw[i] = 0x3c00 + (uint16_t)((i * 40503u) & 0xff);
+        if (F32) {  // fp32 fragments: small random values in the same buffer
+            float* hf = reinterpret_cast<float*>(hw.data());
+            unsigned s = 777u + b;
+            for (size_t i = 0; i < wel / 2; ++i) { s = s * 1664525u + 1013904223u; hf[i] = ((int)(s >> 9) - (1 << 22)) * (0.05f / (1 << 22)); }
+        }
         hipMemcpy(w1, hw.data(), wel * 2, hipMemcpyHostToDevice);
         hipMemcpy(w2, hw.data(), wel * 2, hipMemcpyHostToDevice);
         ConvParams& p = pp.p1[b];
@@ -193,7 +211,7 @@ void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks,
     unsigned long long* trace;
     hipMalloc(&trace, (size_t)G * 2 * 64 * 8); hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
     pp.trace = trace;
-    auto kern = conv_pair_bf16x3_kernel<MI, WM, WN, NC16>;
+    void (*kern)(const PairParams) = F32 ? conv_pair_f32_kernel<MI, WM, WN, NC16> : conv_pair_bf16x3_kernel<MI, WM, WN, NC16>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const size_t lds = pp.in_bytes + pp.ts_bytes;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -203,9 +221,30 @@ void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks,
         for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3(512), lds, 0, pp);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     }
-    printf("%-28s tiles=%d G=%d lds=%zuKB  %.1f us/launch(pair)  %.0f TF-alg\n", label, tile, G, lds / 1024, ms * 100, flops / (ms * 1e-4) / 1e12);
+    printf("%-28s %s tiles=%d G=%d lds=%zuKB  %.1f us/launch(pair)  %.0f TF-alg\n", label, F32 ? "f32" : "bf16x3", tile, G, lds / 1024, ms * 100, flops / (ms * 1e-4) / 1e12);
     std::vector<unsigned long long> ht((size_t)G * 2 * 64);
     hipMemcpy(ht.data(), trace, ht.size() * 8, hipMemcpyDeviceToHost);
+    {   // where the two roles spend a tile, summed over all workgroups and tiles (s_memtime ticks): MFMA waves: wait A | conv1 | wait F + epilogue |
+        // wait B | conv2 | wait C + hand-over;  loader waves: wait A | output pass | wait F + B | staging + wait C
+        double mf[6] = {0, 0, 0, 0, 0, 0}, ld[4] = {0, 0, 0, 0};
+        for (int w = 0; w < G; ++w) {
+            const unsigned long long* m = &ht[(size_t)w * 128];
+            const unsigned long long* l = m + 64;
+            for (int it = 0; 6 * it + 5 < 60 && m[6 * it + 5]; ++it) {
+                for (int q = 0; q < 5; ++q) mf[q] += (double)(m[6 * it + q + 1] - m[6 * it + q]);
+                if (6 * it + 6 < 60 && m[6 * it + 6]) mf[5] += (double)(m[6 * it + 6] - m[6 * it + 5]);
+            }
+            for (int it = 0; 4 * it + 3 < 44 && l[4 * it + 3]; ++it) {
+                for (int q = 0; q < 3; ++q) ld[q] += (double)(l[4 * it + q + 1] - l[4 * it + q]);
+                if (4 * it + 4 < 44 && l[4 * it + 4]) ld[3] += (double)(l[4 * it + 4] - l[4 * it + 3]);
+            }
+        }
+        const double mt = mf[0] + mf[1] + mf[2] + mf[3] + mf[4] + mf[5], lt = ld[0] + ld[1] + ld[2] + ld[3];
+        printf("  MFMA waves: wait A %.1f%% | conv1 %.1f%% | wait F + epilogue %.1f%% | wait B %.1f%% | conv2 %.1f%% | wait C + hand-over %.1f%%\n",
+               100 * mf[0] / mt, 100 * mf[1] / mt, 100 * mf[2] / mt, 100 * mf[3] / mt, 100 * mf[4] / mt, 100 * mf[5] / mt);
+        printf("  loaders   : wait A %.1f%% | output pass %.1f%% | wait F + B %.1f%% | staging + wait C %.1f%%\n", 100 * ld[0] / lt, 100 * ld[1] / lt,
+               100 * ld[2] / lt, 100 * ld[3] / lt);
+    }
     for (int wg : {0}) {
         const unsigned long long* m = &ht[(size_t)wg * 2 * 64];
         const unsigned long long* l = m + 64;
@@ -219,6 +258,15 @@ void run_pair(const char* label, int nseq, int L, int C, int nbr, const int* ks,
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "pairf32")) {  // the fused conv1 -> conv2 kernel in exact fp32: where the two roles spend a tile
+        const int k3[3] = {11, 7, 3};
+        run_pair<4, 2, 2, 4, true>("PAIR stage2 C64 L1000", 64, 1000, 64, 3, k3, 1);
+        run_pair<4, 2, 2, 4, true>("PAIR stage2 C64 L984 (4 full tiles)", 64, 984, 64, 3, k3, 1);
+        run_pair<4, 4, 1, 2, true>("PAIR stage3 C32 L2000", 64, 2000, 32, 3, k3, 1);
+        run_pair<4, 2, 2, 4>("PAIR stage2 C64 L1000", 64, 1000, 64, 3, k3, 1);
+        run_pair<4, 4, 1, 2>("PAIR stage3 C32 L2000", 64, 2000, 32, 3, k3, 1);
+        return 0;
+    }
     {
         const int k3[3] = {11, 7, 3};
         run_pair<4, 2, 2, 4>("PAIR stage2 C64 L1000", 64, 1000, 64, 3, k3, 1);
