@@ -1109,8 +1109,12 @@ struct PackParams {
 //           positions are the packed layer's channels r * cin_g + c, tap q holds kernel index stride * q + r (zero past k).
 //           10: the forward conv (cin' = stride * cin_g -> cout_g, taps 0 .. ntaps - 1);  11: its data gradient (cout_g -> cin', the taps
 //           reversed: a Conv1d with padding ntaps - 1)
-__device__ __forceinline__ void pack_w32_body(const PackParams& p, long long first, long long step) {
-    for (long long i = first; i < p.total; i += step) {
+// (Index type I: int for packs below 2^30 elements — every one in practice — so that the lane / slab / tap / chunk decode runs on 32-bit
+// divisions instead of 64-bit ones; long long otherwise.  Pure copies: the same packed tensor either way.)
+template <typename I>
+__device__ __forceinline__ void pack_w32_body_t(const PackParams& p, I first, I step) {
+    const I total = (I)p.total;
+    for (I i = first; i < total; i += step) {
         if (p.mode >= 4 && p.mode <= 7) {
             if (p.mode == 4) {
                 const int k = (int)(i / p.cout_pad), c = (int)(i - (long long)k * p.cout_pad);
@@ -1126,7 +1130,7 @@ __device__ __forceinline__ void pack_w32_body(const PackParams& p, long long fir
             }
             continue;
         }
-        long long r = i;
+        I r = i;
         const int j = (int)(r & 3);
         r >>= 2;
         const int lane = (int)(r & 63);
@@ -1176,6 +1180,11 @@ __device__ __forceinline__ void pack_w32_body(const PackParams& p, long long fir
         }
         p.dst[i] = val;
     }
+}
+
+__device__ __forceinline__ void pack_w32_body(const PackParams& p, long long first, long long step) {
+    if (p.total < (1LL << 30) && step < (1LL << 30)) pack_w32_body_t<int>(p, (int)first, (int)step);
+    else pack_w32_body_t<long long>(p, first, step);
 }
 
 __global__ __launch_bounds__(256) void pack_w32_kernel(const PackParams p) {
