@@ -543,13 +543,15 @@ class HiFiGANGenerator(torch.nn.Module):
         handle = self._native_handle()
         B, _, T = c.shape
         p = self._params
-        taps = {}
+        Tb = T if T <= 32 else -(-T // 32) * 32  # the launch covers a bucket of frames (hificar.hip: bucket_frames); taps hold that many rows
+        taps, keep = {}, {}
         for name in names:
             parts = name.split(".")
             if name == "ar_feats":
                 shape = (B, p["ar_output"])
             elif name == "input_conv":
-                shape = (B, p["channels"], T)
+                shape = (B, p["channels"], Tb)
+                keep[name] = T
             else:
                 if parts[0] == "upsamples":
                     stage = int(parts[1])
@@ -557,8 +559,9 @@ class HiFiGANGenerator(torch.nn.Module):
                     stage = int(parts[1]) // self.num_blocks
                 else:
                     raise ValueError(f"unknown tap {name!r}")
-                L = T * int(np.prod(p["upsample_scales"][:stage + 1]))
-                shape = (B, p["channels"] // (2 ** (stage + 1)), L)
+                up = int(np.prod(p["upsample_scales"][:stage + 1]))
+                shape = (B, p["channels"] // (2 ** (stage + 1)), Tb * up)
+                keep[name] = T * up
             taps[name] = torch.full(shape, float("nan"), dtype=torch.float32, device=c.device)
         try:
             for name, t in taps.items():
@@ -567,7 +570,7 @@ class HiFiGANGenerator(torch.nn.Module):
             torch.cuda.synchronize(c.device)
         finally:
             self._lib.hificar_debug_tap(handle, None, None, 0)
-        return out, taps
+        return out, {name: (t[..., :keep[name]] if name in keep else t) for name, t in taps.items()}
 
     # ------------------------------------------------------------------ forward paths
     def sync_gradients(self, group=None, average=True, enabled=True):

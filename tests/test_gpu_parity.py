@@ -138,6 +138,27 @@ def test_golden_small_model_every_layer(prec):
         assert rel_err(got, want[name]) < tol, name
 
 
+@pytest.mark.gpu
+def test_debug_taps_at_a_length_that_is_not_a_whole_bucket():
+    """A forward of more than 32 frames covers a bucket of 32-frame multiples (the tail is masked): the debug taps hold the bucket's rows and
+    debug_taps returns the utterance's own.  The tapped last block reproduces the waveform through the output conv's oracle arithmetic."""
+    params = dict(E2W_PARAMS, channels=64)
+    g, w = make(params, "f32")
+    B, T = 2, 40
+    c = torch.from_numpy(synth_features(B, T, 13, seed=41)).permute(0, 2, 1).contiguous().cuda()
+    ar = torch.from_numpy(synth_features(B, 512, 1, seed=42)[:, :, 0] * 0.3).reshape(B, 1, 512).cuda()
+    names = ["input_conv", "upsamples.0", "blocks.11"]
+    with torch.no_grad():
+        y, taps = g.debug_taps(names, c, ar=ar)
+        ref = O.generator_forward(w, params, c.cpu(), ar.cpu())
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < TOLS["f32"]
+    assert tuple(taps["input_conv"].shape) == (B, 64, T)
+    assert tuple(taps["upsamples.0"].shape) == (B, 32, T * 5)
+    assert tuple(taps["blocks.11"].shape) == (B, 4, T * 80)
+    for n in names:
+        assert bool(torch.isfinite(taps[n]).all()), n
+
+
 def test_golden_small_mri_model(prec):
     """MRI-shaped narrow model (scales 8/5/3/2, stage widths 32/16/8/4) against the reference's own output."""
     params = dict(E2W_PARAMS, channels=64, in_channels=20 + 128, upsample_scales=[8, 5, 3, 2], upsample_kernel_sizes=[16, 10, 6, 4])
