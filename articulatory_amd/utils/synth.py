@@ -181,6 +181,90 @@ def synth_state_dict(generator_params: dict, seed: int = 1234, gain: float = 1.0
     return OrderedDict((k, out[k]) for k in spec)
 
 
+GBLOCK_IN = (1, 1, 1, 2, 2, 2, 2, 4, 4, 8)    # divisors of ``channels`` for the ten GBlocks' inputs (gblock_gen.py:63)
+GBLOCK_OUT = (1, 1, 2, 2, 2, 2, 4, 4, 8, 8)   # ... and outputs (gblock_gen.py:64)
+
+
+def gblock_param_spec(
+    in_channels=80,
+    out_channels=1,
+    channels=512,
+    kernel_size=7,
+    g_scales=(8, 8, 2, 2),
+    g_kernel_sizes=(16, 16, 4, 4),
+    use_weight_norm=True,
+    use_ar=False,
+    ar_input=512,
+    ar_hidden=256,
+    ar_output=128,
+    use_spk_id=False,
+    num_spk=None,
+    spk_emb_size=32,
+    **_ignored,
+):
+    """Ordered {state_dict key: shape} of the reference's ``GBlockGenerator(**kwargs)`` (articulatory/models/gblock_gen.py:17-109; the
+    GBlock's layers articulatory/layers/pytorch_layers.py:32-83).  A GBlock's Sequentials hold [ReLU, (Upsample,) conv, ReLU, conv]
+    (conv1), [(Upsample,) conv] (res1) and [ReLU, conv, ReLU, conv] (conv2): the conv indices move by one when ``upsample > 1``.
+    The GBlocks are built with ``norm=False`` but the generator's apply_weight_norm (gblock_gen.py:161-170) wraps every Conv1d, theirs
+    included.  Checked key-for-key against the real class by oracle/make_golden_gblock.py."""
+    spec = OrderedDict()
+
+    def conv(prefix, w_shape):
+        spec[prefix + ".bias"] = (w_shape[0],)
+        if use_weight_norm:
+            spec[prefix + ".weight_g"] = (w_shape[0], 1, 1)
+            spec[prefix + ".weight_v"] = tuple(w_shape)
+        else:  # a plain torch module registers weight before bias
+            del spec[prefix + ".bias"]
+            spec[prefix + ".weight"] = tuple(w_shape)
+            spec[prefix + ".bias"] = (w_shape[0],)
+
+    conv("input_conv", (channels, in_channels, kernel_size))
+    for i, (s, k) in enumerate(zip(g_scales, g_kernel_sizes)):
+        cin, cout = channels // GBLOCK_IN[i], channels // GBLOCK_OUT[i]
+        u = 1 if s > 1 else 0
+        base = f"resamples.{i}"
+        conv(f"{base}.conv1.{1 + u}", (cout, cin, k))
+        conv(f"{base}.conv1.{3 + u}", (cout, cout, k))
+        conv(f"{base}.res1.{u}", (cout, cin, 1))
+        conv(f"{base}.conv2.1", (cout, cout, k))
+        conv(f"{base}.conv2.3", (cout, cout, k))
+    conv("output_conv.1", (out_channels, channels // 8, kernel_size))
+    if use_ar:
+        dims = [ar_input] + [ar_hidden] * 4 + [ar_output]
+        for li in range(5):
+            spec[f"ar_model.model.{2 * li}.weight"] = (dims[li + 1], dims[li])
+            spec[f"ar_model.model.{2 * li}.bias"] = (dims[li + 1],)
+    if use_spk_id:
+        spec["spk_emb_mat.weight"] = (num_spk, spk_emb_size)
+        spec["spk_fc.weight"] = (in_channels, spk_emb_size)
+        spec["spk_fc.bias"] = (in_channels,)
+    return spec
+
+
+def _synth_from_spec(spec, seed, gain):
+    out = OrderedDict()
+    for name, shape in spec.items():
+        if name.endswith(".weight_v") or name.endswith(".weight"):
+            fan_in = int(np.prod(shape[1:]))
+            b = gain * np.sqrt(3.0 / fan_in)
+            out[name] = uniform(seed, name, shape, -b, b)
+        elif name.endswith(".bias"):
+            out[name] = uniform(seed, name, shape, -0.05, 0.05)
+    for name, shape in spec.items():
+        if name.endswith(".weight_g"):
+            v = out[name[: -len("weight_g")] + "weight_v"].astype(np.float64)
+            norm = np.sqrt((v.reshape(v.shape[0], -1) ** 2).sum(axis=1)).reshape(shape)
+            jitter = uniform(seed, name, shape, 0.8, 1.2).astype(np.float64)
+            out[name] = (norm * jitter).astype(np.float32)
+    return OrderedDict((k, out[k]) for k in spec)
+
+
+def synth_gblock_state_dict(generator_params: dict, seed: int = 1234, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """Synthetic reference-layout state_dict of a GBlockGenerator (same recipe as synth_state_dict)."""
+    return _synth_from_spec(gblock_param_spec(**generator_params), seed, gain)
+
+
 def synth_features(batch: int, frames: int, dims: int, seed: int) -> np.ndarray:
     """Synthetic EMA(+pitch) features, (B, T, dims) fp32: N(0,1) with channel 0 ~ U(0,1).
 
