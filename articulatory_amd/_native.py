@@ -23,6 +23,7 @@ PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3}
 # every symbol include/hificar.h declares (tests/test_cabi.py checks the .so exports each one)
 SYMBOLS = (
     "hificar_create",
+    "hificar_gblock_create",
     "hificar_set_weight",
     "hificar_finalize",
     "hificar_set_precision",
@@ -122,6 +123,32 @@ class HificarConfig(ctypes.Structure):
         ("num_ph", ctypes.c_int32),
         ("ph_emb_size", ctypes.c_int32),
         ("use_ph_loss", ctypes.c_int32),
+    ]
+
+
+MAX_GBLOCKS = 10
+
+
+class HificarGBlockConfig(ctypes.Structure):
+    """hificar_gblock_config (include/hificar.h): the keyword arguments of the reference's GBlockGenerator.__init__ (gblock_gen.py:17-31)."""
+
+    _fields_ = [
+        ("in_channels", ctypes.c_int32),
+        ("out_channels", ctypes.c_int32),
+        ("channels", ctypes.c_int32),
+        ("kernel_size", ctypes.c_int32),
+        ("n_blocks", ctypes.c_int32),
+        ("g_scales", ctypes.c_int32 * MAX_GBLOCKS),
+        ("g_kernel_sizes", ctypes.c_int32 * MAX_GBLOCKS),
+        ("use_tanh", ctypes.c_int32),
+        ("use_ar", ctypes.c_int32),
+        ("ar_input", ctypes.c_int32),
+        ("ar_hidden", ctypes.c_int32),
+        ("ar_output", ctypes.c_int32),
+        ("use_spk_id", ctypes.c_int32),
+        ("num_spk", ctypes.c_int32),
+        ("spk_emb_size", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
     ]
 
 
@@ -230,6 +257,8 @@ def load_library():
     vp = ctypes.c_void_p
     lib.hificar_create.argtypes = [ctypes.POINTER(HificarConfig), ctypes.POINTER(vp)]
     lib.hificar_create.restype = ctypes.c_int
+    lib.hificar_gblock_create.argtypes = [ctypes.POINTER(HificarGBlockConfig), ctypes.POINTER(vp)]
+    lib.hificar_gblock_create.restype = ctypes.c_int
     lib.hificar_set_weight.argtypes = [vp, ctypes.c_char_p, vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     lib.hificar_set_weight.restype = ctypes.c_int
     lib.hificar_finalize.argtypes = [vp]
@@ -415,4 +444,30 @@ def make_config(params: dict, precision: int) -> HificarConfig:
     cfg.num_ph = int(params.get("num_ph") or 0)
     cfg.ph_emb_size = int(params.get("ph_emb_size") or 0)
     cfg.use_ph_loss = int(params.get("use_ph_loss", False))
+    return cfg
+
+
+def make_gblock_config(params: dict, precision: int) -> HificarGBlockConfig:
+    """generator_params of a GBlockGenerator (reference keyword names) -> hificar_gblock_config."""
+    cfg = HificarGBlockConfig()
+    scales, ksizes = list(params["g_scales"]), list(params["g_kernel_sizes"])
+    if len(scales) > MAX_GBLOCKS:
+        raise ValueError(f"{len(scales)} GBlocks: the reference's channel plan has {MAX_GBLOCKS} entries (gblock_gen.py:63-64)")
+    cfg.in_channels = params["in_channels"]
+    cfg.out_channels = params["out_channels"]
+    cfg.channels = params["channels"]
+    cfg.kernel_size = params["kernel_size"]
+    cfg.n_blocks = len(scales)
+    for i, (s, k) in enumerate(zip(scales, ksizes)):
+        cfg.g_scales[i] = s
+        cfg.g_kernel_sizes[i] = k
+    cfg.use_tanh = int(params["use_tanh"])
+    cfg.use_ar = int(params["use_ar"])
+    cfg.ar_input = params["ar_input"]
+    cfg.ar_hidden = params["ar_hidden"]
+    cfg.ar_output = params["ar_output"]
+    cfg.use_spk_id = int(params.get("use_spk_id", False))
+    cfg.num_spk = int(params.get("num_spk") or 0)
+    cfg.spk_emb_size = int(params.get("spk_emb_size") or 0)
+    cfg.precision = precision
     return cfg

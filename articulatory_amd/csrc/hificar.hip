@@ -70,8 +70,19 @@ struct ConvLayer {
     float* d_w32c = nullptr;     // fp32 fragments with one K chunk = all channels (fused pair kernel, C <= 64)
 };
 
+// One GBlock of a GBlockGenerator (articulatory/layers/pytorch_layers.py:32-91): conv1 = [ReLU, Upsample, c1a, ReLU, c1b (dilation 3)],
+// res1 = [Upsample, res (1 x 1)], conv2 = [ReLU, c2a (dilation 9), ReLU, c2b (dilation 27)]
+struct GBlockLayers {
+    ConvLayer c1a, c1b, res, c2a, c2b;
+    int scale = 1;
+    int cin = 0, cout = 0;
+};
+
 struct hificar_handle {
     hificar_config cfg;
+    int arch = 0;                  // 0: HiFiGANGenerator (hificar_create); 1: GBlockGenerator (hificar_gblock_create, hificar_gblock.hip.inc)
+    std::vector<GBlockLayers> gb;  // arch 1
+    int c_last = 0;                // channels in front of the output conv
     bool finalized = false;
     int precision = HIFICAR_PREC_F32;
     bool profile_detail = false;   // HIFICAR_PROFILE_DETAIL=1: profile rows carry the layer name
@@ -389,6 +400,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
         }
     }
     const int c_last = stage_channels(c, c.n_stages);
+    h->c_last = c_last;
     expect("output_conv.1.weight", {1, c_last, c.kernel_size});
     expect("output_conv.1.bias", {1});
     if (c.use_ar) {
@@ -650,6 +662,9 @@ extern "C" int hificar_finalize(hificar_handle* h) {
         if ((rc = pack_conv(h, l)) != HIFICAR_OK) return rc;
     for (auto& l : h->convs2)
         if ((rc = pack_conv(h, l)) != HIFICAR_OK) return rc;
+    for (auto& g : h->gb)
+        for (ConvLayer* l : {&g.c1a, &g.c1b, &g.res, &g.c2a, &g.c2b})
+            if ((rc = pack_conv(h, *l)) != HIFICAR_OK) return rc;
     {   // output conv weight (1, C, K) -> [k][C]
         const HostTensor& W = h->tensors.at("output_conv.1.weight");
         const int C = (int)W.shape[1], K = (int)W.shape[2], Cp = round_up(C, 32);  // [k][padded channels]
@@ -689,6 +704,8 @@ extern "C" int hificar_finalize(hificar_handle* h) {
 
 extern "C" int hificar_set_precision(hificar_handle* h, int precision) {
     if (!h) return fail(HIFICAR_E_INVALID, "null handle");
+    if (h->arch == 1 && precision != HIFICAR_PREC_F32)
+        return fail(HIFICAR_E_INVALID, "GBlockGenerator runs in the exact-fp32 arithmetic only (its 1 x 1 residual conv reads raw, un-activated rows)");
     if (precision == HIFICAR_PREC_F32 || precision == HIFICAR_PREC_BF16X3) {
         h->precision = precision;
         return HIFICAR_OK;
@@ -713,6 +730,14 @@ struct Workspace {
 
 static size_t stage_elems(const hificar_handle* h, int B, int T) {
     size_t mx = 0, L = (size_t)T;
+    if (h->arch == 1) {  // GBlockGenerator: the input conv's output and every GBlock's output live in stage buffers
+        mx = L * (size_t)stage_pad(h->cfg, 0);
+        for (const GBlockLayers& g : h->gb) {
+            L *= (size_t)g.scale;
+            mx = std::max(mx, L * (size_t)std::max(g.c1a.cin_pad, g.c1a.cout_pad));
+        }
+        return mx * (size_t)B;
+    }
     for (int i = 0; i < h->cfg.n_stages; ++i) {
         L *= h->cfg.upsample_scales[i];
         mx = std::max(mx, L * (size_t)stage_pad(h->cfg, i + 1));
@@ -751,6 +776,15 @@ extern "C" double hificar_macs(const hificar_handle* h, int B, int T) {
     const hificar_config& c = h->cfg;
     double m = (double)T * c.in_channels * c.channels * c.kernel_size;
     double L = T;
+    for (const GBlockLayers& g : h->gb) {  // arch 1: four k-tap convs and the 1 x 1 residual conv per output row
+        L *= g.scale;
+        m += L * ((double)g.cin * g.cout * (g.c1a.K + 1) + 3.0 * g.cout * g.cout * g.c1a.K);
+    }
+    if (h->arch == 1) {
+        m += L * h->c_last * c.kernel_size;
+        if (c.use_ar) m += (double)c.ar_input * c.ar_hidden + 3.0 * c.ar_hidden * c.ar_hidden + (double)c.ar_hidden * c.ar_output;
+        return m * B;
+    }
     for (int i = 0; i < c.n_stages; ++i) {
         const double cin = stage_channels(c, i), cout = stage_channels(c, i + 1);
         m += L * cin * cout * c.upsample_kernel_sizes[i];
@@ -778,6 +812,13 @@ struct Tape {
     char* x_s[HIFICAR_MAX_STAGES][3][HIFICAR_MAX_DILATIONS] = {};      // activated residual stream after pair d (= next conv1 input)
     float* mlp = nullptr;                                              // (B, 5, 1024) PastFCEncoder layer inputs
     float* fin[3] = {nullptr, nullptr, nullptr};                       // fp32 ResBlock outputs of the LAST stage (output conv backward)
+    // GBlockGenerator (arch 1), per GBlock: the raw and the ReLU'd input at the block's OUTPUT rate (nearest-upsampled copies: the weight
+    // gradients of res1 / conv1's first conv contract over them), and the ReLU'd inputs of the other three convs
+    char* g_xu[HIFICAR_MAX_GBLOCKS] = {};
+    char* g_a1u[HIFICAR_MAX_GBLOCKS] = {};
+    char* g_a2[HIFICAR_MAX_GBLOCKS] = {};
+    char* g_a3[HIFICAR_MAX_GBLOCKS] = {};
+    char* g_a4[HIFICAR_MAX_GBLOCKS] = {};
     size_t bytes = 0;
 };
 
@@ -970,6 +1011,7 @@ struct ConvIO {
     long long x_seq_bytes = 0;        // input row addressing (ConvParams::x_seq_bytes / x_row_bytes); 0: packed rows
     int x_row_bytes = 0;
     int x_rows = 0;                   // input rows per sequence when they differ from the launch's rows (ConvParams::x_rows)
+    int x_up = 0;                     // nearest-neighbour upsampling of the input rows while staging (ConvParams::x_up); the input then has rows / x_up rows
 };
 
 // Replicas of every branch at regular strides (the groups of a grouped conv): see MultiConvParams::zrep
@@ -1062,13 +1104,20 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         mp.p[b].x_seq_bytes = io[b].x_seq_bytes;
         mp.p[b].x_row_bytes = io[b].x_row_bytes;
         mp.p[b].x_rows = io[b].x_rows;
+        if (io[b].x_up > 1) {
+            if (rows % io[b].x_up != 0 || io[b].x_seq_bytes != 0 || io[b].x_row_bytes != 0)
+                return fail(HIFICAR_E_INVALID, "internal: upsampled input rows of %s", Lb.name.c_str());
+            mp.p[b].x_up = io[b].x_up;
+            mp.p[b].x_up_rcp = (unsigned)(0x100000000ull / (unsigned)io[b].x_up) + 1u;
+            mp.p[b].x_seq_bytes = (long long)(rows / io[b].x_up) * Lb.cin_pad * 4;
+        }
         mp.p[b].zeros = h->d_zeros;
         mp.p[b].slope_out = slope_out;
         mp.p[b].cout_real = Lb.cout_pad;
         if (f32) mp.p[b].w16 = reinterpret_cast<const bf16x8*>(Lb.d_w32);
         const double pos = (double)nseq * rows;
         flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K * zr.n;
-        bytes += 4.0 * (pos * Lb.cin_pad + pos * Lb.cout_total * ((io[b].res ? 1 : 0) + (io[b].y ? 1 : 0) + (io[b].ys ? 1 : 0)) +
+        bytes += 4.0 * (pos * Lb.cin_pad / std::max(1, io[b].x_up) + pos * Lb.cout_total * ((io[b].res ? 1 : 0) + (io[b].y ? 1 : 0) + (io[b].ys ? 1 : 0)) +
                         (double)Lb.cin * Lb.cout * Lb.K);
     }
     const size_t buf_bytes = round_up_sz((size_t)(TM + halo_all) * RB, 1024);
@@ -1293,6 +1342,54 @@ static int emit_tap(hificar_handle* h, const std::string& name, const void* src,
 
 static bool tap_wanted(const hificar_handle* h, const std::string& name) { return h->taps.count(name) != 0; }
 
+// LeakyReLU(0.01) + Conv1d(C -> 1, k) + tanh on the mean of `nin` fp32 inputs (hifigan.py:146-159, 231; gblock_gen.py:71-93, 131)
+static int launch_output_conv(hificar_handle* h, const float* const* fin, int nin, int Cpad, int rows, int B, int T, float* out,
+                              int64_t out_bstride, const int32_t* seq_len, const Ragged& rg, const int2* slots, hipStream_t stream) {
+    const hificar_config& cfg = h->cfg;
+    OutConvParams op;
+    memset(&op, 0, sizeof(op));
+    op.x0 = fin[0];
+    op.x1 = nin > 1 ? fin[1] : nullptr;
+    op.x2 = nin > 2 ? fin[2] : nullptr;
+    op.nin = nin;
+    op.w = h->d_out_w;
+    op.bias = h->out_bias;
+    op.bias_ptr = h->d_out_bias;
+    op.out = out;
+    op.out_bstride = out_bstride;
+    op.L = rows;
+    op.C = Cpad;
+    op.K = cfg.kernel_size;
+    op.slope = 0.01f;
+    op.use_tanh = cfg.use_tanh;
+    op.seq_len = seq_len;
+    op.len_const = seq_len ? -1 : rg.const_len;
+    op.len_f0 = rg.f0;
+    op.len_max = T;
+    op.len_mul = rows / T;
+    op.slots = slots;
+    op.hop = h->hop;
+    // samples per workgroup: 256, or what a 64-KB LDS tile of (TR + K - 1) rows x (C + 1) floats + the weights allows
+    const long long fit = ((long long)64 * 1024 / 4 - (long long)op.K * op.C) / (op.C + 1) - (op.K - 1);
+    if (fit < 1) return fail(HIFICAR_E_INVALID, "output conv: %d channels x kernel %d does not fit the LDS tile", op.C, op.K);
+    op.TR = (int)std::min<long long>(256, fit);
+    const size_t lds = ((size_t)(op.TR + op.K - 1) * (op.C + 1) + (size_t)op.K * op.C) * sizeof(float);
+    {
+        const double pos = (double)B * rows;
+        ProfScope prof(h, stream, "output_conv_kernel", 2.0 * pos * op.C * op.K, 4.0 * pos * (op.C * nin + 1));
+        hipLaunchKernelGGL(output_conv_kernel, dim3((rows + op.TR - 1) / op.TR, B), dim3(256), lds, stream, op);
+    }
+    HIP_TRY(hipGetLastError());
+    return HIFICAR_OK;
+}
+
+struct Tape;
+struct Cond;
+struct Workspace;
+// GBlockGenerator body of a forward: input conv -> GBlocks -> output conv (hificar_gblock.hip.inc)
+static int gblock_forward(hificar_handle* h, float* out, int64_t out_bstride, int B, int T, const Workspace& ws, hipStream_t stream,
+                          const int32_t* seq_len, const Ragged& rg, const int2* slots, const Tape* tp);
+
 // One generator forward on B sequences of T frames.
 //   c: element (b, ch, t) at c[b*c_bstride + ch*c_cstride + t];  prev: (b, i) at prev[b*prev_bstride + i] or null
 //   out: sample (b, n) at out[b*out_bstride + n]
@@ -1355,6 +1452,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
         hipLaunchKernelGGL(front_kernel, dim3(B), dim3(kFrontThreads), 0, stream, fp);
     }
     HIP_TRY(hipGetLastError());
+    if (h->arch == 1) return gblock_forward(h, out, out_bstride, B, T, ws, stream, seq_len, rg, slots, tp);
 
     int rc;
     int rows = T;
@@ -1554,41 +1652,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
         HIP_TRY(hipGetLastError());
     }
     // 4. output conv: LeakyReLU(0.01) + Conv1d + tanh (hifigan.py:146-159)
-    OutConvParams op;
-    memset(&op, 0, sizeof(op));
-    op.x0 = fin[0];
-    op.x1 = nbk > 1 ? fin[1] : nullptr;
-    op.x2 = nbk > 2 ? fin[2] : nullptr;
-    op.nin = nbk;
-    op.w = h->d_out_w;
-    op.bias = h->out_bias;
-    op.bias_ptr = h->d_out_bias;
-    op.out = out;
-    op.out_bstride = out_bstride;
-    op.L = rows;
-    op.C = stage_pad(cfg, cfg.n_stages);
-    op.K = cfg.kernel_size;
-    op.slope = 0.01f;
-    op.use_tanh = cfg.use_tanh;
-    op.seq_len = seq_len;
-    op.len_const = seq_len ? -1 : rg.const_len;
-    op.len_f0 = f0;
-    op.len_max = T;
-    op.len_mul = rows / T;
-    op.slots = slots;
-    op.hop = h->hop;
-    // samples per workgroup: 256, or what a 64-KB LDS tile of (TR + K - 1) rows x (C + 1) floats + the weights allows
-    const long long fit = ((long long)64 * 1024 / 4 - (long long)op.K * op.C) / (op.C + 1) - (op.K - 1);
-    if (fit < 1) return fail(HIFICAR_E_INVALID, "output conv: %d channels x kernel %d does not fit the LDS tile", op.C, op.K);
-    op.TR = (int)std::min<long long>(256, fit);
-    const size_t lds = ((size_t)(op.TR + op.K - 1) * (op.C + 1) + (size_t)op.K * op.C) * sizeof(float);
-    {
-        const double pos = (double)B * rows;
-        ProfScope prof(h, stream, "output_conv_kernel", 2.0 * pos * op.C * op.K, 4.0 * pos * (op.C * nbk + 1));
-        hipLaunchKernelGGL(output_conv_kernel, dim3((rows + op.TR - 1) / op.TR, B), dim3(256), lds, stream, op);
-    }
-    HIP_TRY(hipGetLastError());
-    return HIFICAR_OK;
+    return launch_output_conv(h, fin, nbk, stage_pad(cfg, cfg.n_stages), rows, B, T, out, out_bstride, seq_len, rg, slots, stream);
 }
 
 static int check_ready(hificar_handle* h, int B, int T, void* ws, size_t ws_bytes) {
@@ -1825,5 +1889,6 @@ extern "C" int hificar_pcm16(const float* x, int16_t* y, size_t n, void* stream)
 }
 
 #include "hificar_train.hip.inc"
+#include "hificar_gblock.hip.inc"
 #include "hificar_disc.hip.inc"
 #include "hificar_mel.hip.inc"

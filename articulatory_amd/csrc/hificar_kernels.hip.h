@@ -82,6 +82,12 @@ struct ConvParams {
     // multi-tap conv over rows of `stride` input positions (hificar_disc.hip.inc, polyphase-input form) reads ntaps - 1 rows past its
     // last output row, and its data gradient writes more rows than it reads.  Rows in [0, x_rows) are staged, the rest read as zeros.
     int x_rows;
+    // nearest-neighbour upsampling of the input rows in front of the conv (torch.nn.Upsample(scale_factor = x_up) of a GBlock,
+    // articulatory/layers/pytorch_layers.py:48-56): staged row t reads input row t / x_up, so the upsampled tensor never exists in HBM.
+    // 0 / 1: none.  The sequence pitch of the (shorter) input then comes from x_seq_bytes.  x_up_rcp = floor(2^32 / x_up) + 1 (host):
+    // t / x_up == umulhi(t, x_up_rcp) for 0 <= t < 2^32 / x_up — two instructions in the staging loop instead of a division.
+    int x_up;
+    unsigned x_up_rcp;
 };
 
 __device__ __forceinline__ bool is_ragged(const ConvParams& p) { return p.seq_len != nullptr || p.len_const >= 0; }
@@ -505,8 +511,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                 const int t = T.t0 + p.off_min + r;
                 const char* src = p.zeros;
                 if (r < R && t >= 0 && t < Ls) {
-                    if constexpr (F32) src = xs_z + (size_t)t * row_bytes + 2 * c0b + sl * 16;
-                    else src = xs_z + (size_t)t * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
+                    const int ts = p.x_up > 1 ? (int)__umulhi((unsigned)t, p.x_up_rcp) : t;  // (nearest upsample: out[t] = in[t / s])
+                    if constexpr (F32) src = xs_z + (size_t)ts * row_bytes + 2 * c0b + sl * 16;
+                    else src = xs_z + (size_t)ts * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
                 }
                 // aux = 2: non-temporal — an activation row is staged by one or two CUs only (+2.3 % end to end)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,

@@ -10,7 +10,8 @@ from .discriminator import (  # noqa: F401
     HiFiGANPeriodDiscriminator,
     HiFiGANScaleDiscriminator,
 )
+from .gblock import GBlockGenerator  # noqa: F401
 from .hifigan import HiFiGANGenerator  # noqa: F401
 
-__all__ = ["HiFiGANGenerator", "HiFiGANMultiScaleMultiPeriodDiscriminator", "HiFiGANMultiScaleDiscriminator", "HiFiGANMultiPeriodDiscriminator",
+__all__ = ["HiFiGANGenerator", "GBlockGenerator", "HiFiGANMultiScaleMultiPeriodDiscriminator", "HiFiGANMultiScaleDiscriminator", "HiFiGANMultiPeriodDiscriminator",
            "HiFiGANScaleDiscriminator", "HiFiGANPeriodDiscriminator"]

@@ -234,122 +234,10 @@ class _GeneratorFunction(torch.autograd.Function):
         return (None, dc, dar, None, None, None, *gw)
 
 
-class HiFiGANGenerator(torch.nn.Module):
-    """HiFiGAN generator module (MI355X-native forward and backward)."""
-
-    def __init__(
-        self,
-        in_channels=80,
-        out_channels=1,
-        channels=512,
-        kernel_size=7,
-        upsample_scales=(8, 8, 2, 2),
-        upsample_kernel_sizes=(16, 16, 4, 4),
-        paddings=None,
-        output_paddings=None,
-        resblock_kernel_sizes=(3, 7, 11),
-        resblock_dilations=[(1, 3, 5), (1, 3, 5), (1, 3, 5)],
-        use_additional_convs=True,
-        bias=True,
-        nonlinear_activation="LeakyReLU",
-        nonlinear_activation_params={"negative_slope": 0.1},
-        use_weight_norm=True,
-        use_ar=False,
-        ar_input=512,
-        ar_hidden=256,
-        ar_output=128,
-        use_tanh=True,
-        use_spk_id=False,
-        num_spk=None,
-        spk_emb_size=32,
-        use_ph=False,
-        num_ph=None,
-        ph_emb_size=8,
-        use_ph_loss=False,
-        final_scale=None,  # present in e2w_hifigan_car.yaml:42; unused by the network
-        extra_art=None,  # present in e2w_hifigan_car.yaml:54; only read by the WSOLA driver
-        precision=None,  # "f32" (default: the reference's IEEE fp32 products; or $HIFICAR_PRECISION) | "bf16x3" (opt-in fast mode,
-                         # 16-bit-significand products): conv arithmetic, see DESIGN.md §3
-    ):
-        super().__init__()
-        # same validity checks as the reference (hifigan.py:78-80)
-        assert kernel_size % 2 == 1, "Kernel size must be odd number."
-        assert len(upsample_scales) == len(upsample_kernel_sizes)
-        assert len(resblock_dilations) == len(resblock_kernel_sizes)
-        if use_spk_id and use_ph:
-            # spk_fc maps to in_channels values but is added before the phoneme channels are appended (hifigan.py:212-220):
-            # the reference fails with a shape mismatch in forward; fail at construction here
-            raise ValueError("use_spk_id together with use_ph is ill-formed in the reference (shape mismatch at hifigan.py:216)")
-        if nonlinear_activation != "LeakyReLU":
-            raise NotImplementedError(f"nonlinear_activation={nonlinear_activation!r}: only LeakyReLU is built")
-        for name, val in (("paddings", paddings), ("output_paddings", output_paddings)):
-            if val is not None and any(v != "default" for v in val):
-                raise NotImplementedError(f"{name}: only None / 'default' entries are supported (as in the reference)")
-        if precision is None:
-            precision = os.environ.get("HIFICAR_PRECISION", "f32")
-        if precision not in _native.PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(_native.PRECISIONS)}")
-
-        self.use_ar = use_ar
-        self.use_spk_id = use_spk_id
-        self.use_ph = use_ph
-        self.use_ph_loss = use_ph_loss
-        self.num_upsamples = len(upsample_kernel_sizes)
-        self.num_blocks = len(resblock_kernel_sizes)
-        slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
-        self._params = dict(
-            in_channels=in_channels, out_channels=out_channels, channels=channels, kernel_size=kernel_size,
-            upsample_scales=list(upsample_scales), upsample_kernel_sizes=list(upsample_kernel_sizes),
-            resblock_kernel_sizes=list(resblock_kernel_sizes), resblock_dilations=[list(d) for d in resblock_dilations],
-            use_additional_convs=use_additional_convs, bias=bias,
-            nonlinear_activation_params={"negative_slope": slope}, use_tanh=use_tanh,
-            use_ar=use_ar, ar_input=ar_input, ar_hidden=ar_hidden, ar_output=ar_output,
-            use_spk_id=use_spk_id, num_spk=num_spk, spk_emb_size=spk_emb_size, use_ph=use_ph, num_ph=num_ph,
-            ph_emb_size=ph_emb_size, use_ph_loss=use_ph_loss,
-        )
-        self.hop = int(np.prod(upsample_scales))
-        self.precision = precision
-
-        self.input_conv = _ConvParams((channels, in_channels, kernel_size), channels)
-        self.upsamples = torch.nn.ModuleList()
-        self.blocks = torch.nn.ModuleList()
-        for i in range(self.num_upsamples):
-            cin, cout = channels // (2 ** i), channels // (2 ** (i + 1))
-            k = upsample_kernel_sizes[i]
-            # ConvTranspose1d weight is (Cin, Cout, K); torch computes its fan_in from dim 1
-            self.upsamples.append(torch.nn.Sequential(torch.nn.LeakyReLU(slope), _ConvParams((cin, cout, k), cout, fan_in=cout * k)))
-            for j in range(self.num_blocks):
-                self.blocks.append(_ResBlockParams(resblock_kernel_sizes[j], cout, resblock_dilations[j], bias,
-                                                   use_additional_convs, slope))
-        c_last = channels // (2 ** self.num_upsamples)
-        out_mods = [torch.nn.LeakyReLU(), _ConvParams((out_channels, c_last, kernel_size), out_channels)]
-        if use_tanh:
-            out_mods.append(torch.nn.Tanh())
-        self.output_conv = torch.nn.Sequential(*out_mods)
-        if use_ar:
-            self.ar_model = _PastFCParams(ar_input, ar_hidden, ar_output)
-        # speaker / phoneme conditioning parameters (hifigan.py:176-189), same names and registration order as the reference
-        if use_spk_id:
-            assert num_spk is not None
-            self.spk_emb_mat = torch.nn.Embedding(num_spk, spk_emb_size)
-            self.spk_fc = torch.nn.Linear(spk_emb_size, in_channels)
-        if use_ph:
-            assert num_ph is not None
-            self.ph_emb_mat = torch.nn.Embedding(num_ph, ph_emb_size)
-        if use_ph_loss:
-            assert num_ph is not None
-            assert self.hop % 2 == 0
-            self.ph_fc = torch.nn.Linear(c_last, num_ph)
-
-        if use_weight_norm:
-            self.apply_weight_norm()
-        else:
-            self.reset_parameters()
-
-        self._handle = None
-        self._workspaces = {}
-        self._lib = None
-        self._grad_sync = None
+class _NativeGenerator(torch.nn.Module):
+    """What the generator classes of this package share: parameter plumbing (weight norm, folded state, the raw-parameter hand-over), the
+    libhificar handle, workspaces, the inference / AR-synthesis / autograd entry points.  A subclass builds the parameter-holder modules with
+    the reference's names in ``__init__``, fills ``self._params`` and implements ``_create_handle``."""
 
     # ------------------------------------------------------------------ parameter plumbing
     def _conv_params(self):
@@ -484,14 +372,13 @@ class HiFiGANGenerator(torch.nn.Module):
         dev = self._device()
         if dev.type != "cuda":
             raise RuntimeError(
-                "HiFiGANGenerator: parameters are on %s; the generator forward only exists as HIP kernels "
-                "(move the model to a MI355X with .to('cuda')). There is no CPU fallback." % dev)
+                "%s: parameters are on %s; the generator forward only exists as HIP kernels "
+                "(move the model to a MI355X with .to('cuda')). There is no CPU fallback." % (type(self).__name__, dev))
         lib = _native.load_library()
         self._lib = lib
-        cfg = _native.make_config(self._params, _native.PRECISIONS[self.precision])
         handle = ctypes.c_void_p()
         with torch.cuda.device(dev):
-            _native.check(lib.hificar_create(ctypes.byref(cfg), ctypes.byref(handle)), "hificar_create")
+            self._create_handle(lib, handle)
             try:
                 for name, t in self.folded_state().items():
                     shape = (ctypes.c_int64 * t.dim())(*t.shape)
@@ -535,38 +422,24 @@ class HiFiGANGenerator(torch.nn.Module):
         return [dict(name=stats[i].name.decode(), launches=int(stats[i].launches), total_ms=float(stats[i].total_ms),
                      flops=float(stats[i].flops), bytes=float(stats[i].bytes)) for i in range(min(n.value, 96))]
 
-    def debug_taps(self, names, c, ar=None):
+    def debug_taps(self, names, c, ar=None, spk_id=None):
         """Parity aid (C ABI: hificar_debug_tap): one forward that also returns the named per-layer intermediates in the
         reference's (B, C, L) layout — what forward hooks on the reference's modules see.  Names: "ar_feats", "input_conv",
         "upsamples.<i>", "blocks.<n>.convs1.<d>", "blocks.<n>.x.<d>" (residual stream after dilation d), "blocks.<n>".
         Returns (out, {name: tensor})."""
         handle = self._native_handle()
         B, _, T = c.shape
-        p = self._params
         Tb = T if T <= 32 else -(-T // 32) * 32  # the launch covers a bucket of frames (hificar.hip: bucket_frames); taps hold that many rows
         taps, keep = {}, {}
         for name in names:
-            parts = name.split(".")
-            if name == "ar_feats":
-                shape = (B, p["ar_output"])
-            elif name == "input_conv":
-                shape = (B, p["channels"], Tb)
-                keep[name] = T
-            else:
-                if parts[0] == "upsamples":
-                    stage = int(parts[1])
-                elif parts[0] == "blocks":
-                    stage = int(parts[1]) // self.num_blocks
-                else:
-                    raise ValueError(f"unknown tap {name!r}")
-                up = int(np.prod(p["upsample_scales"][:stage + 1]))
-                shape = (B, p["channels"] // (2 ** (stage + 1)), Tb * up)
-                keep[name] = T * up
+            shape, rows = self._tap_shape(name, B, T, Tb)
+            if rows is not None:
+                keep[name] = rows
             taps[name] = torch.full(shape, float("nan"), dtype=torch.float32, device=c.device)
         try:
             for name, t in taps.items():
                 _native.check(self._lib.hificar_debug_tap(handle, name.encode(), t.data_ptr(), t.numel()), "hificar_debug_tap")
-            out = self.forward(c, ar=ar)
+            out = self.forward(c, spk_id=spk_id, ar=ar)
             torch.cuda.synchronize(c.device)
         finally:
             self._lib.hificar_debug_tap(handle, None, None, 0)
@@ -650,7 +523,7 @@ class HiFiGANGenerator(torch.nn.Module):
 
     def _check_input(self, c):
         if not c.is_cuda:
-            raise RuntimeError("HiFiGANGenerator.forward needs a CUDA/HIP tensor; there is no CPU fallback")
+            raise RuntimeError(f"{type(self).__name__}.forward needs a CUDA/HIP tensor; there is no CPU fallback")
         cf = (self._params["in_channels"] - (self._params["ar_output"] if self.use_ar else 0)
               - (self._params["ph_emb_size"] if self.use_ph else 0))
         if c.dim() != 3 or c.shape[1] != cf:
@@ -781,3 +654,142 @@ class HiFiGANGenerator(torch.nn.Module):
             c = (c - self.mean) / self.scale
         c = self.forward(c.transpose(1, 0).unsqueeze(0))
         return c.squeeze(0).transpose(1, 0)
+
+
+class HiFiGANGenerator(_NativeGenerator):
+    """HiFiGAN generator module (MI355X-native forward and backward)."""
+
+    def __init__(
+        self,
+        in_channels=80,
+        out_channels=1,
+        channels=512,
+        kernel_size=7,
+        upsample_scales=(8, 8, 2, 2),
+        upsample_kernel_sizes=(16, 16, 4, 4),
+        paddings=None,
+        output_paddings=None,
+        resblock_kernel_sizes=(3, 7, 11),
+        resblock_dilations=[(1, 3, 5), (1, 3, 5), (1, 3, 5)],
+        use_additional_convs=True,
+        bias=True,
+        nonlinear_activation="LeakyReLU",
+        nonlinear_activation_params={"negative_slope": 0.1},
+        use_weight_norm=True,
+        use_ar=False,
+        ar_input=512,
+        ar_hidden=256,
+        ar_output=128,
+        use_tanh=True,
+        use_spk_id=False,
+        num_spk=None,
+        spk_emb_size=32,
+        use_ph=False,
+        num_ph=None,
+        ph_emb_size=8,
+        use_ph_loss=False,
+        final_scale=None,  # present in e2w_hifigan_car.yaml:42; unused by the network
+        extra_art=None,  # present in e2w_hifigan_car.yaml:54; only read by the WSOLA driver
+        precision=None,  # "f32" (default: the reference's IEEE fp32 products; or $HIFICAR_PRECISION) | "bf16x3" (opt-in fast mode,
+                         # 16-bit-significand products): conv arithmetic, see DESIGN.md §3
+    ):
+        super().__init__()
+        # same validity checks as the reference (hifigan.py:78-80)
+        assert kernel_size % 2 == 1, "Kernel size must be odd number."
+        assert len(upsample_scales) == len(upsample_kernel_sizes)
+        assert len(resblock_dilations) == len(resblock_kernel_sizes)
+        if use_spk_id and use_ph:
+            # spk_fc maps to in_channels values but is added before the phoneme channels are appended (hifigan.py:212-220):
+            # the reference fails with a shape mismatch in forward; fail at construction here
+            raise ValueError("use_spk_id together with use_ph is ill-formed in the reference (shape mismatch at hifigan.py:216)")
+        if nonlinear_activation != "LeakyReLU":
+            raise NotImplementedError(f"nonlinear_activation={nonlinear_activation!r}: only LeakyReLU is built")
+        for name, val in (("paddings", paddings), ("output_paddings", output_paddings)):
+            if val is not None and any(v != "default" for v in val):
+                raise NotImplementedError(f"{name}: only None / 'default' entries are supported (as in the reference)")
+        if precision is None:
+            precision = os.environ.get("HIFICAR_PRECISION", "f32")
+        if precision not in _native.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_native.PRECISIONS)}")
+
+        self.use_ar = use_ar
+        self.use_spk_id = use_spk_id
+        self.use_ph = use_ph
+        self.use_ph_loss = use_ph_loss
+        self.num_upsamples = len(upsample_kernel_sizes)
+        self.num_blocks = len(resblock_kernel_sizes)
+        slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self._params = dict(
+            in_channels=in_channels, out_channels=out_channels, channels=channels, kernel_size=kernel_size,
+            upsample_scales=list(upsample_scales), upsample_kernel_sizes=list(upsample_kernel_sizes),
+            resblock_kernel_sizes=list(resblock_kernel_sizes), resblock_dilations=[list(d) for d in resblock_dilations],
+            use_additional_convs=use_additional_convs, bias=bias,
+            nonlinear_activation_params={"negative_slope": slope}, use_tanh=use_tanh,
+            use_ar=use_ar, ar_input=ar_input, ar_hidden=ar_hidden, ar_output=ar_output,
+            use_spk_id=use_spk_id, num_spk=num_spk, spk_emb_size=spk_emb_size, use_ph=use_ph, num_ph=num_ph,
+            ph_emb_size=ph_emb_size, use_ph_loss=use_ph_loss,
+        )
+        self.hop = int(np.prod(upsample_scales))
+        self.precision = precision
+
+        self.input_conv = _ConvParams((channels, in_channels, kernel_size), channels)
+        self.upsamples = torch.nn.ModuleList()
+        self.blocks = torch.nn.ModuleList()
+        for i in range(self.num_upsamples):
+            cin, cout = channels // (2 ** i), channels // (2 ** (i + 1))
+            k = upsample_kernel_sizes[i]
+            # ConvTranspose1d weight is (Cin, Cout, K); torch computes its fan_in from dim 1
+            self.upsamples.append(torch.nn.Sequential(torch.nn.LeakyReLU(slope), _ConvParams((cin, cout, k), cout, fan_in=cout * k)))
+            for j in range(self.num_blocks):
+                self.blocks.append(_ResBlockParams(resblock_kernel_sizes[j], cout, resblock_dilations[j], bias,
+                                                   use_additional_convs, slope))
+        c_last = channels // (2 ** self.num_upsamples)
+        out_mods = [torch.nn.LeakyReLU(), _ConvParams((out_channels, c_last, kernel_size), out_channels)]
+        if use_tanh:
+            out_mods.append(torch.nn.Tanh())
+        self.output_conv = torch.nn.Sequential(*out_mods)
+        if use_ar:
+            self.ar_model = _PastFCParams(ar_input, ar_hidden, ar_output)
+        # speaker / phoneme conditioning parameters (hifigan.py:176-189), same names and registration order as the reference
+        if use_spk_id:
+            assert num_spk is not None
+            self.spk_emb_mat = torch.nn.Embedding(num_spk, spk_emb_size)
+            self.spk_fc = torch.nn.Linear(spk_emb_size, in_channels)
+        if use_ph:
+            assert num_ph is not None
+            self.ph_emb_mat = torch.nn.Embedding(num_ph, ph_emb_size)
+        if use_ph_loss:
+            assert num_ph is not None
+            assert self.hop % 2 == 0
+            self.ph_fc = torch.nn.Linear(c_last, num_ph)
+
+        if use_weight_norm:
+            self.apply_weight_norm()
+        else:
+            self.reset_parameters()
+
+        self._handle = None
+        self._workspaces = {}
+        self._lib = None
+        self._grad_sync = None
+
+    def _tap_shape(self, name, B, T, Tb):
+        """(buffer shape, valid rows or None) of a debug tap; Tb = the launch's bucket of frames."""
+        p = self._params
+        parts = name.split(".")
+        if name == "ar_feats":
+            return (B, p["ar_output"]), None
+        if name == "input_conv":
+            return (B, p["channels"], Tb), T
+        if parts[0] == "upsamples":
+            stage = int(parts[1])
+        elif parts[0] == "blocks":
+            stage = int(parts[1]) // self.num_blocks
+        else:
+            raise ValueError(f"unknown tap {name!r}")
+        up = int(np.prod(p["upsample_scales"][:stage + 1]))
+        return (B, p["channels"] // (2 ** (stage + 1)), Tb * up), T * up
+
+    def _create_handle(self, lib, handle):
+        cfg = _native.make_config(self._params, _native.PRECISIONS[self.precision])
+        _native.check(lib.hificar_create(ctypes.byref(cfg), ctypes.byref(handle)), "hificar_create")

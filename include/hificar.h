@@ -7,6 +7,7 @@
  * reference Python interface it stands in for (paths relative to the reference repo):
  *
  *   hificar_create          HiFiGANGenerator.__init__            articulatory/models/hifigan.py:24-196
+ *   hificar_gblock_create   GBlockGenerator.__init__             articulatory/models/gblock_gen.py:17-109 (forward :111-132 = hificar_forward*)
  *   hificar_set_weight      load_state_dict + remove_weight_norm articulatory/utils/utils.py:340-342,
  *                                                                articulatory/models/hifigan.py:256-266
  *   hificar_finalize        model.eval().to(device)              egs/ema/voc1/local/predict_wav.py:114-115
@@ -99,6 +100,40 @@ typedef struct hificar_config {
 
 /* Build an (empty) generator for these hyper-parameters on the current HIP device. */
 int hificar_create(const hificar_config* cfg, hificar_handle** out);
+
+/* The reference's OTHER a2w generator behind the same plugin surface: GBlockGenerator (articulatory/models/gblock_gen.py:14-132; GAN-TTS
+ * style GBlocks, articulatory/layers/pytorch_layers.py:32-91).  Mirrors the keyword arguments of GBlockGenerator.__init__
+ * (gblock_gen.py:17-31).  input conv (kernel_size) -> n_blocks GBlocks -> LeakyReLU(0.01) + conv (kernel_size) (+ tanh); GBlock i maps
+ * channels / in_div[i] -> channels / out_div[i] channels with the reference's hard-coded plan in_div = 1,1,1,2,2,2,2,4,4,8,
+ * out_div = 1,1,2,2,2,2,4,4,8,8 (gblock_gen.py:63-64) and upsamples by g_scales[i] (nearest neighbour):
+ *     y = conv_k,d3(ReLU(conv_k(up(ReLU(x))))) + conv_1(up(x));   out = y + conv_k,d27(ReLU(conv_k,d9(ReLU(y))))
+ * The handle is an ordinary hificar_handle: hificar_set_weight (names "input_conv.weight", "resamples.<i>.conv1.<1|2>.weight",
+ * "resamples.<i>.conv1.<3|4>.weight", "resamples.<i>.res1.<0|1>.weight" (cout, cin, 1), "resamples.<i>.conv2.{1,3}.weight", the biases,
+ * "output_conv.1.*", "ar_model.model.*", "spk_*" — the Sequential indices move by one when g_scales[i] > 1, as in the reference's
+ * state_dict), hificar_finalize, hificar_forward[_cond / _ragged], hificar_ar_loop*, hificar_forward_train[_cond], hificar_backward[_cond],
+ * hificar_set_parameters_device, ... all take it.  Exact-fp32 arithmetic only (res1 consumes the raw, un-activated rows).
+ * Restrictions (each is a configuration the reference class itself cannot run, see oracle/make_golden_gblock.py): g_kernel_sizes odd;
+ * the last GBlock must end at channels / 8 channels (n_blocks = 9 or 10). */
+#define HIFICAR_MAX_GBLOCKS 10
+typedef struct hificar_gblock_config {
+    int32_t in_channels;  /* feature dims + ar_output when use_ar, as in hificar_config */
+    int32_t out_channels; /* must be 1 */
+    int32_t channels;
+    int32_t kernel_size;  /* input / output conv */
+    int32_t n_blocks;     /* len(g_scales) == len(g_kernel_sizes) */
+    int32_t g_scales[HIFICAR_MAX_GBLOCKS];
+    int32_t g_kernel_sizes[HIFICAR_MAX_GBLOCKS];
+    int32_t use_tanh;
+    int32_t use_ar;
+    int32_t ar_input;
+    int32_t ar_hidden;
+    int32_t ar_output;
+    int32_t use_spk_id;   /* gblock_gen.py:103-106, 123-127 */
+    int32_t num_spk;
+    int32_t spk_emb_size;
+    int32_t precision;    /* must be HIFICAR_PREC_F32 */
+} hificar_gblock_config;
+int hificar_gblock_create(const hificar_gblock_config* cfg, hificar_handle** out);
 
 /* Hand over one FOLDED tensor (weight-norm already baked: w = v*g/||v||) by its reference
  * state_dict name after remove_weight_norm(), e.g. "input_conv.weight", "upsamples.0.1.weight"
@@ -263,6 +298,12 @@ int hificar_backward_cond(hificar_handle* h, const float* dout, const float* dph
  *   "blocks.<n>.convs1.<d>"   (B, C_i, L_i)             residual_block.py:218 (runs that layer pair unfused)
  *   "blocks.<n>.x.<d>"        (B, C_i, L_i)             residual stream after dilation d: xt + x, residual_block.py:221
  *   "blocks.<n>"              (B, C_i, L_i)             block output, hifigan.py:228
+ * GBlockGenerator handles (hooks on articulatory/layers/pytorch_layers.py:85-91):
+ *   "ar_feats", "input_conv"  as above
+ *   "resamples.<i>.conv1a"    (B, Cout_i, L_i)          first conv of conv1 (pre-activation)
+ *   "resamples.<i>.res1"      (B, Cout_i, L_i)          res1(x)
+ *   "resamples.<i>.mid"       (B, Cout_i, L_i)          conv1(x) + res1(x)
+ *   "resamples.<i>"           (B, Cout_i, L_i)          GBlock output
  * dst: device pointer to `capacity` floats (an error is returned by the forward if it is too small); dst = NULL removes the
  * tap, name = NULL removes all.  Taps add copies and (for convs1) extra launches: not for timed runs. */
 int hificar_debug_tap(hificar_handle* h, const char* name, float* dst, size_t capacity);

@@ -1,0 +1,228 @@
+"""``GBlockGenerator`` (reference articulatory/models/gblock_gen.py:14-132, articulatory/layers/pytorch_layers.py:32-91) on a
+MI355X, through the C ABI, against golden vectors of the REAL reference class (oracle/make_golden_gblock.py) and against the CPU oracle.
+``pytest -m gpu``.  Forward values: 2e-5 of each tensor's scale (1e-3 is north_star's bar); gradients: 2e-4.
+"""
+
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err, same_across_shapes
+from articulatory_amd.models import GBlockGenerator
+from articulatory_amd.utils.synth import synth_features, synth_gblock_state_dict, uniform
+from oracle import gblock_oracle as G
+from oracle.hificar_oracle import check_packed
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+TOL_GRAD = 2e-4
+
+
+def _params(g, key="params"):
+    return dict(ast.literal_eval(str(g[key])))
+
+
+def build(params, seed=1234, train=False):
+    assert torch.cuda.is_available()
+    sd = synth_gblock_state_dict(params, seed=seed)
+    g = GBlockGenerator(**params)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    if train:
+        return g.train().to("cuda:0"), sd
+    g.remove_weight_norm()
+    return g.eval().to("cuda:0"), sd
+
+
+def test_small_model_every_block_vs_reference_golden():
+    """Every GBlock's tensors of the reference's width-64 fixture: block outputs, res1 (the 1 x 1 conv on the nearest-upsampled RAW input),
+    conv1 + res1, the input conv and the PastFCEncoder output — all from the conv kernels' own buffers (hificar_debug_tap)."""
+    g = np.load(os.path.join(GOLDEN, "gold_gblock_small.npz"))
+    model, _ = build(_params(g))
+    names = ["ar_feats", "input_conv"] + [f"resamples.{i}{sfx}" for i in range(10) for sfx in ("", ".res1", ".mid")]
+    with torch.no_grad():
+        y, taps = model.debug_taps(names, torch.from_numpy(g["c"]).cuda(), ar=torch.from_numpy(g["ar"]).cuda())
+        y2 = model(torch.from_numpy(g["c"]).cuda(), ar=torch.from_numpy(g["ar"]).cuda())
+    assert "libhificar.so" in open("/proc/self/maps").read()
+    assert y.shape == (2, 1, 640) and torch.equal(y, y2)
+    assert rel_err(y.cpu().numpy(), g["out"]) < TOL
+    assert rel_err(taps["ar_feats"].cpu().numpy(), g["tap::ar_feats"]) < TOL
+    assert rel_err(taps["input_conv"].cpu().numpy(), g["tap::input_conv"]) < TOL
+    for i in range(10):
+        assert rel_err(taps[f"resamples.{i}"].cpu().numpy(), g[f"tap::resamples.{i}"]) < TOL, i
+        assert rel_err(taps[f"resamples.{i}.res1"].cpu().numpy(), g[f"tap::resamples.{i}.res1"]) < TOL, i
+        assert rel_err(taps[f"resamples.{i}.mid"].cpu().numpy(), g[f"tap::resamples.{i}.conv1"] + g[f"tap::resamples.{i}.res1"]) < TOL, i
+
+
+def test_first_conv_of_a_block_vs_oracle():
+    """conv1's first conv (on the nearest-upsampled ReLU'd rows, staged through the row map) against the oracle's tap, blocks with and without
+    upsampling."""
+    g = np.load(os.path.join(GOLDEN, "gold_gblock_small.npz"))
+    p = _params(g)
+    model, sd = build(p)
+    w = G.fold_weight_norm(sd)
+    ref = {}
+    with torch.no_grad():
+        G.generator_forward(w, p, torch.from_numpy(g["c"]), torch.from_numpy(g["ar"]), taps=ref)
+        _, taps = model.debug_taps([f"resamples.{i}.conv1a" for i in (0, 1, 2, 5, 9)], torch.from_numpy(g["c"]).cuda(), ar=torch.from_numpy(g["ar"]).cuda())
+    for i in (0, 1, 2, 5, 9):
+        assert rel_err(taps[f"resamples.{i}.conv1a"].cpu().numpy(), ref[f"resamples.{i}.conv1a"].numpy()) < TOL, i
+
+
+@pytest.mark.parametrize("name", ["full", "k5spk"])
+def test_forward_vs_reference_golden(name):
+    """channels 512 / kernel 3 (11.99 M parameters) and channels 64 / kernel 5 with speaker conditioning."""
+    g = np.load(os.path.join(GOLDEN, f"gold_gblock_{name}.npz"))
+    p = _params(g)
+    model, _ = build(p)
+    kw = {"spk_id": torch.from_numpy(g["spk_id"]).cuda()} if "spk_id" in g.files else {}
+    names = [f"resamples.{i}" for i in range(10)]
+    with torch.no_grad():
+        y, taps = model.debug_taps(names, torch.from_numpy(g["c"]).cuda(), ar=torch.from_numpy(g["ar"]).cuda(), **kw)
+    assert rel_err(y.cpu().numpy(), g["out"]) < TOL
+    for i in range(10):
+        assert check_packed(g, f"tap::resamples.{i}", taps[f"resamples.{i}"], TOL) < TOL, i
+
+
+def test_ar_loop_vs_reference_ar_loop_golden():
+    """The reference's own ar_loop (decode.py:31-83) at chunk 25 with a ragged tail and at chunk 100."""
+    g = np.load(os.path.join(GOLDEN, "gold_gblock_arloop.npz"))
+    p = _params(np.load(os.path.join(GOLDEN, "gold_gblock_small.npz")))
+    model, _ = build(p)
+    for tag in ("c25", "c100"):
+        x = torch.from_numpy(g[f"{tag}_x"])
+        chunk = int(g[f"{tag}_batch_max_steps"]) // 80
+        with torch.no_grad():
+            y = model.ar_synthesis(x.t()[None].cuda(), chunk)[0].cpu()
+        assert y.shape == (80 * len(x),)
+        assert rel_err(y.numpy(), g[f"{tag}_out"]) < 5e-5, tag  # (chained chunks: the golden's own fp32 noise is 3e-6 per forward)
+
+
+def test_batched_and_ragged_ar_loop_vs_oracle():
+    """Batch 5 with different lengths: per utterance the oracle's batch-1 loop; the same utterance alone is identical."""
+    p = _params(np.load(os.path.join(GOLDEN, "gold_gblock_small.npz")))
+    model, sd = build(p)
+    w = G.fold_weight_norm(sd)
+    lens = [70, 25, 51, 7, 60]
+    x = torch.from_numpy(synth_features(5, 70, 13, seed=931))
+    with torch.no_grad():
+        y = model.ar_synthesis(x.permute(0, 2, 1).cuda(), 25, lengths=lens).cpu()
+        for b, n in enumerate(lens):
+            ref = G.ar_loop(w, p, x[b, :n], 2000, 80)
+            assert rel_err(y[b, :80 * n].numpy(), ref.numpy()) < 5e-5, b
+            assert float(y[b, 80 * n:].abs().max()) == 0.0 if n < 70 else True
+        alone = model.ar_synthesis(x[2:3, :51].permute(0, 2, 1).cuda(), 25).cpu()
+    assert same_across_shapes(alone[0], y[2, :80 * 51])
+
+
+def test_nonar_inference_vs_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "gold_gblock_nonar.npz"))
+    model, _ = build(_params(g))
+    with torch.no_grad():
+        y = model.inference(torch.from_numpy(g["x"]).cuda())
+    assert y.shape == (37 * 80, 1)
+    assert rel_err(y.cpu().numpy(), g["out"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["k3", "k5spk"])
+def test_gradients_vs_reference_golden(tag):
+    """d sum(out * cot) / d(every state_dict parameter, c, ar) with weight norm in the graph against the reference's autograd; seeds whose every
+    ReLU input stays 2e-6 of its tensor's scale away from the kink (oracle/make_golden_gblock.py)."""
+    gold = np.load(os.path.join(GOLDEN, "gold_gblock_grad.npz"))
+    sub = {k[len(tag) + 1:]: gold[k] for k in gold.files if k.startswith(tag + "/")}
+    p = _params(sub)
+    model, _ = build(p, seed=int(sub["seed"]), train=True)
+    c = torch.from_numpy(sub["c"]).cuda().requires_grad_(True)
+    ar = torch.from_numpy(sub["ar"]).cuda().requires_grad_(True)
+    kw = {"spk_id": torch.from_numpy(sub["spk_id"]).cuda()} if "spk_id" in sub else {}
+    y = model(c, ar=ar, **kw)
+    assert y.requires_grad and check_packed(sub, "out", y, TOL) < TOL
+    (y * torch.from_numpy(sub["cot"]).cuda()).sum().backward()
+    worst = {}
+    for k, q in list(model.named_parameters()) + [("c", c), ("ar", ar)]:
+        assert q.grad is not None and bool(torch.isfinite(q.grad).all()), k
+        worst[k] = check_packed(sub, "grad::" + k, q.grad, TOL_GRAD)
+    assert len(worst) == len(list(model.named_parameters())) + 2
+    bad = {k: v for k, v in worst.items() if v >= TOL_GRAD}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    # the training forward (materialised upsampled copies on the tape) and the inference forward (row map in the staging) agree bit for bit
+    with torch.no_grad():
+        model.eval()
+        y_inf = model(c.detach(), ar=ar.detach(), **kw)
+    assert torch.equal(y_inf, y.detach())
+
+
+def test_full_width_gradients_vs_fp64_oracle():
+    """channels 512 at B = 2, T = 12 against the oracle's autograd in float64 (no reference fixture at this size: ~10^6 ReLU inputs always
+    include some within rounding distance of zero, so the statistics are flip-robust: relative L2 per tensor, as close as the CPU's fp32 run)."""
+    p = dict(in_channels=141, out_channels=1, channels=512, kernel_size=7, g_scales=[5, 1, 4, 1, 1, 2, 1, 2, 1, 1], g_kernel_sizes=[3] * 10,
+             use_weight_norm=True, use_ar=True, ar_input=512, ar_hidden=256, ar_output=128, use_tanh=True)
+    model, sd = build(p, seed=77, train=True)
+    B, T = 2, 12
+    c_np = synth_features(B, T, 13, seed=941).transpose(0, 2, 1).copy()
+    ar_np = (synth_features(B, 512, 1, seed=942)[:, :, 0] * 0.5 - 0.25).reshape(B, 1, 512).astype(np.float32)
+    cot = uniform(943, "cotangent", (B, 1, 80 * T), -1.0, 1.0)
+    c = torch.from_numpy(c_np).cuda().requires_grad_(True)
+    ar = torch.from_numpy(ar_np).cuda().requires_grad_(True)
+    y = model(c, ar=ar)
+    (y * torch.from_numpy(cot).cuda()).sum().backward()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    out64, ref64 = G.gradients(sd, p, c_np, ar_np, cot, dtype=torch.float64)
+    _, ref32 = G.gradients(sd, p, c_np, ar_np, cot)
+    assert rel_err(y.detach().cpu().numpy(), out64.numpy()) < TOL
+    got = {k: q.grad for k, q in model.named_parameters()}
+    got.update(c=c.grad, ar=ar.grad)
+    assert sorted(got) == sorted(ref64)
+
+    def l2(a, b):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+    e_dev = {k: l2(got[k].cpu().numpy(), ref64[k].numpy()) for k in ref64}
+    e_cpu = {k: l2(ref32[k].numpy(), ref64[k].numpy()) for k in ref64}
+    assert float(np.median(list(e_dev.values()))) < 1e-4, sorted(e_dev.items(), key=lambda kv: -kv[1])[:5]
+    bad = {k: (e_dev[k], e_cpu[k]) for k in e_dev if e_dev[k] > max(5e-3, 10 * e_cpu[k])}
+    assert not bad, bad
+
+
+def test_load_model_ar_loop_from_reference_layout_checkpoint(tmp_path):
+    """generator_type: GBlockGenerator through the package's load_model (reference utils.py:294-372) and the decode driver's ar_loop."""
+    import yaml
+
+    from articulatory_amd.bin.decode import ar_loop
+    from articulatory_amd.utils import load_model
+
+    g = np.load(os.path.join(GOLDEN, "gold_gblock_arloop.npz"))
+    p = _params(np.load(os.path.join(GOLDEN, "gold_gblock_small.npz")))
+    sd = synth_gblock_state_dict(p, seed=1234)
+    ckpt = tmp_path / "checkpoint-1steps.pkl"
+    torch.save({"model": {"generator": {k: torch.from_numpy(v) for k, v in sd.items()}}, "steps": 1}, ckpt)
+    config = {"generator_type": "GBlockGenerator", "generator_params": p, "format": "npy", "batch_max_steps": 2000, "hop_size": 80,
+              "dataset_mode": "a2w", "sampling_rate": 16000}
+    with open(tmp_path / "config.yml", "w") as f:
+        yaml.dump(config, f)
+    model = load_model(str(ckpt))
+    assert type(model).__name__ == "GBlockGenerator"
+    model.remove_weight_norm()
+    model = model.eval().to("cuda:0")
+    with torch.no_grad():
+        y = ar_loop(model, torch.from_numpy(g["c25_x"]).cuda(), config)
+    assert rel_err(y.cpu().numpy(), g["c25_out"]) < 5e-5
+
+
+def test_unrunnable_configurations_fail_loudly():
+    with pytest.raises(ValueError, match="9 or 10 GBlocks"):
+        GBlockGenerator()  # the reference's defaults: four GBlocks, even kernels
+    with pytest.raises(ValueError, match="odd"):
+        GBlockGenerator(g_scales=[5, 1, 4, 1, 1, 2, 1, 2, 1, 1], g_kernel_sizes=[4] * 10)
+    with pytest.raises(ValueError, match="f32"):
+        GBlockGenerator(g_scales=[5, 1, 4, 1, 1, 2, 1, 2, 1, 1], g_kernel_sizes=[3] * 10, precision="bf16x3")
+    p = _params(np.load(os.path.join(GOLDEN, "gold_gblock_small.npz")))
+    model, _ = build(dict(p, g_kernel_sizes=[9] * 10))
+    with pytest.raises(ValueError, match="> 7"):
+        model(torch.zeros(1, 13, 4).cuda(), ar=torch.zeros(1, 1, 512).cuda())
+    cpu = GBlockGenerator(**p)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cpu(torch.zeros(1, 13, 4), ar=torch.zeros(1, 1, 512))
