@@ -169,8 +169,9 @@ class Trainer:
 
     def __init__(self, config, device, distributed=False):
         self.config, self.device, self.distributed = config, device, distributed
-        if config.get("generator_type", "HiFiGANGenerator") != "HiFiGANGenerator":
-            raise NotImplementedError(f"generator_type {config['generator_type']} is not built")
+        gtype_name = config.get("generator_type", "HiFiGANGenerator")
+        if gtype_name not in ("HiFiGANGenerator", "GBlockGenerator"):
+            raise NotImplementedError(f"generator_type {gtype_name} is not built")
         import articulatory_amd.models as models
 
         dtype_name = config.get("discriminator_type", "HiFiGANMultiScaleMultiPeriodDiscriminator")
@@ -182,7 +183,7 @@ class Trainer:
         gp = config["generator_params"]
         self.use_ar = bool(gp.get("use_ar", False))
         self.use_ph_loss = bool(gp.get("use_ph_loss", False))  # train.py:1735-1739: the generator's flag decides, criterion = F.cross_entropy
-        self.G = HiFiGANGenerator(**gp, precision="f32").to(device).train()
+        self.G = getattr(models, gtype_name)(**gp, precision="f32").to(device).train()  # train.py:1649-1660
         self.D = getattr(models, dtype_name)(**config["discriminator_params"]).to(device).train()  # train.py:1661-1668
         self.mel = MelSpectrogramLoss(**config["mel_loss_params"]) if config.get("use_mel_loss", False) else None
         self.stft = MultiResolutionSTFTLoss(**config.get("stft_loss_params", {})) if config.get("use_stft_loss", False) else None  # train.py:1688

@@ -136,8 +136,12 @@ class GBlockGenerator(_NativeGenerator):
         up = int(np.prod(p["g_scales"][:i + 1]))
         return (B, p["channels"] // GBLOCK_OUT[i], Tb * up), T * up
 
-    def forward(self, c, spk_id=None, ar=None, lengths=None):
-        """c: (B, in_channels[-ar_output], T) -> (B, out_channels, T * prod(g_scales))  (gblock_gen.py:111-132)."""
+    def forward(self, c, spk_id=None, ar=None, ph=None, lengths=None):
+        """c: (B, in_channels[-ar_output], T) -> (B, out_channels, T * prod(g_scales))  (gblock_gen.py:111-132).
+        ``ph`` is accepted when None only: the reference's trainer passes ph= to every generator (train.py:276), which its own
+        GBlockGenerator.forward(c, spk_id, ar) rejects with a TypeError."""
+        if ph is not None:
+            raise TypeError("GBlockGenerator.forward() has no phoneme conditioning (gblock_gen.py:111)")
         return super().forward(c, spk_id=spk_id, ar=ar, lengths=lengths)
 
     def inference(self, c, normalize_before=False):

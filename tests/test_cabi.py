@@ -63,7 +63,8 @@ def test_training_structs_match_header_layout(tmp_path):
     import subprocess
     if shutil.which("gcc") is None:
         pytest.skip("gcc not available")
-    pairs = [("hificar_disc_config", _native.HificarDiscConfig), ("hificar_disc_output", _native.HificarDiscOutput),
+    pairs = [("hificar_gblock_config", _native.HificarGBlockConfig),
+             ("hificar_disc_config", _native.HificarDiscConfig), ("hificar_disc_output", _native.HificarDiscOutput),
              ("hificar_gan_loss_config", _native.HificarGanLossConfig), ("hificar_mel_config", _native.HificarMelConfig)]
     body, want = "", []
     for cname, cls in pairs:
@@ -82,6 +83,7 @@ def test_training_structs_match_header_layout(tmp_path):
     assert _native.DISC_MAX_SUBS == 8 and _native.DISC_MAX_LAYERS == 12  # HIFICAR_DISC_MAX_* of the header
     hdr = open(os.path.join(inc, "hificar.h")).read()
     assert "#define HIFICAR_DISC_MAX_SUBS 8" in hdr and "#define HIFICAR_DISC_MAX_LAYERS 12" in hdr
+    assert _native.MAX_GBLOCKS == 10 and "#define HIFICAR_MAX_GBLOCKS 10" in hdr
 
 
 def test_create_macs_workspace(lib):

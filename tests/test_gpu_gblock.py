@@ -226,3 +226,42 @@ def test_unrunnable_configurations_fail_loudly():
     cpu = GBlockGenerator(**p)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         cpu(torch.zeros(1, 13, 4), ar=torch.zeros(1, 1, 512))
+
+
+def test_gan_iteration_with_a_gblock_generator_vs_oracle():
+    """``generator_type: GBlockGenerator`` through the Trainer (the generator half of train.py:241-440): the first iteration's logged losses
+    against the CPU oracles' restatement of the same step, then 12 iterations that fit the batch."""
+    from articulatory_amd.bin.train import SyntheticPairs, Trainer, WindowCollater
+    from articulatory_amd.utils.synth import synth_disc_state_dict
+    from oracle import disc_oracle as DO
+    from oracle.make_golden_disc import SMALL
+    from test_gpu_gan import make_config
+
+    p = _params(np.load(os.path.join(GOLDEN, "gold_gblock_small.npz")))
+    config = dict(make_config(True), generator_type="GBlockGenerator", generator_params=p, batch_max_steps=400)
+    t = Trainer(config, torch.device("cuda:0"))
+    gsd = synth_gblock_state_dict(p, seed=31)
+    dsd = synth_disc_state_dict(config["discriminator_params"], seed=32)
+    t.G.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()})
+    t.D.load_state_dict({k: torch.from_numpy(v) for k, v in dsd.items()})
+    data = SyntheticPairs(4, 30, 13, 80, seed=3)
+    batch = WindowCollater(400, 80, 512, np.random.default_rng(5))([data[i] for i in range(4)])
+    t.steps = 1
+    log = {k: float(v) for k, v in t.train_step(batch).items()}
+    x, y, ar = batch["x"], batch["y"], batch["ar"]
+    with torch.no_grad():
+        y_ = G.generator_forward(G.fold_weight_norm(gsd), p, x, ar)
+        mel = DO.mel_loss(y_, y, **config["mel_loss_params"])
+        dw = DO.fold_disc_weight_norm(dsd)
+        p_, pr = DO.disc_forward(dw, SMALL, torch.cat([ar, y_], 2)), DO.disc_forward(dw, SMALL, torch.cat([ar, y], 2))
+        adv = DO.gen_adv_loss(p_, False)
+        fm = DO.feat_match_loss(p_, pr, False, False, False)
+        gen = 45.0 * mel + 1.0 * (adv + 2.0 * fm)
+    ref = {"train/mel_loss": float(mel), "train/adversarial_loss": float(adv), "train/feature_matching_loss": float(fm), "train/generator_loss": float(gen)}
+    for k, v in ref.items():
+        assert abs(log[k] - v) < 1e-4 * max(abs(v), 1e-3), (k, log[k], v)
+    for _ in range(12):
+        last = {k: float(v) for k, v in t.train_step(batch).items()}
+    assert all(np.isfinite(v) for v in last.values()) and last["train/mel_loss"] < log["train/mel_loss"]
+    now = t.G.state_dict()
+    assert any(not np.allclose(now[k].cpu().numpy(), v) for k, v in gsd.items())
