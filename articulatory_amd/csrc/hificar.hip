@@ -68,6 +68,7 @@ struct ConvLayer {
     uint16_t* d_w16c = nullptr;  // same fragments packed with one K chunk = all channels (fused pair kernel, C <= 64)
     float* d_w32 = nullptr;      // exact-fp32 arithmetic: fp32 fragments in the same order
     float* d_w32c = nullptr;     // fp32 fragments with one K chunk = all channels (fused pair kernel, C <= 64)
+    float* d_w32n = nullptr;     // fp32 fragments packed with 16-channel K chunks (the 128-accumulator wave tile conv_f32nb_kernel<4,1,4,1>, C >= 256)
 };
 
 // One GBlock of a GBlockGenerator (articulatory/layers/pytorch_layers.py:32-91): conv1 = [ReLU, Upsample, c1a, ReLU, c1b (dilation 3)],
@@ -583,6 +584,10 @@ static int pack_conv(hificar_handle* h, ConvLayer& L) {
 
     if ((rc = pack_w16(h, L, W, L.chunk16, &L.d_w16)) != HIFICAR_OK) return rc;
     if ((rc = pack_w32(h, L, W, L.chunk16, &L.d_w32)) != HIFICAR_OK) return rc;
+    // wide layers: a second fp32 pack with 16-channel K chunks for the 128-accumulator wave tile (its 128 x 256 out-buffer leaves room for
+    // 16-channel staging items only); HIFICAR_NB=0 (the default) never launches it
+    static const bool want_nb4 = getenv("HIFICAR_NB") && atoi(getenv("HIFICAR_NB")) != 0;
+    if (want_nb4 && L.n_blocks32 >= 8 && L.chunk16 != 16 && (rc = pack_w32(h, L, W, 16, &L.d_w32n)) != HIFICAR_OK) return rc;
     if (!L.transposed && L.cin_pad == L.cin && (L.cin == 32 || L.cin == 64) && L.cout == L.cin) {
         if ((rc = pack_w16(h, L, W, L.cin_pad, &L.d_w16c)) != HIFICAR_OK) return rc;
         if ((rc = pack_w32(h, L, W, L.cin_pad, &L.d_w32c)) != HIFICAR_OK) return rc;
@@ -608,6 +613,9 @@ static hipError_t set_lds_attr_f() {
 #define HIFICAR_FOR_TILES(X, nc) \
     X(4, 1, 4, nc) X(4, 2, 2, nc) X(4, 4, 1, nc) X(2, 1, 4, nc) X(2, 2, 2, nc) X(2, 4, 1, nc) X(1, 1, 4, nc) X(1, 2, 2, nc) X(1, 4, 1, nc)
 #define HIFICAR_FOR_ALL_TILES(X) HIFICAR_FOR_TILES(X, 1) HIFICAR_FOR_TILES(X, 2) HIFICAR_FOR_TILES(X, 4)
+// the register-blocked (NB = 2) shapes: (MI, WM, WN)
+#define HIFICAR_FOR_NB_TILES(X, nc) X(2, 2, 2, nc) X(2, 4, 1, nc) X(2, 1, 4, nc)
+#define HIFICAR_FOR_ALL_NB_TILES(X) HIFICAR_FOR_NB_TILES(X, 2) HIFICAR_FOR_NB_TILES(X, 4) X(4, 1, 4, 1)
 // split-K forms: (MI, NC16)
 #define HIFICAR_FOR_SK_TILES(X) X(1, 1) X(2, 1) X(4, 1) X(1, 2) X(2, 2) X(4, 2) X(1, 4) X(2, 4) X(4, 4)
 
@@ -636,6 +644,12 @@ static int engine_setup(hificar_handle* h) {
     HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>()));
     HIFICAR_FOR_ALL_TILES(HIFICAR_SET_ATTR)
 #undef HIFICAR_SET_ATTR
+#define HIFICAR_SET_ATTR_NB(mi, wm, wn, nc)                                                                                                \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32nb_kernel<mi, wm, wn, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                160 * 1024));                                                                                              \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3nb_kernel<mi, wm, wn, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIFICAR_FOR_ALL_NB_TILES(HIFICAR_SET_ATTR_NB)
+#undef HIFICAR_SET_ATTR_NB
 #define HIFICAR_SET_ATTR_SK(mi, nc)                                                                                              \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_bf16x3_kernel<mi, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 160 * 1024));                                                                                  \
@@ -979,11 +993,21 @@ static int enter_stream(hificar_handle* h, hipStream_t stream) {
 struct TileCfg {
     int MI, WM, WN;
     int KS;  // 1: each MFMA wave owns a 32-channel block of the tile; 4: the four MFMA waves split the K loop of ONE block (WM = WN = 1)
+    int NB;  // channel blocks per MFMA wave (conv_ws_body's register blocking): tile = WM*MI*32 rows x WN*NB*32 channels
+    int CH;  // K chunk (channels per LDS item) the shape is built for; 0: the layer's own chunk16
 };
-static size_t out_buf_bytes(const TileCfg& t) { return (size_t)t.KS * (t.WM * t.MI * 32) * (t.WN * 32 + 4) * sizeof(float); }
+static size_t out_buf_bytes(const TileCfg& t) { return (size_t)t.KS * (t.WM * t.MI * 32) * (t.WN * t.NB * 32 + 4) * sizeof(float); }
 // preference order: ties keep the earlier entry (taller wave tiles re-read fewer weights per MFMA)
-static const TileCfg kTileCfgs[12] = {{4, 1, 4, 1}, {4, 2, 2, 1}, {4, 4, 1, 1}, {2, 1, 4, 1}, {2, 2, 2, 1}, {2, 4, 1, 1},
-                                      {1, 1, 4, 1}, {1, 2, 2, 1}, {1, 4, 1, 1}, {4, 1, 1, 4}, {2, 1, 1, 4}, {1, 1, 1, 4}};
+static const TileCfg kTileCfgs[16] = {{4, 1, 4, 1, 2, 16}, {4, 1, 4, 1, 1, 0}, {4, 2, 2, 1, 1, 0}, {4, 4, 1, 1, 1, 0}, {2, 2, 2, 1, 2, 0}, {2, 4, 1, 1, 2, 0},
+                                      {2, 1, 4, 1, 2, 0}, {2, 1, 4, 1, 1, 0}, {2, 2, 2, 1, 1, 0}, {2, 4, 1, 1, 1, 0},
+                                      {1, 1, 4, 1, 1, 0}, {1, 2, 2, 1, 1, 0}, {1, 4, 1, 1, 1, 0}, {4, 1, 1, 4, 1, 0}, {2, 1, 1, 4, 1, 0}, {1, 1, 1, 4, 1, 0}};
+
+template <int MI, int WM, int WN, int NC16>
+static hipError_t launch_conv_nb_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
+    if (f32) hipLaunchKernelGGL((conv_f32nb_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
+    else hipLaunchKernelGGL((conv_bf16x3nb_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
+    return hipGetLastError();
+}
 
 template <int MI, int NC16>
 static hipError_t launch_conv_sk_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
@@ -1026,12 +1050,14 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     const bool f32 = h->precision == HIFICAR_PREC_F32;  // rows are plain fp32 LeakyReLU(x) instead of split rows
     int halo_all = 0;
     for (int b = 0; b < nbr; ++b) halo_all = std::max(halo_all, layers[b]->off_max - layers[b]->off_min);
-    const int RB = L0.chunk16 * 4;
     // Tile shape: simulate the kernel's static tile walk (workgroup w takes tiles w, w+G, ...; branch-major order) and
     // take the shape with the smallest makespan.  A tile costs its MFMA issue cycles (all four MFMA waves run in
     // lock step: 3*MI MFMAs of 32 cycles per 16-channel K slab) plus a fixed per-tile and per-item overhead.
-    TileCfg tc = kTileCfgs[8];
+    TileCfg tc = {1, 4, 1, 1, 1, 0};
     double best = 1e300;
+    // HIFICAR_NB: 0 = never use the register-blocked (NB = 2) wave tiles (default: measured slower), 1 = when the cost model prefers
+    // them, 2 = whenever one fits (A/B runs: tools/nb_ab.sh)
+    static const int nb_mode = getenv("HIFICAR_NB") ? atoi(getenv("HIFICAR_NB")) : 0;
     const int nsteps_min = [&] {
         int m = 1 << 30;
         for (int b = 0; b < nbr; ++b) m = std::min(m, layers[b]->ntaps * (L0.chunk16 / 16));
@@ -1047,25 +1073,38 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     if (force1) sscanf(force1, "%d,%d,%d,%d", &fc1, &fmi1, &fwm1, &fwn1);
     for (const TileCfg& t : kTileCfgs) {
         const int TM = t.WM * t.MI * 32;
+        const int chunk = t.CH ? t.CH : L0.chunk16, RB = chunk * 4;
+        if (t.CH) {  // a shape with its own K chunk: exact fp32, inference packs only (device-resident training weights refresh d_w32 alone)
+            bool ok = f32 && !h->train && t.CH != L0.chunk16;
+            for (int b = 0; b < nbr; ++b) ok = ok && layers[b]->d_w32n != nullptr;
+            if (!ok) continue;
+        } else if (t.NB == 2 && L0.chunk16 == 16) {
+            continue;  // (not instantiated)
+        }
         if (2 * round_up_sz((size_t)(TM + halo_all) * RB, 1024) + out_buf_bytes(t) > 160 * 1024) continue;
+        if (t.NB == 2) {  // a wave's two channel blocks share the activation fragments: same phase of a polyphase (transposed) conv
+            bool ok = nb_mode != 0 && L0.n_blocks32 >= 2;
+            for (int b = 0; b < nbr; ++b) ok = ok && (layers[b]->n_phase == 1 || layers[b]->nb32_per_phase % 2 == 0);
+            if (!ok) continue;
+        }
         if (fc == L0.cin_pad && nbr == 3 && !(t.MI == fmi && t.WM == fwm && t.WN == fwn)) continue;
         if (fc1 == L0.cin_pad && nbr == 1 && zr.n == 1 && !(t.KS == 1 && t.MI == fmi1 && t.WM == fwm1 && t.WN == fwn1)) continue;
         if (t.KS == 4 && (h->ksplit == 0 || nsteps_min < 2)) continue;
         if (t.KS == 1 && h->ksplit == 2 && nsteps_min >= 2) continue;
-        const long long tiles_per_branch = (long long)nseq * ((rows + TM - 1) / TM) * ((L0.n_blocks32 + t.WN - 1) / t.WN);
+        const long long tiles_per_branch = (long long)nseq * ((rows + TM - 1) / TM) * ((L0.n_blocks32 + t.WN * t.NB - 1) / (t.WN * t.NB));
         const long long total = tiles_per_branch * nbr * zr.n;
         const int G = (int)std::min<long long>(total, h->num_cus);
-        const int nchunks = L0.cin_pad / L0.chunk16;
+        const int nchunks = L0.cin_pad / chunk;
         // LPT makespan estimate: max(heaviest tile, total / G), plus one light tile when the count does not divide
         double total_cost = 0.0, heaviest = 0.0, lightest = 1e300;
         for (int b = 0; b < nbr; ++b) {
             // MFMA issue cycles per 16-channel slab and 32x32 accumulator: 3 x 32 (bf16x3, ~75 % sustained) or 8 x 64 (fp32)
             const double slab = f32 ? 8 * 64.0 : 3 * 32 / 0.75;
-            double c = (double)layers[b]->ntaps * (L0.cin_pad / 16) * slab * t.MI + 2500.0 + 400.0 * nchunks;
+            double c = (double)layers[b]->ntaps * (L0.cin_pad / 16) * slab * t.MI * t.NB + 2500.0 + 400.0 * nchunks;
             if (t.KS == 4) {
                 // each wave runs ceil(steps / 4) of an item's (tap, slab) steps; exposed weight latency at every tile start, the partial
                 // sums' extra pass, and four times the staging per output
-                const int steps = layers[b]->ntaps * (L0.chunk16 / 16);
+                const int steps = layers[b]->ntaps * (chunk / 16);
                 c = (double)((steps + 3) / 4) * nchunks * slab * t.MI + 4000.0 + 600.0 * nchunks;
             }
             total_cost += c * tiles_per_branch * zr.n;
@@ -1080,7 +1119,10 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         // launches with fewer tiles than pick_throughput stay latency-driven.)
         if (h->pick_throughput > 0 && total >= h->pick_throughput) worst = total_cost / h->num_cus;
         // shorter wave tiles re-read the weight stream more often per MFMA (MI = 2 measured ~10 % slower per flop)
-        if (t.MI < 4) worst *= f32 ? (t.MI == 2 ? 1.02 : h->mi1_penalty) : (t.MI == 2 ? 1.10 : 1.25);
+        // operand loads per MFMA: 2 (MI + NB) 16-byte loads per slab step against (8 | 3) MI NB MFMAs
+        if (t.NB == 2) worst *= f32 ? (t.MI == 4 ? 0.95 : t.MI == 2 ? 0.975 : 1.02) : (t.MI == 2 ? 0.93 : 1.10);
+        else if (t.MI < 4) worst *= f32 ? (t.MI == 2 ? 1.02 : h->mi1_penalty) : (t.MI == 2 ? 1.10 : 1.25);
+        if (t.NB == 2 && (nb_mode == 2 || (nb_mode == 3 && t.CH))) worst *= 0.5;  // (3: only the 128-accumulator shape is forced)
         if (t.KS == 4) worst *= 1.05;  // near-ties go to the dense form
         if (worst < best * 0.98) {  // near-ties keep the earlier (taller) shape
             best = worst;
@@ -1088,7 +1130,8 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         }
     }
     const int TM = tc.WM * tc.MI * 32;
-    const int nc16 = L0.chunk16 / 16;
+    const int chunk_sel = tc.CH ? tc.CH : L0.chunk16, RB = chunk_sel * 4;
+    const int nc16 = chunk_sel / 16;
     MultiConvParams mp;
     memset(&mp, 0, sizeof(mp));
     double flops = 0.0, bytes = 0.0;
@@ -1114,7 +1157,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         mp.p[b].zeros = h->d_zeros;
         mp.p[b].slope_out = slope_out;
         mp.p[b].cout_real = Lb.cout_pad;
-        if (f32) mp.p[b].w16 = reinterpret_cast<const bf16x8*>(Lb.d_w32);
+        if (f32) mp.p[b].w16 = reinterpret_cast<const bf16x8*>(tc.CH ? Lb.d_w32n : Lb.d_w32);
         const double pos = (double)nseq * rows;
         flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K * zr.n;
         bytes += 4.0 * (pos * Lb.cin_pad / std::max(1, io[b].x_up) + pos * Lb.cout_total * ((io[b].res ? 1 : 0) + (io[b].y ? 1 : 0) + (io[b].ys ? 1 : 0)) +
@@ -1124,7 +1167,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     const size_t lds = 2 * buf_bytes + out_buf_bytes(tc);
     mp.n_branches = nbr;
     mp.nseq_tiles = nseq * ((rows + TM - 1) / TM);
-    mp.ngroups = (L0.n_blocks32 + tc.WN - 1) / tc.WN;
+    mp.ngroups = (L0.n_blocks32 + tc.WN * tc.NB - 1) / (tc.WN * tc.NB);
     mp.total_tiles = nbr * zr.n * mp.ngroups * mp.nseq_tiles;
     mp.buf_bytes = (int)buf_bytes;
     mp.trace = nullptr;
@@ -1150,12 +1193,13 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         }
         if (zr.n > 1) key += "z" + std::to_string(zr.n);
         key += "|" + std::to_string(nseq) + "x" + std::to_string((rows + TM - 1) / TM) + "t" + std::to_string(TM) + "w" + std::to_string(tc.WN) +
-               "k" + std::to_string(tc.KS);
+               "k" + std::to_string(tc.KS) + (tc.NB == 2 ? "b" : "") + (tc.CH ? "c" + std::to_string(tc.CH) : "");
         int rc2 = get_schedule(h, key, costs, (int)grid.x, stream, &mp.sched_start, &mp.sched_tiles);
         if (rc2 != HIFICAR_OK) return rc2;
     }
     char kname[96];
     if (tc.KS == 4) snprintf(kname, sizeof(kname), "%s<%d,%d>", f32 ? "conv_sk_f32_kernel" : "conv_sk_bf16x3_kernel", tc.MI, nc16);
+    else if (tc.NB == 2) snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_f32nb_kernel" : "conv_bf16x3nb_kernel", tc.MI, tc.WM, tc.WN, nc16);
     else snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_f32_kernel" : "conv_bf16x3_kernel", tc.MI, tc.WM, tc.WN, nc16);
     if (h->profile_detail) {  // per-layer rows in the profile (tools/layer_profile.py)
         const size_t n = strlen(kname);
@@ -1164,9 +1208,13 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     ProfScope prof(h, stream, kname, flops, bytes);
     hipError_t e = hipErrorInvalidValue;
 #define HIFICAR_DISPATCH(mi, wm, wn, nc) \
-    if (tc.KS == 1 && tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_t<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
+    if (tc.KS == 1 && tc.NB == 1 && tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_t<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
     HIFICAR_FOR_ALL_TILES(HIFICAR_DISPATCH)
 #undef HIFICAR_DISPATCH
+#define HIFICAR_DISPATCH_NB(mi, wm, wn, nc) \
+    if (tc.KS == 1 && tc.NB == 2 && tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_nb_t<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
+    HIFICAR_FOR_ALL_NB_TILES(HIFICAR_DISPATCH_NB)
+#undef HIFICAR_DISPATCH_NB
 #define HIFICAR_DISPATCH_SK(mi, nc) \
     if (tc.KS == 4 && tc.MI == mi && nc16 == nc) e = launch_conv_sk_t<mi, nc>(mp, grid, lds, stream, f32);
     HIFICAR_FOR_SK_TILES(HIFICAR_DISPATCH_SK)

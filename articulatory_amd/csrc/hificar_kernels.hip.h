@@ -212,8 +212,14 @@ __device__ __forceinline__ void pin_slab_step() {
 // 32-channel block's dependent MFMA chain is a quarter as long and four times as many workgroups have work.  Each wave leaves a partial
 // accumulator in the out-buffer; the output pass sums them in the fixed order (p0 + p1) + (p2 + p3): deterministic, but a different
 // rounding order than the dense form (results agree to fp32 rounding, not bit for bit).
-template <int MI, int WM, int WN, int NC16, bool F32, int KS = 1>
+//
+// NB = 2 is the register-blocked wave tile: an MFMA wave owns NB adjacent 32-channel blocks x MI row blocks (NB * MI accumulators), so one
+// activation fragment read feeds NB times the MFMAs and one weight fragment MI of them: 2 (MI + NB) 16-byte loads per 8 MI NB MFMAs per K slab
+// (fp32) — MI = 2, NB = 2: 0.25 loads per MFMA against 0.31 at MI = 4, NB = 1 on the same 64 accumulator registers and the same LDS budget
+// (tile = WM*MI*32 rows x WN*NB*32 channels).  Every 16-byte load next to fp32 MFMAs costs ~22 cycles of matrix-pipe time.
+template <int MI, int WM, int WN, int NC16, bool F32, int KS = 1, int NB = 1>
 __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
+    static_assert(NB == 1 || (NB == 2 && KS == 1), "one or two channel blocks per MFMA wave");
     static_assert(KS == 1 || (KS == 4 && WM == 1 && WN == 1), "split-K: four waves share one 32-channel block");
     static_assert(KS == 4 || WM * WN == 4 || WM * WN == 8, "4 or 8 MFMA waves per workgroup");
     constexpr int NW = KS == 4 ? 4 : WM * WN;  // MFMA waves; waves NW .. NW+3 are the loaders
@@ -263,7 +269,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         return T;
     };
 
-    constexpr int TN = WN * 32;
+    constexpr int TN = WN * NB * 32;
     constexpr int OP = TN + 4;  // out-buffer row pitch (floats)
     // Tile walk.  With a host schedule: the tiles assigned to this workgroup, already ordered light -> heavy.
     // Without: tiles w, w+G, w+2G, ... (rounds run heavy -> light because tile ids are heaviest-branch-major), walked
@@ -574,27 +580,43 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
 
     // ---------------- MFMA role ----------------
     __builtin_amdgcn_s_setprio(1);  // the MFMA wave outranks the loader wave sharing its SIMD for issue slots
-    f32x16 acc[MI];
-    // weight fragments: wr[u] holds slab u's fragments for its NEXT use; right after a slab's MFMAs have been issued its registers are
+    f32x16 acc[NB][MI];
+    // weight fragments: wr[q][u] holds slab u's fragments (of the wave's channel block q) for its NEXT use; right after a slab's MFMAs have been issued its registers are
     // reloaded for the following tap (one tap = NC16 slab steps ahead).  One register set per slab and no rotation: a two-deep ring
     // needs register copies at every loop back-edge, and hipcc waits for the just-issued loads there (a full L2 latency per item).
     using frag_t = typename std::conditional<F32, f32x4, bf16x8>::type;  // 16 bytes per lane either way
-    constexpr int NMF = (F32 ? 8 : 3) * MI;  // MFMAs of one K-slab step
-    frag_t wr[NC16][2];
+    constexpr int NMF = (F32 ? 8 : 3) * MI * NB;  // MFMAs of one K-slab step
+    frag_t wr[NB][NC16][2];
     auto wstream = [&](const Tile& T) {
         const ConvParams& p = mp.p[T.b];
-        const int nb = T.ng * WN + wn;
+        const int nb = (T.ng * WN + wn) * NB;
         return reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(p.w16) + (size_t)T.z * mp.zs_w) + (size_t)(nb < p.n_blocks32 ? nb : 0) * p.ntaps * (p.cin / 16) * 128 + lane;
     };
+    // NB = 2: the second channel block's stream lies one block's worth of fragments behind the first's (0 when the layer has no such block:
+    // a partial channel group — the wave then multiplies the first block twice and the output pass ignores the columns)
+    auto wstride = [&](const Tile& T) {
+        const ConvParams& p = mp.p[T.b];
+        return ((T.ng * WN + wn) * NB + 1 < p.n_blocks32) ? (long long)p.ntaps * (p.cin / 16) * 128 : 0LL;
+    };
     const frag_t* wp = nullptr;   // where the next tap-group of weight fragments is loaded from
+    const frag_t* wp2 = nullptr;  // ... of the second channel block (NB = 2)
     int groups_left = 0;          // tap-groups of the current tile's stream not yet requested
     bool primed = false;          // the ring holds the head of the tile about to be computed
     auto prime = [&](const Tile& T) {
         wp = wstream(T);
 #pragma unroll
         for (int u = 0; u < NC16; ++u) {
-            wr[u][0] = wp[u * 128];
-            wr[u][1] = wp[u * 128 + 64];
+            wr[0][u][0] = wp[u * 128];
+            wr[0][u][1] = wp[u * 128 + 64];
+        }
+        if constexpr (NB == 2) {
+            wp2 = wp + wstride(T);
+#pragma unroll
+            for (int u = 0; u < NC16; ++u) {
+                wr[1][u][0] = wp2[u * 128];
+                wr[1][u][1] = wp2[u * 128 + 64];
+            }
+            wp2 += NC16 * 128;
         }
         wp += NC16 * 128;
         groups_left = nchunks * mp.p[T.b].ntaps - 1;
@@ -624,26 +646,54 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             xl[mi] = *reinterpret_cast<const frag_t*>(smem_b + ad[1] + mi * 32 * RB);
         }
     };
-    auto mfma_step = [&](const frag_t (&xh)[MI], const frag_t (&xl)[MI], const frag_t& wh, const frag_t& wl) {
-        // consecutive MFMAs never share an accumulator (MI > 1)
+    auto mfma_step = [&](const frag_t (&xh)[MI], const frag_t (&xl)[MI], const frag_t (&wh)[NB], const frag_t (&wl)[NB]) {
+        // consecutive MFMAs never share an accumulator (MI * NB > 1)
         if constexpr (F32) {
             // (xh, wh) = channels 0..7 of the slab, (xl, wl) = channels 8..15; step s multiplies channels s and 4 + s
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[s4], xh[mi][s4], acc[mi], 0, 0, 0);
+                for (int q = 0; q < NB; ++q)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[q][s4], xh[mi][s4], acc[q][mi], 0, 0, 0);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[s4], xl[mi][s4], acc[mi], 0, 0, 0);
+                for (int q = 0; q < NB; ++q)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[q][s4], xl[mi][s4], acc[q][mi], 0, 0, 0);
         } else {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[mi], acc[mi], 0, 0, 0);
+            for (int q = 0; q < NB; ++q)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[mi], acc[mi], 0, 0, 0);
+                for (int mi = 0; mi < MI; ++mi) acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[q], xl[mi], acc[q][mi], 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[mi], acc[mi], 0, 0, 0);
+            for (int q = 0; q < NB; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[q], xh[mi], acc[q][mi], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[q], xh[mi], acc[q][mi], 0, 0, 0);
         }
+    };
+    // one K-slab step of the ring: take slab u's fragments, reload the registers for the following tap, multiply
+    auto slab_step = [&](const frag_t (&xh)[MI], const frag_t (&xl)[MI], int u) {
+        frag_t wh[NB], wl[NB];
+        wh[0] = wr[0][u][0];
+        wl[0] = wr[0][u][1];
+        wr[0][u][0] = wp[u * 128];
+        wr[0][u][1] = wp[u * 128 + 64];
+        if constexpr (NB == 2) {
+            wh[1] = wr[1][u][0];
+            wl[1] = wr[1][u][1];
+            wr[1][u][0] = wp2[u * 128];
+            wr[1][u][1] = wp2[u * 128 + 64];
+        }
+        HIFICAR_PIN_BARRIER();
+        mfma_step(xh, xl, wh, wl);
+        pin_slab_step<2 * MI, 2 * NB, NMF>();
+        HIFICAR_PIN_BARRIER();
     };
 
     int j = 0;
@@ -666,7 +716,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[0][mi][r] = 0.f;
             auto x_addr = [&](int buf_off, int s, int (&ad)[2]) {
                 const int t = s >> LOG_NC, u = s & (NC16 - 1);
                 const int r0 = li + roff0 + t * tap_step;
@@ -710,7 +760,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                         load_x(x1h, x1l, ad);
                     }
                     {
-                        const frag_t cwh = w0h, cwl = w0l;
+                        const frag_t cwh[1] = {w0h}, cwl[1] = {w0l};
                         if (i + 2 < spi) {
                             w0h = wc[(size_t)(i + 2) * 512];
                             w0l = wc[(size_t)(i + 2) * 512 + 64];
@@ -722,7 +772,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                             x_addr(buf_off, ks + 4 * (i + 2), ad);
                             load_x(x0h, x0l, ad);
                         }
-                        const frag_t cwh = w1h, cwl = w1l;
+                        const frag_t cwh[1] = {w1h}, cwl[1] = {w1l};
                         if (i + 3 < spi) {
                             w1h = wc[(size_t)(i + 3) * 512];
                             w1l = wc[(size_t)(i + 3) * 512 + 64];
@@ -739,7 +789,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[mi][4 * q + e];
+                        for (int e = 0; e < 4; ++e) v[e] = acc[0][mi][4 * q + e];
                         *reinterpret_cast<f32x4*>(&Ow[(mi * 32 + li) * OP + 8 * q + 4 * g]) = v;
                     }
             }
@@ -756,7 +806,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         last = it;
         const Tile T = decode(tile_of(it));
         const ConvParams& p = mp.p[T.b];
-        const int nb = T.ng * WN + wn;
+        const int nb = (T.ng * WN + wn) * NB;
         const bool active = nb < p.n_blocks32;
         const int phase = active ? nb / p.nb32_per_phase : 0;
         const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
@@ -766,12 +816,15 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         // primed when it starts (the last tile re-reads its own head: harmless)
         const Tile Tn = decode(tile_of(itn < my_rounds ? itn : it));
         const frag_t* wp_next = wstream(Tn);
+        const long long wst_next = NB == 2 ? wstride(Tn) : 0LL;
         const int groups_next = nchunks * mp.p[Tn.b].ntaps;
         if (active && !primed) prime(T);  // first tile, or this wave sat out the previous tile (partial channel group)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int q = 0; q < NB; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][mi][r] = 0.f;
 
         for (int c = 0; c < nchunks; ++c, ++j) {
             HIFICAR_STAMP(1 + 3 * j);
@@ -790,34 +843,20 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                     addr_set(buf_off, roff0 + (last_tap ? t : t + 1) * tap_step, adn);
                     if (groups_left == 0) {  // stream exhausted: continue with the next tile's head
                         wp = wp_next;
+                        if constexpr (NB == 2) wp2 = wp_next + wst_next;
                         groups_left = groups_next;
                     }
                     --groups_left;
 #pragma unroll
                     for (int u = 0; u < NC16; u += 2) {
                         load_x(x1h, x1l, ad[u + 1]);
-                        {
-                            const frag_t wh = wr[u][0], wl = wr[u][1];
-                            wr[u][0] = wp[u * 128];
-                            wr[u][1] = wp[u * 128 + 64];
-                            HIFICAR_PIN_BARRIER();
-                            mfma_step(x0h, x0l, wh, wl);
-                            pin_slab_step<2 * MI, 2, NMF>();
-                            HIFICAR_PIN_BARRIER();
-                        }
+                        slab_step(x0h, x0l, u);
                         if (u + 2 < NC16) load_x(x0h, x0l, ad[u + 2]);
                         else load_x(x0h, x0l, adn[0]);
-                        {
-                            const frag_t wh = wr[u + 1][0], wl = wr[u + 1][1];
-                            wr[u + 1][0] = wp[(u + 1) * 128];
-                            wr[u + 1][1] = wp[(u + 1) * 128 + 64];
-                            HIFICAR_PIN_BARRIER();
-                            mfma_step(x1h, x1l, wh, wl);
-                            pin_slab_step<2 * MI, 2, NMF>();
-                            HIFICAR_PIN_BARRIER();
-                        }
+                        slab_step(x1h, x1l, u + 1);
                     }
                     wp += NC16 * 128;
+                    if constexpr (NB == 2) wp2 += NC16 * 128;
 #pragma unroll
                     for (int u = 0; u < NC16; ++u) {
                         ad[u][0] = adn[u][0];
@@ -832,17 +871,13 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                 auto tap = [&](const frag_t (&xh)[MI], const frag_t (&xl)[MI]) {
                     if (groups_left == 0) {
                         wp = wp_next;
+                        if constexpr (NB == 2) wp2 = wp_next + wst_next;
                         groups_left = groups_next;
                     }
                     --groups_left;
-                    const frag_t wh = wr[0][0], wl = wr[0][1];
-                    wr[0][0] = wp[0];
-                    wr[0][1] = wp[64];
+                    slab_step(xh, xl, 0);
                     wp += NC16 * 128;
-                    HIFICAR_PIN_BARRIER();
-                    mfma_step(xh, xl, wh, wl);
-                    pin_slab_step<2 * MI, 2, NMF>();
-                    HIFICAR_PIN_BARRIER();
+                    if constexpr (NB == 2) wp2 += NC16 * 128;
                 };
                 for (int t = 0; t < ntaps; t += 2) {
                     if (t + 1 < ntaps) {
@@ -868,14 +903,16 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             // lane (li, g) holds time column li and channels 8q + 4g + {0..3} in acc[mi][4q..4q+3]
             float* O = reinterpret_cast<float*>(smem_b + 2 * buf_bytes);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int b2 = 0; b2 < NB; ++b2)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v;
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][4 * q + e];
-                    *reinterpret_cast<f32x4*>(&O[(wave_row0 + mi * 32 + li) * OP + wn * 32 + 8 * q + 4 * g]) = v;
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[b2][mi][4 * q + e];
+                        *reinterpret_cast<f32x4*>(&O[(wave_row0 + mi * 32 + li) * OP + (wn * NB + b2) * 32 + 8 * q + 4 * g]) = v;
+                    }
         }
     }
     __syncthreads();  // matches the loader waves' final barrier
@@ -892,6 +929,17 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void conv_bf16x3_kernel(const M
 template <int MI, int WM, int WN, int NC16>
 __global__ __launch_bounds__((WM * WN + 4) * 64) void conv_f32_kernel(const MultiConvParams mp) {
     conv_ws_body<MI, WM, WN, NC16, true>(mp);
+}
+
+// register-blocked wave tiles (NB = 2): tile = WM*MI*32 rows x WN*64 channels
+template <int MI, int WM, int WN, int NC16>
+__global__ __launch_bounds__((WM * WN + 4) * 64) void conv_f32nb_kernel(const MultiConvParams mp) {
+    conv_ws_body<MI, WM, WN, NC16, true, 1, 2>(mp);
+}
+
+template <int MI, int WM, int WN, int NC16>
+__global__ __launch_bounds__((WM * WN + 4) * 64) void conv_bf16x3nb_kernel(const MultiConvParams mp) {
+    conv_ws_body<MI, WM, WN, NC16, false, 1, 2>(mp);
 }
 
 // split-K forms (small launches): tile = MI*32 rows x 32 channels, the four MFMA waves split the K loop
