@@ -196,9 +196,8 @@ class Trainer:
             "discriminator": _optimizer(config.get("discriminator_optimizer_type", "RAdam"), self.D.parameters(),
                                         config["discriminator_optimizer_params"], config.get("fused_optimizers", True)),
         }
-        # the modules notice parameter updates through the tensors' version counters — which torch's fused optimizers do not bump: tell them
-        self.optimizer["generator"].register_step_post_hook(lambda *_: self.G.invalidate_parameters())
-        self.optimizer["discriminator"].register_step_post_hook(lambda *_: self.D.invalidate_parameters())
+        # (the modules notice parameter updates through the tensors' version counters — which torch's fused optimizers do not bump; both
+        # networks watch optimizer steps themselves: articulatory_amd/utils/optim_hook.py)
         self.scheduler = {
             k: getattr(torch.optim.lr_scheduler, config.get(f"{k}_scheduler_type", "StepLR"))(optimizer=self.optimizer[k],
                                                                                                **config[f"{k}_scheduler_params"])
@@ -208,6 +207,16 @@ class Trainer:
         self.total_train_loss = defaultdict(float)
 
     # ------------------------------------------------------------------ one iteration (train.py:241-440)
+    def _check_conditioning(self, batch):
+        """The reference's collaters slice ``ph`` with the windows' frame starts and pass ``spk_id`` along (train.py:1029-1032, 248-249); the
+        datasets of this package (NpyPairs / DumpDirPairs / SyntheticPairs) carry neither, so a conditioned generator needs a caller-built batch."""
+        gp = self.config["generator_params"]
+        need = [k for k, on in (("spk_id", gp.get("use_spk_id", False)), ("ph", gp.get("use_ph", False) or self.use_ph_loss)) if on and k not in batch]
+        if need:
+            raise ValueError(f"the generator is conditioned on {' / '.join(need)} (generator_params) but the batch has no such entry: "
+                             f"batch keys {sorted(batch)}.  WindowCollater and this package's datasets do not produce it; build the batch yourself "
+                             "(ph: (B, frames) indices sliced with the window's frame starts, spk_id: (B,))")
+
     def train_step(self, batch):
         cfg = self.config
         x = batch["x"].to(self.device, non_blocking=True)
@@ -215,6 +224,7 @@ class Trainer:
         ar = batch["ar"].to(self.device, non_blocking=True) if self.use_ar else None
         spk_id = batch["spk_id"].to(self.device, non_blocking=True) if "spk_id" in batch else None  # train.py:248-249
         ph = batch["ph"].to(self.device, non_blocking=True) if "ph" in batch else None
+        self._check_conditioning(batch)
         log = {}
         adv_on = self.steps > cfg["discriminator_train_start_steps"]
         disc_y = (torch.cat([ar, y], dim=2) if self.use_ar else y) if adv_on else None  # train.py:340-346 (the same tensor in both parts)
@@ -355,6 +365,7 @@ class Trainer:
         log = {}
         spk_id = batch["spk_id"].to(self.device, non_blocking=True) if "spk_id" in batch else None
         ph = batch["ph"].to(self.device, non_blocking=True) if "ph" in batch else None
+        self._check_conditioning(batch)
         y_ = self.G(x, spk_id=spk_id, ar=ar, ph=ph)
         if self.use_ph_loss:
             y_, ph_ = y_
@@ -471,6 +482,11 @@ def main(argv=None):
     frames = config["batch_max_steps"] // hop
     gp = config["generator_params"]
     ar_len = gp.get("ar_input") if gp.get("use_ar", False) else None
+    if gp.get("use_spk_id", False) or gp.get("use_ph", False) or gp.get("use_ph_loss", False):
+        # the reference's collaters slice ph with the windows' starts and carry spk_id (train.py:1029-1032); the datasets below hold neither
+        raise NotImplementedError("articulatory-train: speaker / phoneme conditioned generators (use_spk_id / use_ph / use_ph_loss) need batches with "
+                                  "'spk_id' / 'ph' entries, which this package's datasets and WindowCollater do not produce; drive Trainer.train_step "
+                                  "with your own batches")
     if a.synthetic:
         data = SyntheticPairs(a.synthetic, 4 * frames, feature_dims(config), hop, seed=rank)
     elif a.train_dumpdir:

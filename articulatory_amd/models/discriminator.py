@@ -183,6 +183,7 @@ class _GeneratorLossFunction(torch.autograd.Function):
                                        douts.data_ptr() + 4 * doff, stream)
         _native.check(rc, "hificar_disc_loss")
         ctx.module, ctx.fake, ctx.douts, ctx.doff, ctx.BT, ctx.cfg, ctx.with_fm = module, fake, douts, doff, (B, T), cfg, real is not None
+        ctx.real_pass = real  # (identity only: which cached D(y_real) pass this loss was computed against)
         total, adv, fm = values[2], values[0], values[1]
         ctx.mark_non_differentiable(adv, fm)
         return total, adv, fm
@@ -206,7 +207,10 @@ class _GeneratorLossFunction(torch.autograd.Function):
         ctx.fake = ctx.douts = None
         done = torch.cuda.Event()
         done.record()
-        module.__dict__["_gside_done"] = done  # (start_real_gradient's side stream starts behind this point, not behind the generator's backward)
+        # start_real_gradient's side stream may start behind this point instead of behind everything enqueued since — but only for the real
+        # pass THIS loss used: the event is stored with that pass's identity
+        module.__dict__["_gside_done"] = (ctx.real_pass, done)
+        ctx.real_pass = None
         return (None, dx * g_total, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
 
 
@@ -441,6 +445,9 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         self._lib = self._handle = None
         self._grad_sync = None
         self._info_cache = {}
+        from ..utils.optim_hook import watch
+
+        watch(self)  # fused optimizers do not bump Parameter._version: every optimizer.step() over these parameters calls invalidate_parameters()
 
     # ------------------------------------------------------------------ native handle
     def _config(self):
@@ -503,11 +510,12 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
     def invalidate_parameters(self):
         """Force the next call to hand the parameters over again.  In-place updates through autograd-visible ops (foreach optimizer.step(),
         load_state_dict, p.copy_ under no_grad) are noticed by themselves through the tensors' version counters; writes through
-        ``p.data`` and torch's FUSED optimizers (``Adam(fused=True)`` does not bump ``_version``) are not — the Trainer calls this from an
-        optimizer post-step hook."""
+        ``p.data`` are not.  torch's FUSED optimizers (``Adam(fused=True)`` does not bump ``_version``) are covered by the process-wide
+        post-step hook the constructor registers (articulatory_amd/utils/optim_hook.py)."""
         self.__dict__.pop("_sent_sig", None)
         self.__dict__["_real_cache"] = None
         self.__dict__.pop("_early_real", None)
+        self.__dict__.pop("_gside_done", None)
 
     def _raw_parameters(self):
         cached = self.__dict__.get("_raw_cache")  # (walking the module tree costs ~1 ms per call; the criterion needs it every pass)
@@ -619,9 +627,9 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
             if side is None:
                 side = self.__dict__["_early_stream"] = torch.cuda.Stream(device=dev)
             after = self.__dict__.pop("_gside_done", None)
-            if after is not None:
-                side.wait_event(after)
-            else:
+            if after is not None and after[0] is ps:  # recorded by the backward of the generator loss that used THIS cached real pass
+                side.wait_event(after[1])
+            else:  # no such backward ran (early return, retain_graph, a newer cached pass): order behind everything enqueued so far
                 side.wait_stream(torch.cuda.current_stream())
             ps.tape.record_stream(side)
             with torch.cuda.stream(side):

@@ -113,6 +113,9 @@ class GBlockGenerator(_NativeGenerator):
         self._workspaces = {}
         self._lib = None
         self._grad_sync = None
+        from ..utils.optim_hook import watch
+
+        watch(self)
 
     def _create_handle(self, lib, handle):
         cfg = _native.make_gblock_config(self._params, _native.PRECISIONS[self.precision])

@@ -34,12 +34,20 @@ def _fold(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     return v * (g / norm)
 
 
+_PARAM_EPOCH = [0]  # bumped whenever a Parameter OBJECT is (re)assigned on any _ConvParams: cached parameter lists are rebuilt when it moves
+
+
 class _ConvParams(torch.nn.Module):
     """Parameter holder for one Conv1d / ConvTranspose1d of the reference, with or without weight norm.
 
     Registration order matches torch's weight-normed modules (bias, weight_g, weight_v) so that
     ``state_dict()`` key order equals the reference's.
     """
+
+    def __setattr__(self, name, value):
+        if isinstance(value, torch.nn.Parameter) or (value is None and name in self.__dict__.get("_parameters", ())):
+            _PARAM_EPOCH[0] += 1  # (a direct ``m.weight = Parameter(...)`` must not leave a stale list in the owning generator)
+        super().__setattr__(name, value)
 
     def __init__(self, weight_shape, n_bias, bias=True, fan_in=None):
         super().__init__()
@@ -234,6 +242,21 @@ class _GeneratorFunction(torch.autograd.Function):
         return (None, dc, dar, None, None, None, *gw)
 
 
+class _NoGraph(torch.autograd.Function):
+    """Marks the output of an eval-mode forward that ran on the inference kernels (no tape): backward raises a message that says why."""
+
+    @staticmethod
+    def forward(ctx, out, name, _witness):  # _witness: one trainable parameter, so that the output is part of a graph at all
+        ctx.name = name
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise RuntimeError(f"{ctx.name}: this forward ran on the inference kernels because the module is in eval() mode (no activations were "
+                           "kept for a backward pass).  Call .train(), or set `module.eval_autograd = True` to get torch's semantics "
+                           "(a graph whenever gradients are enabled), before the forward whose gradients you need.")
+
+
 class _NativeGenerator(torch.nn.Module):
     """What the generator classes of this package share: parameter plumbing (weight norm, folded state, the raw-parameter hand-over), the
     libhificar handle, workspaces, the inference / AR-synthesis / autograd entry points.  A subclass builds the parameter-holder modules with
@@ -330,7 +353,8 @@ class _NativeGenerator(torch.nn.Module):
     def invalidate_parameters(self):
         """The parameters were updated in a way their version counters do not show — ``p.data`` writes, and torch's FUSED optimizers
         (``torch.optim.Adam(fused=True)`` updates in place without bumping ``_version``): the next forward hands them over again.
-        ``articulatory_amd.bin.train.Trainer`` calls this from an optimizer post-step hook."""
+        The module registers itself with ``articulatory_amd.utils.optim_hook.watch`` at construction, so every ``optimizer.step()`` of an
+        optimizer that holds one of its parameters calls this — no wiring by the training loop."""
         self._param_sig = None
 
     def set_precision(self, precision):
@@ -345,11 +369,15 @@ class _NativeGenerator(torch.nn.Module):
 
     def _plist(self):
         """The parameters as a flat list, cached: walking the module tree (self.parameters()) costs ~1 ms per call on this model, and the
-        training forward needs the list three times.  Rebuilt whenever a parameter OBJECT may have changed (_invalidate: .to(), weight
-        norm applied / removed, load_state_dict) and checked against the cheap count of registered parameters."""
+        training forward needs the list three times.  Rebuilt whenever a parameter OBJECT may have changed: _invalidate (.to(), weight
+        norm applied / removed, load_state_dict) and any Parameter assignment on a conv holder (``_PARAM_EPOCH``).  Replacing the Parameter
+        object of one of torch's own sub-modules (the PastFCEncoder's Linear layers, the embeddings) by assignment is not seen: call
+        ``refresh_native()`` after such surgery."""
         lst = self.__dict__.get("_plist_cache")
-        if lst is None:
+        if lst is None or self.__dict__.get("_plist_epoch") != _PARAM_EPOCH[0]:
             lst = self.__dict__["_plist_cache"] = list(self.parameters())
+            self.__dict__["_plist_epoch"] = _PARAM_EPOCH[0]
+            self.__dict__["_raw_cache"] = None
         return lst
 
     def _param_signature(self):
@@ -471,7 +499,8 @@ class _NativeGenerator(torch.nn.Module):
     def _raw_parameters(self):
         """(names, tensors): every parameter as it sits in this module (state_dict keys: weight_g / weight_v of weight-normed convs,
         plain weights, biases) — the form hificar_set_parameters_device consumes."""
-        cache = getattr(self, "_raw_cache", None)
+        self._plist()  # (drops the cache below when a Parameter object was re-assigned)
+        cache = self.__dict__.get("_raw_cache")
         if cache is not None:
             cur = list(cache[2]())
             if len(cur) == len(cache[1]) and all(t is p for t, p in zip(cache[1], cur)):
@@ -507,8 +536,8 @@ class _NativeGenerator(torch.nn.Module):
                 mods.append(m)
                 names.append(name + ".weight")
         tensors = list(current())
-        self._raw_cache = (tuple(names), tensors, current)
-        return self._raw_cache[0], tensors
+        self.__dict__["_raw_cache"] = (tuple(names), tensors, current)
+        return self.__dict__["_raw_cache"][0], tensors
 
     def _forward_autograd(self, c, ar, spk_id=None, ph=None):
         """Training-mode forward (train.py:276,398: y_ = generator(x, spk_id=spk_id, ar=ar, ph=ph) under autograd)."""
@@ -569,10 +598,13 @@ class _NativeGenerator(torch.nn.Module):
             if int(ph.min()) < 0 or int(ph.max()) >= self._params["num_ph"]:
                 raise IndexError("index out of range in self")
             ph = ph.to(device=c.device, dtype=torch.int32).contiguous()
-        # the autograd node (and its full-utterance tape) only when a gradient can be asked for: an input that requires grad, or a
-        # module in training mode with trainable parameters — model.eval() inference without torch.no_grad() stays on the inference kernels
+        # the autograd node (and its full-utterance tape) when a gradient can be asked for: an input that requires grad, or trainable
+        # parameters of a module in training mode (or with ``eval_autograd = True``).  model.eval() inference without torch.no_grad() stays
+        # on the inference kernels; its output then carries a node whose backward explains that instead of torch's bare "element 0 of
+        # tensors does not require grad" (plain torch modules build a graph in eval mode too: set ``eval_autograd`` for that)
+        trainable = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist())
         if torch.is_grad_enabled() and (c.requires_grad or (ar is not None and ar.requires_grad)
-                                        or (self.training and any(p.requires_grad for p in self._plist()))):
+                                        or (trainable and (self.training or getattr(self, "eval_autograd", False)))):
             if lengths is not None:
                 raise NotImplementedError("autograd with ragged lengths is not built")
             return self._forward_autograd(c, ar, spk_id if self.use_spk_id else None, ph if self.use_ph else None)
@@ -592,6 +624,8 @@ class _NativeGenerator(torch.nn.Module):
                                                 ph_out.data_ptr() if ph_out is not None else None,
                                                 B, T, ws_ptr, ws_bytes, ctypes.c_void_p(stream))
         _native.check(rc, "hificar_forward")
+        if trainable:  # eval mode with trainable parameters: no tape was kept — say so if somebody calls backward on this
+            out = _NoGraph.apply(out, type(self).__name__, next(p for p in self._plist() if p.requires_grad))
         return (out, ph_out) if self.use_ph_loss else out
 
     def ar_synthesis(self, c, chunk_frames, lengths=None):
@@ -772,6 +806,9 @@ class HiFiGANGenerator(_NativeGenerator):
         self._workspaces = {}
         self._lib = None
         self._grad_sync = None
+        from ..utils.optim_hook import watch
+
+        watch(self)  # fused optimizers do not bump Parameter._version: every optimizer.step() over these parameters invalidates the hand-over
 
     def _tap_shape(self, name, B, T, Tb):
         """(buffer shape, valid rows or None) of a debug tap; Tb = the launch's bucket of frames."""

@@ -250,3 +250,49 @@ def test_gradient_all_reduce_over_rccl_world1():
     spans = sorted(r for _, rs in seen for r in rs)
     assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:]))
     assert spans[-1][0] + spans[-1][1] == sum((p.numel() + 3) & ~3 for p in ref.values())
+
+
+def test_fused_adam_without_the_trainer_reaches_the_native_weights():
+    """torch.optim.Adam(fused=True) leaves Parameter._version untouched; the modules watch optimizer steps themselves
+    (articulatory_amd/utils/optim_hook.py), so a plain training loop — no Trainer, no hooks — sees the new weights in the next forward:
+    a no_grad forward after the step equals the oracle on the UPDATED state_dict and differs from the forward before it."""
+    params = dict(E2W_PARAMS, channels=64)
+    g, sd = build(params, 5)
+    B, T = 2, 6
+    c = torch.from_numpy(synth_features(B, T, 13, seed=61).transpose(0, 2, 1).copy()).cuda()
+    ar = torch.zeros(B, 1, 512).cuda()
+    opt = torch.optim.Adam(g.parameters(), lr=1e-2, fused=True)
+    versions = [p._version for p in g.parameters()]
+    y0 = g(c, ar=ar)
+    y0.square().mean().backward()
+    opt.step()
+    assert [p._version for p in g.parameters()] == versions  # the premise: a fused step is invisible to version counters
+    with torch.no_grad():
+        y1 = g(c, ar=ar)
+        now = {k: v.detach().cpu().numpy() for k, v in g.state_dict().items()}
+        ref = O.generator_forward(O.fold_weight_norm(now), params, c.cpu(), ar.cpu())
+    assert rel_err(y1.cpu().numpy(), ref.numpy()) < 2e-5
+    assert float((y1 - y0.detach()).abs().max()) > 1e-4
+
+
+def test_eval_mode_forward_explains_itself_on_backward():
+    """model.eval() with gradients enabled stays on the inference kernels (no tape); a backward through its output says why instead of torch's
+    bare "does not require grad"; ``eval_autograd = True`` gives torch's semantics (a graph in eval mode too), identical gradients to train()."""
+    params = dict(E2W_PARAMS, channels=64)
+    g, _ = build(params, 6)
+    c = torch.from_numpy(synth_features(1, 5, 13, seed=62).transpose(0, 2, 1).copy()).cuda()
+    ar = torch.zeros(1, 1, 512).cuda()
+    y_train = g(c, ar=ar)
+    y_train.sum().backward()
+    want = g.input_conv.weight_v.grad.clone()
+    g.zero_grad(set_to_none=True)
+    g.eval()
+    y = g(c, ar=ar)
+    assert torch.equal(y.detach(), y_train.detach())
+    with pytest.raises(RuntimeError, match="eval\\(\\) mode"):
+        y.sum().backward()
+    g.eval_autograd = True
+    g(c, ar=ar).sum().backward()
+    assert torch.equal(g.input_conv.weight_v.grad, want)
+    with torch.no_grad():  # plain inference is untouched
+        assert not g(c, ar=ar).requires_grad

@@ -302,3 +302,46 @@ def test_decode_lists_then_loads_lazily(tmp_path):
         np.load = real_load
     with pytest.raises(ValueError):
         D.list_features(None, None)
+
+
+def test_optimizer_steps_invalidate_the_native_hand_over():
+    """torch's fused optimizers update in place without bumping Parameter._version, the modules' only own signal: every module registers with the
+    process-wide optimizer post-step hook (articulatory_amd/utils/optim_hook.py), so ANY optimizer.step() over its parameters invalidates the
+    hand-over — with or without the Trainer."""
+    from articulatory_amd.models import GBlockGenerator, HiFiGANGenerator, HiFiGANMultiScaleMultiPeriodDiscriminator
+    from articulatory_amd.utils.synth import disc_params
+
+    g = HiFiGANGenerator(**dict(E2W_PARAMS, channels=32))
+    b = GBlockGenerator(in_channels=13, channels=32, g_scales=[5, 1, 4, 1, 1, 2, 1, 2, 1, 1], g_kernel_sizes=[3] * 10)
+    d = HiFiGANMultiScaleMultiPeriodDiscriminator(**disc_params())
+    calls = {"g": 0, "b": 0, "d": 0}
+    for key, m in (("g", g), ("b", b), ("d", d)):
+        orig = m.invalidate_parameters
+        m.invalidate_parameters = (lambda orig=orig, key=key: (calls.__setitem__(key, calls[key] + 1), orig())[1])
+    for p in list(g.parameters()) + list(d.parameters()):
+        p.grad = torch.zeros_like(p)
+    og = torch.optim.Adam(g.parameters(), lr=1e-3)
+    od = torch.optim.SGD(d.parameters(), lr=1e-3)
+    og.step()
+    assert calls == {"g": 1, "b": 0, "d": 0}
+    od.step()
+    od.step()
+    assert calls == {"g": 1, "b": 0, "d": 2}
+    other = torch.nn.Linear(2, 2)
+    other.weight.grad = torch.zeros_like(other.weight)
+    torch.optim.SGD([other.weight], lr=0.1).step()  # an unrelated optimizer touches nobody
+    assert calls == {"g": 1, "b": 0, "d": 2}
+
+
+def test_reassigned_parameter_objects_refresh_the_cached_lists():
+    from articulatory_amd.models import HiFiGANGenerator
+
+    g = HiFiGANGenerator(**dict(E2W_PARAMS, channels=32))
+    before = g._plist()
+    names0, tensors0 = g._raw_parameters()
+    new = torch.nn.Parameter(torch.zeros_like(g.input_conv.weight_v))
+    g.input_conv.weight_v = new  # direct surgery on a conv holder: no load_state_dict / .to() / weight-norm call in between
+    after = g._plist()
+    assert any(p is new for p in after) and not any(p is new for p in before)
+    names1, tensors1 = g._raw_parameters()
+    assert names1 == names0 and any(t is new for t in tensors1)

@@ -128,3 +128,18 @@ def test_recipe_values_equal_the_shipped_yaml(recipe, path):
             v = {kk: vv for kk, vv in v.items() if kk in ref[k]}
         assert ref[k] == v, (k, ref[k], v)
     assert mine["discriminator_params"] == ref["discriminator_params"]
+
+
+def test_conditioned_generators_need_conditioning_batches():
+    """use_spk_id / use_ph / use_ph_loss: the reference's collaters carry spk_id and slice ph (train.py:1029-1032, 248-249); this package's
+    datasets do not — a clear error instead of an AttributeError on None deep inside the step."""
+    import types
+
+    from articulatory_amd.bin.train import Trainer
+
+    t = types.SimpleNamespace(config={"generator_params": {"use_spk_id": True, "use_ph": False}}, use_ph_loss=True)
+    with pytest.raises(ValueError, match="spk_id / ph"):
+        Trainer._check_conditioning(t, {"x": None, "y": None})
+    Trainer._check_conditioning(t, {"x": None, "y": None, "spk_id": None, "ph": None})
+    t = types.SimpleNamespace(config={"generator_params": {}}, use_ph_loss=False)
+    Trainer._check_conditioning(t, {"x": None})
