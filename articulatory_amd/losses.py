@@ -101,7 +101,9 @@ class MelSpectrogramLoss(torch.nn.Module):
     """Mel-spectrogram loss, constructor arguments as the reference's (mel_loss.py:117-132).  MI355X-native (no CPU fallback)."""
 
     def __init__(self, fs=22050, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=80, fmax=7600, center=True,
-                 normalized=False, onesided=True, eps=1e-10, log_base=10.0):
+                 normalized=False, onesided=True, eps=1e-10, log_base=10.0, melmat=None):
+        """``melmat`` (not in the reference): a (num_mels, fft_size / 2 + 1) filterbank to use instead of this package's restatement of
+        ``librosa.filters.mel`` — e.g. librosa's own matrix where librosa is installed."""
         super().__init__()
         if window != "hann" or not center or normalized or not onesided:
             raise NotImplementedError("MelSpectrogramLoss: only window='hann', center=True, normalized=False, onesided=True are built")
@@ -109,7 +111,11 @@ class MelSpectrogramLoss(torch.nn.Module):
             raise ValueError(f"log_base: {log_base} is not supported.")
         fmin = 0 if fmin is None else fmin
         fmax = fs / 2 if fmax is None else fmax
-        self.melmat = np.ascontiguousarray(mel_filterbank(fs, fft_size, num_mels, fmin, fmax))
+        if melmat is None:
+            melmat = mel_filterbank(fs, fft_size, num_mels, fmin, fmax)
+        self.melmat = np.ascontiguousarray(np.asarray(melmat, dtype=np.float32))
+        if self.melmat.shape != (num_mels, fft_size // 2 + 1):
+            raise ValueError(f"melmat must be ({num_mels}, {fft_size // 2 + 1}), got {self.melmat.shape}")
         self._cfg = _native.HificarMelConfig(fft_size, hop_size, fft_size if win_length is None else win_length, num_mels, eps,
                                              0 if log_base is None else int(log_base), 0)
         self._lib = self._handle = None
