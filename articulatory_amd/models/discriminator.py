@@ -259,7 +259,7 @@ class _DiscriminatorLossFunction(torch.autograd.Function):
             ws, woff = _aligned(wsb // 4, dev)
             nfold = int(lib.hificar_disc_grad_floats(handle))
             raw = torch.zeros(int(lib.hificar_disc_raw_grad_floats(handle)), dtype=torch.float32, device=dev)
-            reducer, cb, errors = None, None, []
+            reducer, cb = None, None
             # ONE folded-gradient buffer: the second pass adds to what the first left (hificar_disc_set_grad_accumulate), and the weight-norm
             # chain rule multiplies by the upstream gradient while it writes (hificar_disc_set_grad_scale): no add pass, no scaling pass
             g_total = g_total.to(torch.float32).contiguous()
@@ -281,25 +281,22 @@ class _DiscriminatorLossFunction(torch.autograd.Function):
                     # data-parallel training: one gradient bucket per sub-discriminator.  During the LAST pass libhificar calls back as
                     # each sub-network's gradients (both passes' sum by then) are enqueued on its side stream: there the weight-norm chain
                     # rule runs and the bucket's all-reduce (RCCL over xGMI) starts while the other sub-networks still compute.
-                    from ..utils.buckets import BucketReducer, bucket_ranges
+                    from ..utils.buckets import BucketHook, BucketReducer, bucket_ranges
 
                     group, average = module._grad_sync
                     nb = int(lib.hificar_disc_grad_bucket_count(handle))
                     ids = [int(lib.hificar_disc_raw_param_bucket(handle, i)) for i in range(len(ctx.shapes))]
                     ranges, total = bucket_ranges(ids, [int(np.prod(sh)) for sh in ctx.shapes], nb)
                     assert total == raw.numel()
-                    reducer = BucketReducer(raw, ranges, group, average)
 
-                    def on_bucket(bucket, bstream, _user):
-                        try:
-                            with torch.cuda.stream(torch.cuda.ExternalStream(bstream, device=dev)):
-                                _native.check(lib.hificar_disc_weight_norm_backward_bucket(handle, g.data_ptr(), raw.data_ptr(), bucket,
-                                                                                           ctypes.c_void_p(bstream)), "hificar_disc_weight_norm_backward_bucket")
-                                reducer.reduce(bucket)
-                        except BaseException as e:  # an exception must not cross the C frames: re-raised below
-                            errors.append(e)
+                    def chain_rule(bucket, bstream):
+                        _native.check(lib.hificar_disc_weight_norm_backward_bucket(handle, g.data_ptr(), raw.data_ptr(), bucket, ctypes.c_void_p(bstream)),
+                                      "hificar_disc_weight_norm_backward_bucket")
 
-                    cb = _native.BUCKET_FN(on_bucket)
+                    # (the sub-network's side stream becomes torch's current stream inside the callback: the collective orders itself behind it)
+                    reducer = BucketHook(BucketReducer(raw, ranges, group, average), chain_rule,
+                                         lambda bstream: torch.cuda.stream(torch.cuda.ExternalStream(bstream, device=dev)))
+                    cb = _native.BUCKET_FN(reducer)
                     _native.check(lib.hificar_disc_set_bucket_callback(handle, cb, None), "hificar_disc_set_bucket_callback")
                 try:
                     _native.check(lib.hificar_disc_set_grad_accumulate(handle, 1 if (step > 0 or first_accumulates) else 0), "hificar_disc_set_grad_accumulate")
@@ -313,10 +310,8 @@ class _DiscriminatorLossFunction(torch.autograd.Function):
                         lib.hificar_disc_set_bucket_callback(handle, _native.BUCKET_FN(), None)
                         lib.hificar_disc_set_grad_scale(handle, None)
                 _native.check(rc, "hificar_disc_backward_flat")
-                if errors:
-                    raise errors[0]
             if reducer is not None:
-                reducer.finish()
+                reducer.finish()  # (re-raises what a bucket callback caught)
             else:
                 try:
                     _native.check(lib.hificar_disc_set_grad_scale(handle, g_total.data_ptr()), "hificar_disc_set_grad_scale")

@@ -193,29 +193,24 @@ class _GeneratorFunction(torch.autograd.Function):
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             raw = torch.zeros(int(lib.hificar_raw_grad_floats(handle)), dtype=torch.float32, device=dev)
             reducer = cb = None
-            errors = []
             if module._grad_sync is not None:
                 # data-parallel training: the gradients are all-reduced bucket by bucket (RCCL over xGMI under the "nccl" backend) WHILE
                 # the backward pass still runs — libhificar calls back when a bucket's gradient kernels are enqueued (last stage first),
                 # the bucket's weight-norm chain rule runs right behind them and its collective starts on the communication stream
-                from ..utils.buckets import BucketReducer, bucket_ranges
+                from ..utils.buckets import BucketHook, BucketReducer, bucket_ranges
 
                 group, average = module._grad_sync
                 nb = int(lib.hificar_grad_bucket_count(handle))
                 ids = [int(lib.hificar_raw_param_bucket(handle, i)) for i in range(len(ctx.shapes))]
                 ranges, total = bucket_ranges(ids, [int(np.prod(sh)) for sh in ctx.shapes], nb)
                 assert total == raw.numel()
-                reducer = BucketReducer(raw, ranges, group, average)
 
-                def on_bucket(bucket, bstream, _user):
-                    try:
-                        _native.check(lib.hificar_weight_norm_backward_bucket(handle, grads.data_ptr(), raw.data_ptr(), bucket, ctypes.c_void_p(bstream)),
-                                      "hificar_weight_norm_backward_bucket")
-                        reducer.reduce(bucket)  # (bstream is the current stream: the collective waits for what is enqueued so far)
-                    except BaseException as e:  # an exception must not cross the C frames: re-raised below
-                        errors.append(e)
+                def chain_rule(bucket, bstream):  # (bstream is the current stream here: the generator's backward runs on one stream)
+                    _native.check(lib.hificar_weight_norm_backward_bucket(handle, grads.data_ptr(), raw.data_ptr(), bucket, ctypes.c_void_p(bstream)),
+                                  "hificar_weight_norm_backward_bucket")
 
-                cb = _native.BUCKET_FN(on_bucket)
+                reducer = BucketHook(BucketReducer(raw, ranges, group, average), chain_rule)
+                cb = _native.BUCKET_FN(reducer)
                 _native.check(lib.hificar_set_bucket_callback(handle, cb, None), "hificar_set_bucket_callback")
             try:
                 rc = lib.hificar_backward_cond(handle, dout.data_ptr(), dph_out.data_ptr() if dph_out is not None else None, out.data_ptr(),
@@ -227,10 +222,8 @@ class _GeneratorFunction(torch.autograd.Function):
                 if cb is not None:
                     lib.hificar_set_bucket_callback(handle, _native.BUCKET_FN(), None)
             _native.check(rc, "hificar_backward")
-            if errors:
-                raise errors[0]
             if reducer is not None:
-                reducer.finish()
+                reducer.finish()  # (re-raises what a bucket callback caught)
             else:
                 _native.check(lib.hificar_weight_norm_backward(handle, grads.data_ptr(), raw.data_ptr(), stream), "hificar_weight_norm_backward")
         gw, off = [], 0

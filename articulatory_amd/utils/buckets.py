@@ -54,3 +54,36 @@ class BucketReducer:
         if self.average:
             self.raw.div_(dist.get_world_size(self.group))
         return self.raw
+
+
+class BucketHook:
+    """Host side of ``hificar_bucket_fn`` (include/hificar.h) for one backward pass: libhificar calls it — on the host, from inside the native
+    backward — right after bucket ``b``'s last gradient kernel has been enqueued on ``bstream``.  The hook runs the bucket's weight-norm chain rule
+    behind those kernels (``chain_rule(bucket, bstream)``) and starts the bucket's all-reduce on that stream (``stream_ctx(bstream)`` makes it the
+    current one: the collective waits for what is enqueued on it so far and runs beside the rest of the backward pass).  An exception must not
+    cross the C frames: it is kept and re-raised by ``finish()``, which otherwise waits for every collective and averages.
+
+    Every rank's native backward reports its buckets in the same order (same code, same shapes), which is what the collectives need; the order is
+    NOT ascending and the callbacks of the discriminators come from eight different streams."""
+
+    def __init__(self, reducer, chain_rule, stream_ctx=None):
+        self.reducer, self.chain_rule, self.stream_ctx, self.errors = reducer, chain_rule, stream_ctx, []
+
+    def __call__(self, bucket, bstream, _user=None):
+        try:
+            if self.stream_ctx is None:
+                self.chain_rule(bucket, bstream)
+                self.reducer.reduce(bucket)
+            else:
+                with self.stream_ctx(bstream):
+                    self.chain_rule(bucket, bstream)
+                    self.reducer.reduce(bucket)
+        except BaseException as e:  # noqa: BLE001  (re-raised on the Python side of the call)
+            self.errors.append(e)
+
+    def finish(self):
+        if self.errors:
+            for w in self.reducer.pending:  # collectives already started must still complete on every rank
+                w.wait()
+            raise self.errors[0]
+        return self.reducer.finish()

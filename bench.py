@@ -347,6 +347,15 @@ def main(argv=None, synth_factory=None):
         else:
             dist.init_process_group(backend="gloo")
 
+    ranks = 1
+    if use_dist:
+        ranks = dist.get_world_size()  # what the backend (RCCL under "nccl") actually formed, not what the environment promised
+        if ranks != args.gpus and not (args.gpus == 1 and ranks == 1):
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {ranks} ranks")
+    from articulatory_amd.utils.affinity import pin_rank
+
+    affinity = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))  # N ranks must not share one OpenMP pool / core set
+
     params = dict(CAR_PARAMS)
     sd = synth_state_dict(params, seed=1234)
     g = None
@@ -403,6 +412,7 @@ def main(argv=None, synth_factory=None):
         "value": round(value, 1),
         "unit": "samples/s",
         "n_gpus": world,
+        "ranks": ranks,  # torch.distributed's own count (RCCL ranks at N > 1)
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
@@ -419,6 +429,7 @@ def main(argv=None, synth_factory=None):
             "arithmetic": "exact fp32 products (v_mfma_f32_32x32x2_f32), fp32 accumulate" if args.precision == "f32"
                           else "split-bf16 products hi*hi + hi*lo + lo*hi (3 x v_mfma_f32_32x32x16_bf16), fp32 accumulate",
             "gather": (args.gather if use_dist else "none"),
+            "host_affinity": affinity,
         },
         "x_realtime": round(value / SAMPLING_RATE, 1),
         "algorithmic_tflops": round(2.0 * macs_step * world * args.steps / dt / 1e12, 2),

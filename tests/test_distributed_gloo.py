@@ -192,3 +192,121 @@ def test_bucketed_all_reduce_equals_single_collective_world2():
         p.join(timeout=60)
     assert status == "ok", msg
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _hook_worker(rank, world, port, q):
+    """The bucket wiring both networks' backward passes use (articulatory_amd/utils/buckets.py::BucketHook + BucketReducer) driven by a stand-in
+    native backward: callbacks in the native (non-ascending) order, some of them from side threads as the discriminators' sub-network streams
+    would, a chain rule between "folded" and "raw" gradients, an error inside a callback."""
+    import threading
+
+    import torch.distributed as dist
+
+    from articulatory_amd.utils.buckets import BucketHook, BucketReducer, bucket_ranges
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_buckets = 6
+        ids = [5, 0, 0, 3, 3, 3, 1, 2, 2, 4, 4, 5]
+        numels = [9, 130, 64, 7, 1, 300, 32, 17, 5, 1024, 3, 11]
+        ranges, total = bucket_ranges(ids, numels, n_buckets)
+        folded = torch.from_numpy(np.random.default_rng(7 + rank).standard_normal(total).astype(np.float32))  # this rank's folded gradients
+        want = folded * 0.5
+        dist.all_reduce(want)
+        want /= world
+        raw = torch.zeros(total)
+        seen = []
+
+        def chain_rule(bucket, bstream):  # stand-in for hificar[_disc]_weight_norm_backward_bucket: raw slices of ONE bucket from the folded ones
+            seen.append((bucket, bstream, threading.get_ident()))
+            for off, n in ranges[bucket]:
+                raw[off:off + n] = folded[off:off + n] * 0.5
+
+        entered = []
+
+        class Ctx:  # stand-in for torch.cuda.stream(ExternalStream(bstream))
+            def __init__(self, s):
+                self.s = s
+
+            def __enter__(self):
+                entered.append(self.s)
+
+            def __exit__(self, *a):
+                return False
+
+        hook = BucketHook(BucketReducer(raw, ranges, None, True), chain_rule, Ctx)
+        order = (4, 1, 5, 0, 3, 2)  # the order the (stand-in) native backward completes its buckets in: identical on every rank
+        for i, b in enumerate(order):
+            if i % 2:  # every other callback arrives on a side thread (one at a time: the collectives' order must match across ranks)
+                t = threading.Thread(target=hook, args=(b, 1000 + b, None))
+                t.start()
+                t.join()
+            else:
+                hook(b, 1000 + b, None)
+        out = hook.finish()
+        assert out is raw and torch.equal(raw, want), float((raw - want).abs().max())
+        assert [s[0] for s in seen] == list(order) and entered == [1000 + b for b in order]
+        assert len({s[2] for s in seen}) >= 2  # callbacks really came from more than one thread
+
+        # a failing chain rule inside a callback: nothing crosses the (C) caller's frames, finish() raises it — on every rank alike
+        def bad_rule(bucket, bstream):
+            if bucket == 1:
+                raise ValueError("chain rule failed")
+            chain_rule(bucket, bstream)
+
+        hook2 = BucketHook(BucketReducer(torch.zeros(total), ranges, None, True), bad_rule)
+        for b in order:
+            hook2(b, None, None)  # must not raise here
+        try:
+            hook2.finish()
+            raise AssertionError("finish() swallowed the callback's error")
+        except ValueError as e:
+            assert "chain rule failed" in str(e)
+        if rank == 0:
+            q.put(("ok", None, None))
+    except Exception as e:  # pragma: no cover
+        if rank == 0:
+            q.put(("err", repr(e), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_hook_wiring_with_a_stand_in_backward_world2():
+    """What sync_gradients() installs in both networks' backward passes, end to end at world size 2 over gloo, with a stand-in for the native
+    backward: buckets reported out of order and from side threads, the per-bucket chain rule in front of each collective, errors inside the
+    callback.  (The CUDA-side plumbing around it — ctypes callback, ExternalStream — runs in the world-1 RCCL tests on the GPU box.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hook_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status, msg, _ = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+    assert status == "ok", msg
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_pin_rank_partitions_the_allowed_cores():
+    """articulatory_amd/utils/affinity.py: rank r of W gets the r-th W-th of the cores this process may use, and a bounded intra-op pool."""
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no sched_getaffinity")
+    import subprocess
+    import sys
+
+    code = ("import os, sys; sys.path.insert(0, %r); from articulatory_amd.utils.affinity import pin_rank; import torch;"
+            "before = sorted(os.sched_getaffinity(0)); d = pin_rank(int(sys.argv[1]), 2); after = sorted(os.sched_getaffinity(0));"
+            "print(len(before), after[0], after[-1], len(after), torch.get_num_threads(), d is not None)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = [subprocess.run([sys.executable, "-c", code, str(r)], capture_output=True, text=True, check=True).stdout.split() for r in (0, 1)]
+    n = int(outs[0][0])
+    if n < 2:
+        pytest.skip("one core")
+    a, b = outs
+    assert int(a[3]) == int(b[3]) == n // 2 and int(a[2]) < int(b[1])      # disjoint contiguous halves
+    assert int(a[4]) == min(n // 2, 16) and a[5] == "True"
+    env = dict(os.environ, HIFICAR_NO_AFFINITY="1")
+    off = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, check=True, env=env).stdout.split()
+    assert int(off[3]) == n and off[5] == "False"
