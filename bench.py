@@ -254,8 +254,10 @@ def training_leg(steps=5):
     t0 = time.perf_counter()
     for _ in range(steps):
         log = iteration()
+    t_enq = time.perf_counter()  # every launch of the K iterations is enqueued (train_step returns device scalars: nothing waits inside)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    host_enqueue = (t_enq - t0) / steps
     assert all(np.isfinite(float(v)) for v in log.values())
     g_fwd, d_fwd = 2.0 * t.G.macs(B, frames), 2.0 * t.D.macs(B, T_disc)
     breakdown = {"generator_forward_x2": 2 * g_fwd, "generator_backward": 2 * g_fwd, "discriminator_forward_x3": 3 * d_fwd,
@@ -286,6 +288,9 @@ def training_leg(steps=5):
             "workload": f"e2w_hifigan_car.yaml: batch {B} x ({cfg['batch_max_steps']} + {cfg['generator_params']['ar_input']} AR) samples, mel + adversarial + "
                         "feature-matching losses, Adam x2",
             "parity_gate": gate, "steps": steps, "gan_iteration_ms": round(dt * 1e3, 2), "gan_windows_per_s": round(B / dt, 1),
+            # host time to ENQUEUE one iteration (Python + ctypes + launches, no profiler attached) next to its wall time: at >= 0.85 the
+            # iteration is host-bound and a slower host — or 8 ranks sharing one — becomes the bottleneck
+            "host_enqueue_ms": round(host_enqueue * 1e3, 2), "host_enqueue_over_wall": round(host_enqueue / dt, 3),
             "gan_training_samples_per_s": round(B * cfg["batch_max_steps"] / dt, 1),
             "flops_per_iteration": flops, "flops_breakdown": breakdown,
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["f32"], 4),
