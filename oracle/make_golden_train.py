@@ -39,7 +39,12 @@ B, SEED_G, SEED_D, SEED_X = 8, 41, 42, 43
 # shipped recipes (same Trainer, same checks) at a batch the CPU finishes in minutes:  --recipe e2w | mri
 #   e2w  egs/ema/voc1/conf/e2w_hifigan.yaml          the same networks on 8000-sample windows (100 frames: several row chunks per sequence)
 #   mri  egs/mri/voc1/conf/mri2w_hifigan_car.yaml    230-dim features, x240 upsampling (scales 8, 5, 3, 2), 30000-sample windows at 20 kHz
+#   car_lin  the "car" recipe with every LeakyReLU SLOPE SET TO 1 in both networks (generator_params / scale_ / period_discriminator_params
+#            nonlinear_activation_params): the assembled iteration without the kinks that make recipe-size gradients a coin flip per activation
+#            (what remains: the generator's hard-coded LeakyReLU(0.01) in front of its output conv and LeakyReLU(0.1) in the PastFCEncoder,
+#            |.| of the L1 mel / feature-matching terms) — lets the device's assembled step be held element-wise, see tests/test_gpu_recipe.py
 RECIPES = {"car": ("egs/ema/voc1/conf/e2w_hifigan_car.yaml", 8, "gold_train_step.npz", ("mel", "stft")),
+           "car_lin": ("egs/ema/voc1/conf/e2w_hifigan_car.yaml", 8, "gold_train_step_lin.npz", ("mel",)),
            "e2w": ("egs/ema/voc1/conf/e2w_hifigan.yaml", 4, "gold_train_step_e2w.npz", ("mel",)),
            "mri": ("egs/mri/voc1/conf/mri2w_hifigan_car.yaml", 2, "gold_train_step_mri.npz", ("mel",))}
 
@@ -50,6 +55,17 @@ def recipe_config(recipe="car"):
     with open(os.path.join(REF, RECIPES[recipe][0])) as f:
         cfg = yaml.safe_load(f)
     cfg["generator_params"] = {k: v for k, v in cfg["generator_params"].items() if k not in ("final_scale", "extra_art")}
+    if recipe == "car_lin":
+        linearize(cfg)
+    return cfg
+
+
+def linearize(cfg):
+    """Every configurable LeakyReLU slope of both networks -> 1 (in place; also used by the tests on the package's own config)."""
+    cfg["generator_params"] = dict(cfg["generator_params"], nonlinear_activation_params={"negative_slope": 1.0})
+    dp = cfg["discriminator_params"] = dict(cfg["discriminator_params"])
+    for k in ("scale_discriminator_params", "period_discriminator_params"):
+        dp[k] = dict(dp[k], nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 1.0})
     return cfg
 
 
@@ -135,6 +151,8 @@ def main():
             logs, tensors = kept[torch.float32]
             for k, v in logs.items():
                 out[f"{aux}::log::{k}"] = np.array(v)
+                if recipe == "car_lin":  # (the yardstick for the logged losses too: the discriminator part runs on the UPDATED generator, whose
+                    out[f"{aux}::log64::{k}"] = np.array(kept[torch.float64][0][k])  # first Adam step is a sign function of noisy gradients)
                 print(f"{aux}: {k} = {v:.7f}   (float64: {kept[torch.float64][0][k]:.7f})")
             for net, names in (("generator", G_TENSORS), ("discriminator", D_TENSORS)):
                 for n in names:

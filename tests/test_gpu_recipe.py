@@ -18,7 +18,7 @@ from articulatory_amd.models import HiFiGANGenerator
 from articulatory_amd.utils.recipes import recipe_train_config
 from articulatory_amd.utils.synth import synth_disc_state_dict, synth_state_dict
 from oracle import hificar_oracle as O
-from oracle.make_golden_train import D_TENSORS, G_TENSORS, make_batch
+from oracle.make_golden_train import D_TENSORS, G_TENSORS, linearize, make_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -31,14 +31,32 @@ def sampled(gold, name, arr):
     return flat[gold[name + "::idx"]], gold[name + "::vals"].astype(np.float64)
 
 
+FIXTURES = {"car": "gold_train_step.npz", "car_lin": "gold_train_step_lin.npz", "e2w": "gold_train_step_e2w.npz", "mri": "gold_train_step_mri.npz"}
+# The one fixture tensor whose device gradient sits further from the reference's fp32 run than a small multiple of the reference's own
+# fp32-vs-fp64 deviation: the period-2 discriminator's first layer (Conv2d 1 -> 32, 160 weights, each a sum over ~20 000 positions that nearly
+# cancels on the "car" batch: 3.0e-4 median against the yardstick's 1.0e-5; on the other three fixtures the same tensor is AT its yardstick,
+# 7e-6 .. 1.5e-4).  The weight-gradient kernel accumulates a row split's positions sequentially in the MFMA accumulator; oneDNN blocks them.
+CANCELLING = {("car", "mpd.discriminators.0.convs.0.0.weight_v")}
+
+
 # (recipe, auxiliary loss): config 5's recipe with both losses; the other two shipped recipes — e2w_hifigan.yaml (8000-sample windows) and
-# mri2w_hifigan_car.yaml (230-dim features, x240, 30000-sample windows) — with the mel loss they ship with (oracle/make_golden_train.py --recipe)
-@pytest.mark.parametrize("recipe,aux", [("car", "mel"), ("car", "stft"), ("e2w", "mel"), ("mri", "mel")])
+# mri2w_hifigan_car.yaml (230-dim features, x240, 30000-sample windows) — with the mel loss they ship with (oracle/make_golden_train.py --recipe);
+# "car_lin": config 5's recipe with every LeakyReLU slope of both networks set to 1 (round 4: the assembled iteration without its activation kinks)
+@pytest.mark.parametrize("recipe,aux", [("car", "mel"), ("car", "stft"), ("e2w", "mel"), ("mri", "mel"), ("car_lin", "mel")])
 def test_full_recipe_iteration_vs_reference_train_step(recipe, aux):
-    gold = np.load(os.path.join(GOLDEN, {"car": "gold_train_step.npz", "e2w": "gold_train_step_e2w.npz", "mri": "gold_train_step_mri.npz"}[recipe]))
+    """What "equal" can mean here.  The fixtures carry, per tensor, the reference's OWN fp32-vs-fp64 gradient deviation (the same _train_step run
+    in float64).  It is NOT small and NOT a kink effect: with every LeakyReLU slope at 1 ("car_lin") the reference's fp32 gradients sit 1e-4 .. 3e-4
+    (median; 1e-3 .. 3.5e-3 max) of each tensor's scale from its float64 ones — the mel loss's log and the un-normalised 80-conv network amplify
+    fp32 rounding that far — and its fp32 fake / discriminator loss 1.5e-4 from the float64 value (the discriminator part runs on the generator
+    AFTER its first Adam step, a sign function of those gradients).  So the assembled step is held to a small multiple of that yardstick, tensor by
+    tensor: measured 1 - 6 x (tests/dev/recipe_yardstick_probe.py), i.e. the device is as close to the reference's fp32 run as two correct fp32
+    implementations of this step can be expected to be.  (Round 3's review hoped a slope-1 fixture would allow 1e-5: the yardstick says no.)"""
+    gold = np.load(os.path.join(GOLDEN, FIXTURES[recipe]))
     B = int(gold["B"])
     seed_g, seed_d, seed_x = (int(s) for s in gold["seeds"])
-    config = recipe_train_config(recipe, aux=aux, batch=B)
+    config = recipe_train_config("car" if recipe == "car_lin" else recipe, aux=aux, batch=B)
+    if recipe == "car_lin":
+        linearize(config)
     t = Trainer(config, torch.device("cuda:0"))
     gsd = synth_state_dict(config["generator_params"], seed=seed_g)
     dsd = synth_disc_state_dict(config["discriminator_params"], seed=seed_d)
@@ -48,24 +66,29 @@ def test_full_recipe_iteration_vs_reference_train_step(recipe, aux):
     t.steps = 2  # past generator_train_start_steps (1) and discriminator_train_start_steps (0), as in the fixture
     log = {k: float(v) for k, v in t.train_step(batch).items()}
     assert "libhificar.so" in open("/proc/self/maps").read()
-    # ---- every logged loss (seven with the mel loss, eight with the two STFT terms): 1e-4
+    # ---- every logged loss (seven with the mel loss, eight with the two STFT terms): 1e-4 (+ 3 x the reference's own fp32-vs-fp64 gap where the
+    # fixture stores it)
     keys = [k[len(aux) + 7:] for k in gold.files if k.startswith(f"{aux}::log::")]
     assert sorted(keys) == sorted(log) and len(keys) == (7 if aux == "mel" else 8)
     for k in keys:
         ref = float(gold[f"{aux}::log::{k}"])
-        assert abs(log[k] - ref) < 1e-4 * max(abs(ref), 1e-3), (k, log[k], ref)
+        slack = 3.0 * abs(ref - float(gold[f"{aux}::log64::{k}"])) if f"{aux}::log64::{k}" in gold.files else 0.0
+        assert abs(log[k] - ref) < 1e-4 * max(abs(ref), 1e-3) + slack, (k, log[k], ref)
     # ---- gradients left in .grad and parameters after the Adam step, for the fixture's tensors
     lr = config["generator_optimizer_params"]["lr"]
+    k_med, k_max = (8.0, 5.0) if recipe == "car_lin" else (20.0, 10.0)  # (measured: <= 3.2 / 1.9 and <= 12.2 / 3.8)
     for net, names, module, sd in (("generator", G_TENSORS, t.G, gsd), ("discriminator", D_TENSORS, t.D, dsd)):
         params = dict(module.named_parameters())
         for n in names:
             g, gr = sampled(gold, f"{aux}::{net}::grad::{n}", params[n].grad)
             err = np.abs(g - gr) / max(np.abs(gr).max(), 1e-30)
-            # LeakyReLU / |.| kinks: an activation within rounding distance of zero falls on either side in two correct fp32
-            # implementations, and ONE such flip in an upper layer moves every channel of the layers below by ~5e-4 of the tensor's scale
-            # (tests/dev/disc_wgrad_probe.py: the CPU's own fp32 run shows the same against float64; the fixture's ``grad_f32_vs_f64``
-            # entries are the reference's fp32-vs-fp64 deviation per tensor, 1e-8 .. 3e-4 median).  Tensors without a flip agree to 1e-5.
-            assert np.median(err) < 1e-3 and (err < 5e-3).mean() > 0.9 and err.max() < 5e-2, (net, n, float(np.median(err)), float(err.max()))
+            yard_med, yard_max = (float(v) for v in gold[f"{aux}::{net}::grad_f32_vs_f64::{n}"])
+            if (recipe, n) in CANCELLING:  # (see above) the absolute bounds of round 3 only
+                assert np.median(err) < 1e-3 and err.max() < 5e-3, (net, n, float(np.median(err)), float(err.max()))
+            else:
+                assert np.median(err) <= k_med * yard_med + 2e-6, (net, n, float(np.median(err)), yard_med)
+                assert err.max() <= k_max * yard_max + 5e-5, (net, n, float(err.max()), yard_max)
+            assert np.median(err) < 1e-3 and err.max() < 5e-3  # (and never worse than this in absolute terms: round 3 allowed 5e-2)
             p, pr = sampled(gold, f"{aux}::{net}::new::{n}", params[n])
             old = sampled(gold, f"{aux}::{net}::new::{n}", torch.from_numpy(sd[n]))[0]
             d, dr = p - old, pr - old
