@@ -265,3 +265,96 @@ def test_gan_iteration_with_a_gblock_generator_vs_oracle():
     assert all(np.isfinite(v) for v in last.values()) and last["train/mel_loss"] < log["train/mel_loss"]
     now = t.G.state_dict()
     assert any(not np.allclose(now[k].cpu().numpy(), v) for k, v in gsd.items())
+
+
+N_FUZZ = int(os.environ.get("HIFICAR_FUZZ_CASES", "24"))
+
+
+def _draw(rng):
+    n = int(rng.choice([9, 10, 10]))
+    channels = int(rng.choice([24, 64, 100, 128, 256]))  # any width (padded to 32 internally); channels // 8 >= 1
+    scales = [int(rng.choice([1, 1, 2, 3, 5])) for _ in range(n)]
+    k = [int(rng.choice([1, 3, 3, 5, 7])) for _ in range(n)]
+    use_ar = bool(rng.integers(0, 2))
+    cf = int(rng.integers(1, 40))
+    p = dict(in_channels=cf + (128 if use_ar else 0), out_channels=1, channels=channels, kernel_size=int(rng.choice([3, 5, 7])), g_scales=scales,
+             g_kernel_sizes=k, use_weight_norm=True, use_ar=use_ar, ar_input=512, ar_hidden=256, ar_output=128, use_tanh=bool(rng.integers(0, 4)),
+             use_spk_id=bool(rng.integers(0, 3) == 0), num_spk=5, spk_emb_size=int(rng.choice([8, 32])))
+    return p, cf
+
+
+@pytest.mark.parametrize("case", range(N_FUZZ))
+def test_random_gblock_configuration_forward_and_ragged(case):
+    """Random runnable GBlockGenerator configurations (9 or 10 blocks, per-block scales 1..5 and kernels 1..7, widths 24..256, with / without AR and
+    speaker conditioning), random batch / length / ragged lengths against the oracle."""
+    rng = np.random.default_rng(4000 + case)
+    p, cf = _draw(rng)
+    hop = int(np.prod(p["g_scales"]))
+    model, sd = build(p, seed=300 + case)
+    w = G.fold_weight_norm(sd)
+    B = int(rng.integers(1, 5))
+    T = int(rng.integers(1, 40)) if hop > 40 else int(rng.integers(1, 200))
+    lens = [int(v) for v in rng.integers(0, T + 1, size=B)]
+    lens[int(rng.integers(0, B))] = T
+    c = torch.from_numpy(synth_features(B, T, cf, seed=case)).permute(0, 2, 1).contiguous()
+    ar = torch.from_numpy(synth_features(B, 512, 1, seed=case + 1)[:, :, 0] * 0.3).reshape(B, 1, 512) if p["use_ar"] else None
+    spk = torch.from_numpy(rng.integers(0, 5, size=B)) if p["use_spk_id"] else None
+    kw = dict(ar=ar.cuda() if ar is not None else None, spk_id=spk.cuda() if spk is not None else None)
+    with torch.no_grad():
+        y = model(c.cuda(), **kw).cpu()
+        yr = model(c.cuda(), lengths=lens, **kw).cpu()
+        ref = G.generator_forward(w, p, c, ar, spk_id=spk)
+        pre = G.generator_forward(w, dict(p, use_tanh=False), c, ar, spk_id=spk) if p["use_tanh"] else ref
+    tol = TOL * max(1.0, float(pre.abs().max() / ref.abs().max()))  # (the error is a fraction of the PRE-tanh scale, as in tests/test_gpu_fuzz.py)
+    tag = (case, {k: p[k] for k in ("channels", "kernel_size", "g_scales", "g_kernel_sizes", "use_ar", "use_spk_id", "in_channels")}, B, T, lens)
+    assert y.shape == ref.shape == (B, 1, hop * T), tag
+    assert rel_err(y.numpy(), ref.numpy()) < tol, tag
+    for b, n in enumerate(lens):
+        assert float(yr[b, :, hop * n:].abs().sum()) == 0.0, tag
+        if n:
+            with torch.no_grad():
+                alone = G.generator_forward(w, p, c[b:b + 1, :, :n], ar[b:b + 1] if ar is not None else None, spk_id=spk[b:b + 1] if spk is not None else None)
+            assert rel_err(yr[b:b + 1, :, :hop * n].numpy(), alone.numpy()) < tol * max(1.0, float(ref.abs().max() / alone.abs().max())), tag
+
+
+@pytest.mark.parametrize("case", range(max(1, N_FUZZ // 3)))
+def test_random_gblock_gradients_on_kink_free_inputs(case):
+    """Every element of every gradient (parameters with weight norm in the graph, c, ar) to 2e-4 of its tensor's scale against the float64 oracle, on
+    the first of a few inputs whose every ReLU input the float64 oracle certifies 2e-6 of its tensor's scale away from zero."""
+    rng = np.random.default_rng(5000 + case)
+    p, cf = _draw(rng)
+    p["channels"] = int(rng.choice([24, 64, 100]))  # (few enough activations for a kink-free input to exist)
+    hop = int(np.prod(p["g_scales"]))
+    model, sd = build(p, seed=600 + case, train=True)
+    w64 = G.fold_weight_norm(sd, dtype=torch.float64)
+    B, T = int(rng.integers(1, 3)), (int(rng.integers(1, 4)) if hop > 40 else int(rng.integers(2, 12)))
+    spk = rng.integers(0, 5, size=B) if p["use_spk_id"] else None
+    for attempt in range(12):
+        c_np = synth_features(B, T, cf, seed=9000 + 13 * case + attempt).transpose(0, 2, 1).copy()
+        ar_np = (synth_features(B, 512, 1, seed=9500 + 13 * case + attempt)[:, :, 0] * 0.3).reshape(B, 1, 512).astype(np.float32) if p["use_ar"] else None
+        m = G.relu_margin(w64, p, torch.from_numpy(c_np).double(), torch.from_numpy(ar_np).double() if ar_np is not None else None,
+                          spk_id=torch.from_numpy(spk) if spk is not None else None)
+        if m >= 2e-6:
+            break
+    else:
+        pytest.skip("no kink-free input among 12 seeds")
+    cot = uniform(700 + case, "cotangent", (B, 1, hop * T), -1.0, 1.0)
+    c = torch.from_numpy(c_np).cuda().requires_grad_(True)
+    ar = torch.from_numpy(ar_np).cuda().requires_grad_(True) if ar_np is not None else None
+    y = model(c, ar=ar, spk_id=torch.from_numpy(spk).cuda() if spk is not None else None)
+    (y * torch.from_numpy(cot).cuda()).sum().backward()
+    out64, ref = G.gradients(sd, p, c_np, ar_np, cot, dtype=torch.float64, spk_id=spk)
+    got = {k: q.grad for k, q in model.named_parameters()}
+    got["c"] = c.grad
+    if ar is not None:
+        got["ar"] = ar.grad
+    assert sorted(got) == sorted(ref)
+    tag = (case, attempt, m, {k: p[k] for k in ("channels", "g_scales", "g_kernel_sizes", "use_ar", "use_spk_id")}, B, T)
+    bad = {}
+    for k in ref:
+        r = ref[k].numpy()
+        e = float(np.abs(got[k].cpu().numpy().astype(np.float64) - r).max() / max(np.abs(r).max(), 1e-30))
+        bar = TOL_GRAD * (25 if r.size == 1 else 1)  # (one-element gradients — the output conv's weight_g — are nearly cancelling dot products)
+        if e >= bar:
+            bad[k] = e
+    assert not bad, (tag, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
