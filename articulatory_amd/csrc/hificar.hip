@@ -1055,9 +1055,10 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     // lock step: 3*MI MFMAs of 32 cycles per 16-channel K slab) plus a fixed per-tile and per-item overhead.
     TileCfg tc = {1, 4, 1, 1, 1, 0};
     double best = 1e300;
-    // HIFICAR_NB: 0 = never use the register-blocked (NB = 2) wave tiles (default: measured slower), 1 = when the cost model prefers
-    // them, 2 = whenever one fits (A/B runs: tools/nb_ab.sh)
-    static const int nb_mode = getenv("HIFICAR_NB") ? atoi(getenv("HIFICAR_NB")) : 0;
+    // HIFICAR_NB: 0 = never use the register-blocked (NB = 2) wave tiles, 1 = when the cost model prefers them, 2 = whenever one fits, 3 = only the
+    // 128-accumulator shape forced (A/B runs: tools/nb_ab.sh; measured in profiles/r04_nb_register_blocking.txt)
+    static const int nb_env = getenv("HIFICAR_NB") ? atoi(getenv("HIFICAR_NB")) : -1;
+    const int nb_mode = nb_env >= 0 ? nb_env : (f32 ? 0 : 1);  // default: off in exact fp32 (-1.0 %), cost model in bf16x3 (+1.3 %)
     const int nsteps_min = [&] {
         int m = 1 << 30;
         for (int b = 0; b < nbr; ++b) m = std::min(m, layers[b]->ntaps * (L0.chunk16 / 16));

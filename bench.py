@@ -190,7 +190,7 @@ def roofline_block(stats, precision, wall_s, steps, traffic_table, strict=False)
     return blk
 
 
-def training_leg(steps=5):
+def training_leg(steps=5, traffic_table=None):
     """Secondary leg: BASELINE config 5's train step on this GPU — the whole GAN iteration of
     articulatory_amd/bin/train.py::Trainer on the shipped recipe e2w_hifigan_car.yaml (full generator + multi-scale / multi-period
     discriminators, mel + adversarial + feature-matching losses, both Adam updates) at the recipe's batch (64 windows of 2000 samples +
@@ -263,25 +263,52 @@ def training_leg(steps=5):
     breakdown = {"generator_forward_x2": 2 * g_fwd, "generator_backward": 2 * g_fwd, "discriminator_forward_x3": 3 * d_fwd,
                  "discriminator_backward_data_only_x1": d_fwd, "discriminator_backward_full_x2": 4 * d_fwd}
     flops = sum(breakdown.values())
-    t.G.profile_begin()
-    t.D.profile_begin()
+    # per-kernel table from a SERIAL pass: the timed iterations above overlap the eight sub-discriminators (and the auxiliary loss, and the real
+    # pass's backward) on side streams, where an event-bracketed launch's duration is an occupancy artefact; a second Trainer with every engine on
+    # the caller's stream (HIFICAR_DISC_STREAMS=0, no side-stream overlap in the step) gives launch times that ARE a fraction of something
+    del t
+    os.environ["HIFICAR_DISC_STREAMS"] = "0"  # (read when the discriminators' native handle is created: at the first forward)
+    try:
+        ts, _ = build(B, 1234, 4321)
+        ts.config["overlap_aux_loss"] = ts.config["early_real_gradient"] = False
+
+        def serial_iteration():
+            ts.steps = 2
+            return ts.train_step(batch)
+
+        for _ in range(2):
+            serial_iteration()
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("HIFICAR_DISC_STREAMS", None)
+    ts.G.profile_begin()
+    ts.D.profile_begin()
+    t1 = time.perf_counter()
     for _ in range(steps):
-        iteration()
+        serial_iteration()
+    torch.cuda.synchronize()
+    serial_dt = (time.perf_counter() - t1) / steps
     stats = {}
-    for s in t.G.profile_end() + t.D.profile_end():
-        a = stats.setdefault(s["name"], dict(name=s["name"], launches=0, total_ms=0.0, flops=0.0))
+    for s in ts.G.profile_end() + ts.D.profile_end():
+        a = stats.setdefault(s["name"], dict(name=s["name"], launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
         a["launches"] += s["launches"]
         a["total_ms"] += s["total_ms"]
         a["flops"] += s["flops"]
+        a["bytes"] += s["bytes"]
     stats = sorted(stats.values(), key=lambda s: -s["total_ms"])
     total_ms = sum(s["total_ms"] for s in stats)
     dom = stats[0]
     tf = flops / dt / 1e12
+    table = (traffic_table or {}).get("train_gan", {})
 
     def row(s):
+        alg = s["bytes"] / s["launches"]
+        tr = table.get(s["name"])
+        tfk = s["flops"] / (s["total_ms"] * 1e-3) / 1e12
         return {"name": s["name"], "launches_per_iteration": round(s["launches"] / steps, 1), "avg_launch_us": round(s["total_ms"] * 1e3 / s["launches"], 2),
-                "ms_per_iteration": round(s["total_ms"] / steps, 3), "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2),
-                "kernel_time_share": round(s["total_ms"] / total_ms, 4)}
+                "ms_per_iteration": round(s["total_ms"] / steps, 3), "tflops": round(tfk, 2), "frac_of_fp32_mfma_peak": round(tfk / PEAK_TFLOPS["f32"], 4),
+                "kernel_time_share": round(s["total_ms"] / total_ms, 4), "algorithmic_bytes": round(alg), "traffic": tr,
+                "traffic_over_algorithmic": round(tr / alg, 3) if (tr and alg > 0) else None}
 
     return {"note": "BASELINE config 5's recipe on ONE GPU, exact fp32 (the reference has no bf16 path); losses gated against the reference's "
                     "own _train_step fixture before timing",
@@ -294,7 +321,13 @@ def training_leg(steps=5):
             "gan_training_samples_per_s": round(B * cfg["batch_max_steps"] / dt, 1),
             "flops_per_iteration": flops, "flops_breakdown": breakdown,
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["f32"], 4),
-                         "traffic": None, "dominant_kernel": row(dom)},
+                         "traffic": table.get(dom["name"]),
+                         "traffic_source": "profiles/hbm_traffic.json[train_gan] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tools/gan_bench.py with "
+                                           "HIFICAR_DISC_STREAMS=0, average per launch of the kernel name)" if table else None,
+                         "dominant_kernel": row(dom),
+                         "note": "achieved / frac: the whole iteration (overlapped, as timed); dominant_kernel and `kernels`: a serial pass "
+                                 "(every engine on one stream), so each row's tflops is that kernel's own rate"},
+            "serial_iteration_ms": round(serial_dt * 1e3, 2),
             "kernel_ms_per_iteration_sum": round(total_ms / steps, 2),
             "kernels": [row(s) for s in stats[:14]],
             "first_losses": {k.split("/")[1]: float(v) for k, v in sorted(log.items())}}
@@ -508,7 +541,7 @@ def main(argv=None, synth_factory=None):
         out["fast_bf16x3"] = leg
 
     if solo and args.precision == "f32" and not args.no_training:
-        out["training"] = training_leg()
+        out["training"] = training_leg(traffic_table=traffic_table)
 
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, sd, args.chunk_frames, seed=20260929)

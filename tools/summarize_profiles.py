@@ -122,6 +122,30 @@ for what, cmd in (("train", "python tools/train_bench.py --steps 5"), ("gan", "p
                 gui = c.get("GRBM_GUI_ACTIVE", 0.0)
                 util = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8 * 1024) if gui else 0.0
                 f.write(f"\"{k}\",{dur[k][0]},{dur[k][1] / dur[k][0] / 1e3:.2f},{gui:.0f},{c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.0f},{util:.4f}\n")
+    if os.path.isdir(base + "_FETCH_SIZE"):  # round 4: HBM bytes per launch of the training kernels (serial GAN iteration, 3 warm-up + 1 timed)
+        fe, _ = counters(base + "_FETCH_SIZE")
+        wr, _ = counters(base + "_WRITE_SIZE")
+        train = {}
+        by_base = collections.defaultdict(lambda: [0, 0.0])
+        with open(f"profiles/{tag}_{what}_pmc_hbm.csv", "w") as f:
+            f.write(f"# HIFICAR_DISC_STREAMS=0 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- {cmd.replace('--steps 5', '--steps 1')}\n"
+                    "# counter units KiB; gfx950 correction (FETCH_SIZE reports 1/2 of wide coalesced reads) in the last column = (2*FETCH + WRITE)*1024; "
+                    "averages over ALL launches of a kernel name in the run (many different layers share a name)\n")
+            f.write("Kernel,Launches,FETCH_SIZE_KiB_per_launch_raw,WRITE_SIZE_KiB_per_launch,HBM_bytes_per_launch_corrected\n")
+            for k in sorted(fe, key=lambda k: -fe[k]["FETCH_SIZE"][1]):
+                if "hificar" not in k:
+                    continue
+                n, v = fe[k]["FETCH_SIZE"]
+                n2, v2 = wr.get(k, {}).get("WRITE_SIZE", [1, 0.0])
+                b = (2 * v / n + v2 / max(n2, 1)) * 1024
+                f.write(f"\"{k}\",{n},{v / n:.1f},{v2 / max(n2, 1):.1f},{b:.0f}\n")
+                train[short(k)] = round(b)
+                a = by_base[short(k).split("<")[0]]  # the library's event profile names the weight-gradient kernels without template arguments
+                a[0] += n
+                a[1] += b * n
+        for k, (n, tot) in by_base.items():
+            train.setdefault(k, round(tot / n))
+        allt["train_" + what] = train
     txt = f"{base}_bench.txt"
     if os.path.exists(txt):
         lines = [ln for ln in open(txt).read().splitlines() if "ms" in ln and ("step" in ln or "iteration" in ln)]
