@@ -496,7 +496,7 @@ def main(argv=None, synth_factory=None):
     if rank == 0 and not args.no_roofline:
         with torch.no_grad():
             stats, te = event_pass(feats, args.steps)
-        out["roofline"] = roofline_block(stats, args.precision, te, args.steps, traffic_table, strict=True)
+        out["roofline"] = roofline_block(stats, args.precision, te, args.steps, traffic_table, strict=(world == 1))  # (never strand the other ranks at the barrier)
     if use_dist:
         dist.barrier()
 
