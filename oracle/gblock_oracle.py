@@ -70,6 +70,8 @@ def gblock(w, i, x, scale, k, taps=None):
     if taps is not None:
         taps[f"resamples.{i}.mid"] = x
     h = F.conv1d(F.relu(x), w[n3 + ".weight"], w[n3 + ".bias"], dilation=9, padding=_pad(k, 9))
+    if taps is not None:
+        taps[f"resamples.{i}.conv2a"] = h
     h = F.conv1d(F.relu(h), w[n4 + ".weight"], w[n4 + ".bias"], dilation=27, padding=_pad(k, 27))
     return x + h
 
@@ -160,7 +162,8 @@ def relu_margin(w, params, c, ar=None, spk_id=None):
     p = _cfg(params)
     worst = 1.0
     for i in range(len(p["g_scales"])):
-        for name in (f"resamples.{i - 1}" if i else "input_conv", f"resamples.{i}.conv1a", f"resamples.{i}.mid"):
+        # the four ReLU inputs of a GBlock: its input, conv1's first conv, conv1 + res1, conv2's first conv
+        for name in (f"resamples.{i - 1}" if i else "input_conv", f"resamples.{i}.conv1a", f"resamples.{i}.mid", f"resamples.{i}.conv2a"):
             t = taps[name]
             worst = min(worst, float(t.abs().min() / t.abs().max()))
     t = taps[f"resamples.{len(p['g_scales']) - 1}"]
