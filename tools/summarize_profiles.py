@@ -145,6 +145,11 @@ for what, cmd in (("train", "python tools/train_bench.py --steps 5"), ("gan", "p
                 a[1] += b * n
         for k, (n, tot) in by_base.items():
             train.setdefault(k, round(tot / n))
+            import re
+
+            alias = re.sub(r"\d+_kernel$", "_kernel", k)  # (the library's event profile calls col2im_mask4_kernel / im2col4_kernel by their family name)
+            if alias != k and alias not in by_base:
+                train.setdefault(alias, round(tot / n))
         allt["train_" + what] = train
     txt = f"{base}_bench.txt"
     if os.path.exists(txt):
