@@ -140,16 +140,17 @@ for what, cmd in (("train", "python tools/train_bench.py --steps 5"), ("gan", "p
                 b = (2 * v / n + v2 / max(n2, 1)) * 1024
                 f.write(f"\"{k}\",{n},{v / n:.1f},{v2 / max(n2, 1):.1f},{b:.0f}\n")
                 train[short(k)] = round(b)
-                a = by_base[short(k).split("<")[0]]  # the library's event profile names the weight-gradient kernels without template arguments
-                a[0] += n
-                a[1] += b * n
-        for k, (n, tot) in by_base.items():
-            train.setdefault(k, round(tot / n))
-            import re
+                import re
 
-            alias = re.sub(r"\d+_kernel$", "_kernel", k)  # (the library's event profile calls col2im_mask4_kernel / im2col4_kernel by their family name)
-            if alias != k and alias not in by_base:
-                train.setdefault(alias, round(tot / n))
+                # the library's event profile names kernels by FAMILY: no template arguments, and col2im_mask4_kernel / im2col4_kernel under
+                # their scalar siblings' names — launch-weighted averages over the family
+                for fam in {short(k).split("<")[0], re.sub(r"\d+_kernel$", "_kernel", short(k).split("<")[0])}:
+                    a = by_base[fam]
+                    a[0] += n
+                    a[1] += b * n
+        for k, (n, tot) in by_base.items():
+            if "<" not in k:
+                train[k] = round(tot / n)
         allt["train_" + what] = train
     txt = f"{base}_bench.txt"
     if os.path.exists(txt):
