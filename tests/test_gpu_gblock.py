@@ -358,3 +358,32 @@ def test_random_gblock_gradients_on_kink_free_inputs(case):
         if e >= bar:
             bad[k] = e
     assert not bad, (tag, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
+
+
+def test_packed_ar_loop_and_taps_at_a_length_that_is_not_a_whole_bucket():
+    """The continuously batched AR loop (hificar_ar_loop_packed: step table, slots) and the debug taps at a frame count that is not a multiple of
+    the 32-frame launch bucket, on a GBlockGenerator handle."""
+    p = _params(np.load(os.path.join(GOLDEN, "gold_gblock_small.npz")))
+    model, sd = build(p)
+    w = G.fold_weight_norm(sd)
+    lens = [61, 50, 26, 25, 3]
+    x = torch.from_numpy(synth_features(5, 61, 13, seed=951))
+    with torch.no_grad():
+        yp = model.ar_synthesis_packed(x.permute(0, 2, 1).cuda(), 25, lens, batch=2).cpu()
+        yr = model.ar_synthesis(x.permute(0, 2, 1).cuda(), 25, lengths=lens).cpu()
+    assert same_across_shapes(yp, yr)
+    for b, n in enumerate(lens):
+        with torch.no_grad():
+            ref = G.ar_loop(w, p, x[b, :n], 2000, 80)
+        assert rel_err(yp[b, :80 * n].numpy(), ref.numpy()) < 5e-5, b
+        assert float(yp[b, 80 * n:].abs().sum()) == 0.0
+    c = torch.from_numpy(synth_features(2, 40, 13, seed=952)).permute(0, 2, 1).contiguous()
+    ar = torch.zeros(2, 1, 512)
+    taps_ref = {}
+    with torch.no_grad():
+        y, taps = model.debug_taps(["input_conv", "resamples.0", "resamples.4.mid", "resamples.9"], c.cuda(), ar=ar.cuda())
+        ref = G.generator_forward(w, p, c, ar, taps=taps_ref)
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < TOL
+    for name in ("input_conv", "resamples.0", "resamples.4.mid", "resamples.9"):
+        assert taps[name].shape == taps_ref[name].shape, name
+        assert rel_err(taps[name].cpu().numpy(), taps_ref[name].numpy()) < TOL, name
