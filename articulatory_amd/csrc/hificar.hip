@@ -639,9 +639,13 @@ static int engine_setup(hificar_handle* h) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<1, 4, 1, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32do_kernel<4, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32do_kernel<4, 4, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32do_kernel<1, 4, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define HIFICAR_SET_ATTR(mi, wm, wn, nc)         \
     HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>())); \
-    HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>()));
+    HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>())); \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32do_kernel<mi, wm, wn, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIFICAR_FOR_ALL_TILES(HIFICAR_SET_ATTR)
 #undef HIFICAR_SET_ATTR
 #define HIFICAR_SET_ATTR_NB(mi, wm, wn, nc)                                                                                                \
@@ -1003,6 +1007,12 @@ static const TileCfg kTileCfgs[16] = {{4, 1, 4, 1, 2, 16}, {4, 1, 4, 1, 1, 0}, {
                                       {1, 1, 4, 1, 1, 0}, {1, 2, 2, 1, 1, 0}, {1, 4, 1, 1, 1, 0}, {4, 1, 1, 4, 1, 0}, {2, 1, 1, 4, 1, 0}, {1, 1, 1, 4, 1, 0}};
 
 template <int MI, int WM, int WN, int NC16>
+static hipError_t launch_conv_do_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((conv_f32do_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
+    return hipGetLastError();
+}
+
+template <int MI, int WM, int WN, int NC16>
 static hipError_t launch_conv_nb_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
     if (f32) hipLaunchKernelGGL((conv_f32nb_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
     else hipLaunchKernelGGL((conv_bf16x3nb_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
@@ -1165,7 +1175,10 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
                         (double)Lb.cin * Lb.cout * Lb.K);
     }
     const size_t buf_bytes = round_up_sz((size_t)(TM + halo_all) * RB, 1024);
-    const size_t lds = 2 * buf_bytes + out_buf_bytes(tc);
+    // HIFICAR_DOUT=1 (dev experiment): exact-fp32 forward launches write their tiles straight from the accumulators (conv_f32do_kernel)
+    static const bool dout_env = getenv("HIFICAR_DOUT") && atoi(getenv("HIFICAR_DOUT")) != 0;
+    const bool dout = dout_env && f32 && tc.KS == 1 && tc.NB == 1;
+    const size_t lds = 2 * buf_bytes + (dout ? 0 : out_buf_bytes(tc));
     mp.n_branches = nbr;
     mp.nseq_tiles = nseq * ((rows + TM - 1) / TM);
     mp.ngroups = (L0.n_blocks32 + tc.WN * tc.NB - 1) / (tc.WN * tc.NB);
@@ -1199,7 +1212,8 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         if (rc2 != HIFICAR_OK) return rc2;
     }
     char kname[96];
-    if (tc.KS == 4) snprintf(kname, sizeof(kname), "%s<%d,%d>", f32 ? "conv_sk_f32_kernel" : "conv_sk_bf16x3_kernel", tc.MI, nc16);
+    if (dout) snprintf(kname, sizeof(kname), "conv_f32do_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, nc16);
+    else if (tc.KS == 4) snprintf(kname, sizeof(kname), "%s<%d,%d>", f32 ? "conv_sk_f32_kernel" : "conv_sk_bf16x3_kernel", tc.MI, nc16);
     else if (tc.NB == 2) snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_f32nb_kernel" : "conv_bf16x3nb_kernel", tc.MI, tc.WM, tc.WN, nc16);
     else snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_f32_kernel" : "conv_bf16x3_kernel", tc.MI, tc.WM, tc.WN, nc16);
     if (h->profile_detail) {  // per-layer rows in the profile (tools/layer_profile.py)
@@ -1208,8 +1222,9 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     }
     ProfScope prof(h, stream, kname, flops, bytes);
     hipError_t e = hipErrorInvalidValue;
-#define HIFICAR_DISPATCH(mi, wm, wn, nc) \
-    if (tc.KS == 1 && tc.NB == 1 && tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_t<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
+#define HIFICAR_DISPATCH(mi, wm, wn, nc)                                                                                        \
+    if (tc.KS == 1 && tc.NB == 1 && tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc)                                   \
+        e = dout ? launch_conv_do_t<mi, wm, wn, nc>(mp, grid, lds, stream) : launch_conv_t<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
     HIFICAR_FOR_ALL_TILES(HIFICAR_DISPATCH)
 #undef HIFICAR_DISPATCH
 #define HIFICAR_DISPATCH_NB(mi, wm, wn, nc) \
@@ -1331,13 +1346,20 @@ static int launch_pair(hificar_handle* h, const ConvLayer* const* l1, const Conv
         if (rc2 != HIFICAR_OK) return rc2;
     }
     char kname[96];
-    snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_pair_f32_kernel" : "conv_pair_bf16x3_kernel", MI, WM, 4 / WM, C / 16);
+    static const bool dout_env = getenv("HIFICAR_DOUT") && atoi(getenv("HIFICAR_DOUT")) != 0;  // (dev experiment: direct output, see launch_conv)
+    const bool dout = f32 && dout_env;
+    snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", dout ? "conv_pair_f32do_kernel" : f32 ? "conv_pair_f32_kernel" : "conv_pair_bf16x3_kernel", MI, WM, 4 / WM,
+             C / 16);
     if (h->profile_detail) {
         const size_t n = strlen(kname);
         snprintf(kname + n, sizeof(kname) - n, "|%s x%d", l1[0]->name.c_str(), nbr);
     }
     ProfScope prof(h, stream, kname, flops, bytes);
-    if (f32) {
+    if (dout) {
+        if (C == 64) hipLaunchKernelGGL((conv_pair_f32do_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
+        else if (small) hipLaunchKernelGGL((conv_pair_f32do_kernel<1, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
+        else hipLaunchKernelGGL((conv_pair_f32do_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
+    } else if (f32) {
         if (C == 64) hipLaunchKernelGGL((conv_pair_f32_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
         else if (small) hipLaunchKernelGGL((conv_pair_f32_kernel<1, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
         else hipLaunchKernelGGL((conv_pair_f32_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);

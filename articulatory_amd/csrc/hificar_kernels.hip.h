@@ -217,8 +217,14 @@ __device__ __forceinline__ void pin_slab_step() {
 // activation fragment read feeds NB times the MFMAs and one weight fragment MI of them: 2 (MI + NB) 16-byte loads per 8 MI NB MFMAs per K slab
 // (fp32) — MI = 2, NB = 2: 0.25 loads per MFMA against 0.31 at MI = 4, NB = 1 on the same 64 accumulator registers and the same LDS budget
 // (tile = WM*MI*32 rows x WN*NB*32 channels).  Every 16-byte load next to fp32 MFMAs costs ~22 cycles of matrix-pipe time.
-template <int MI, int WM, int WN, int NC16, bool F32, int KS = 1, int NB = 1>
+//
+// DOUT = true (dev experiment of round 4, exact fp32 forward launches): the MFMA waves write a finished tile straight from their accumulators
+// (bias, residual, LeakyReLU, 16-byte stores: lane (li, g) owns row li and four adjacent channels per register quad) — no LDS out-buffer, no
+// output pass in the loader waves, which then only stage.  Trades the loaders' share of the SIMDs' issue slots during the K loop (and the waits
+// at the out-buffer hand-over barriers) for an epilogue the matrix pipe idles through.
+template <int MI, int WM, int WN, int NC16, bool F32, int KS = 1, int NB = 1, bool DOUT = false>
 __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
+    static_assert(!DOUT || (F32 && KS == 1 && NB == 1), "direct output: exact fp32, dense form, one channel block per wave");
     static_assert(NB == 1 || (NB == 2 && KS == 1), "one or two channel blocks per MFMA wave");
     static_assert(KS == 1 || (KS == 4 && WM == 1 && WN == 1), "split-K: four waves share one 32-channel block");
     static_assert(KS == 4 || WM * WN == 4 || WM * WN == 8, "4 or 8 MFMA waves per workgroup");
@@ -563,7 +569,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                     dma_item(T, c, j);
                     // the tile that finished with item j-2 published its accumulators at barrier j-1 (nchunks >= 2, so the
                     // MFMA waves cannot overwrite the out-buffer before barrier j+1)
-                    if (c == 1 && have_prev) write_out(Tprev, ltid, 256);
+                    if constexpr (!DOUT) {
+                        if (c == 1 && have_prev) write_out(Tprev, ltid, 256);
+                    }
                     HIFICAR_STAMP(1 + 2 * j);
                     __syncthreads();  // item j landed (hipcc drains vmcnt before the barrier); MFMA waves are done with item j-1's buffer
                     HIFICAR_STAMP(2 + 2 * j);
@@ -573,7 +581,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             }
         }
         __syncthreads();  // the last tile's accumulators are in the out-buffer
-        if (have_prev) write_out(Tprev, tid, NTHR);  // all waves share the final output pass (nothing left to hide it behind)
+        if constexpr (!DOUT) {
+            if (have_prev) write_out(Tprev, tid, NTHR);  // all waves share the final output pass (nothing left to hide it behind)
+        }
         HIFICAR_STAMP(63);
         return;
     }
@@ -898,7 +908,63 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         HIFICAR_STAMP(3 * j);
         primed = active;  // an active tile ends with the ring holding the next tile's head
         if constexpr (kSplitPass) __syncthreads();  // X: the loader waves have finished the previous tile's output pass
-        if (active) {
+        if constexpr (DOUT) {
+            if (active) {
+                const int vc0 = nb * 32 + 4 * g;  // this lane's first virtual channel
+                const size_t seq_base = (size_t)T.seq * p.L;
+                const int rows_valid = min(TM, seq_rows(p, T.seq) - T.t0);
+                const float* const bias_z = p.bias + (size_t)T.z * mp.zs_b;
+                float* const y_z = p.y ? p.y + (size_t)T.z * mp.zs_y : nullptr;
+                float* const ys_z = p.ys ? reinterpret_cast<float*>(p.ys) + (size_t)T.z * mp.zs_y : nullptr;
+                f32x4 bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(bias_z + vc0 + 8 * q);
+                const float slope_out = p.slope_out;
+                // residual / mask rows are requested two row blocks at a time before the first is used (the K loop's operand registers are dead
+                // here; all MI blocks at once would need 128 registers with a mask and spills)
+                constexpr int G2 = MI >= 2 ? 2 : 1;
+#pragma unroll
+                for (int m0 = 0; m0 < MI; m0 += G2) {
+                    f32x4 rs[G2][4], mk[G2][4];
+#pragma unroll
+                    for (int mm = 0; mm < G2; ++mm) {
+                        const int row_l = wave_row0 + (m0 + mm) * 32 + li;
+                        const size_t off = (seq_base + T.t0 + min(row_l, max(rows_valid - 1, 0))) * p.cout_total + vc0;  // (clamped: rows past the end are not stored)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            rs[mm][q] = p.res ? *reinterpret_cast<const f32x4*>(p.res + off + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (p.mask_src) mk[mm][q] = *reinterpret_cast<const f32x4*>(p.mask_src + off + 8 * q);
+                        }
+                    }
+#pragma unroll
+                    for (int mm = 0; mm < G2; ++mm) {
+                        const int mi = m0 + mm;
+                        const int row_l = wave_row0 + mi * 32 + li;
+                        if (row_l < rows_valid) {
+                            const size_t off = (seq_base + T.t0 + row_l) * p.cout_total + vc0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                f32x4 o;
+                                if (p.mask_src) {  // backward: act'(x) * dgrad + skip gradient (as write_out)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[e] = (acc[0][mi][4 * q + e] + bv[q][e]) * (mk[mm][q][e] > 0.f ? 1.f : p.mask_slope) + rs[mm][q][e];
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[e] = (acc[0][mi][4 * q + e] + bv[q][e]) + rs[mm][q][e];
+                                }
+                                if (y_z) *reinterpret_cast<f32x4*>(y_z + off + 8 * q) = o;
+                                if (ys_z) {
+                                    f32x4 a;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) a[e] = fmaxf(o[e], o[e] * slope_out);
+                                    *reinterpret_cast<f32x4*>(ys_z + off + 8 * q) = a;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (active) {
             // hand the raw accumulators to the loader waves through the LDS out-buffer O[time row][channel]:
             // lane (li, g) holds time column li and channels 8q + 4g + {0..3} in acc[mi][4q..4q+3]
             float* O = reinterpret_cast<float*>(smem_b + 2 * buf_bytes);
@@ -917,8 +983,16 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     }
     __syncthreads();  // matches the loader waves' final barrier
     HIFICAR_STAMP(62);
-    if (last >= 0) write_out(decode(tile_of(last)), tid, NTHR);
+    if constexpr (!DOUT) {
+        if (last >= 0) write_out(decode(tile_of(last)), tid, NTHR);
+    }
     HIFICAR_STAMP(63);
+}
+
+// direct-output form (DOUT, dev experiment): exact fp32 forward launches
+template <int MI, int WM, int WN, int NC16>
+__global__ __launch_bounds__((WM * WN + 4) * 64) void conv_f32do_kernel(const MultiConvParams mp) {
+    conv_ws_body<MI, WM, WN, NC16, true, 1, 1, true>(mp);
 }
 
 template <int MI, int WM, int WN, int NC16>
@@ -986,8 +1060,12 @@ struct PairParams {
     unsigned long long* trace;
 };
 
-template <int MI, int WM, int WN, int NC16, bool F32>
+// DOUT (exact fp32): conv2's result leaves straight from the accumulators (bias, residual, LeakyReLU, 16-byte stores) — no out-buffer aliasing the
+// intermediate, so barriers F and C and the loader waves' output pass disappear: A (input landed) | conv1 | intermediate -> TS | B | conv2 | store.
+// (The next tile's intermediate overwrites TS only behind the next barrier A, which every wave reaches after its conv2.)
+template <int MI, int WM, int WN, int NC16, bool F32, bool DOUT = false>
 __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
+    static_assert(!DOUT || F32, "direct output: exact fp32");
     static_assert(WM * WN == 4, "4 MFMA waves per workgroup");
     static_assert(NC16 == 2 || NC16 == 4, "C = 32 or 64");
     static_assert(WN * 32 == NC16 * 16, "the workgroup covers all C channels");
@@ -1211,17 +1289,21 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
             HIFICAR_STAMP(4 * it);
             __syncthreads();                 // A: input of tile `it` landed (hipcc drains vmcnt first)
             HIFICAR_STAMP(4 * it + 1);
-            if (it != first) write_out(Tprev, ltid, 256);  // hidden behind conv1 of this tile
-            HIFICAR_STAMP(4 * it + 2);
-            __syncthreads();                 // F: shared region free
+            if constexpr (!DOUT) {
+                if (it != first) write_out(Tprev, ltid, 256);  // hidden behind conv1 of this tile
+                HIFICAR_STAMP(4 * it + 2);
+                __syncthreads();             // F: shared region free
+            }
             __syncthreads();                 // B: TS complete, input buffer free
             HIFICAR_STAMP(4 * it + 3);
             if (itn < my_rounds) stage_in(decode(tile_of(itn)));  // hidden behind conv2
-            __syncthreads();                 // C: conv2 done reading TS
+            if constexpr (!DOUT) __syncthreads();  // C: conv2 done reading TS
             Tprev = T;
         }
         __syncthreads();                     // Z: the last tile's accumulators are in the out-buffer
-        if (first < my_rounds) write_out(Tprev, tid, 512);  // all eight waves share the final output pass
+        if constexpr (!DOUT) {
+            if (first < my_rounds) write_out(Tprev, tid, 512);  // all eight waves share the final output pass
+        }
         return;
     }
 
@@ -1377,7 +1459,7 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
         run_conv(0, wave_row0 + li + (p1.tap_off0[0] - p1.off_min), p1.tap_step, p1.ntaps, stream2(T), k2);
         if constexpr (F32) act_on = false;
         HIFICAR_STAMP(6 * it + 2);
-        __syncthreads();  // F: the loaders are done with the previous tile's out-buffer (same LDS region as TS)
+        if constexpr (!DOUT) __syncthreads();  // F: the loaders are done with the previous tile's out-buffer (same LDS region as TS)
         {   // bias + LeakyReLU + split -> TS (zero outside the sequence: conv2's padding)
             const float slope = mp.slope_mid;
             f32x4 bias4[4];
@@ -1423,6 +1505,48 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
         // ---- conv2 over TS: output row r2 reads TS rows r2 .. r2 + k2 - 1 ----
         run_conv(ts_off, wave_row0 + li, 1, k2, stream1(Tn), mp.p1[Tn.b].ntaps);
         HIFICAR_STAMP(6 * it + 5);
+        if constexpr (DOUT) {
+            const size_t seq_base = (size_t)T.seq * p2.L;
+            const int rows_valid = min(T.tmo, seq_rows(p2, T.seq) - T.t0);
+            const int vc0 = wn * 32 + 4 * g;
+            f32x4 bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(p2.bias + vc0 + 8 * q);
+            const float slope_out = p2.slope_out;
+            constexpr int G2 = MI >= 2 ? 2 : 1;
+#pragma unroll
+            for (int m0 = 0; m0 < MI; m0 += G2) {
+                f32x4 rs[G2][4];
+#pragma unroll
+                for (int mm = 0; mm < G2; ++mm) {
+                    const int row_l = wave_row0 + (m0 + mm) * 32 + li;
+                    const size_t off = (seq_base + T.t0 + min(row_l, max(rows_valid - 1, 0))) * TN + vc0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rs[mm][q] = *reinterpret_cast<const f32x4*>(p2.res + off + 8 * q);
+                }
+#pragma unroll
+                for (int mm = 0; mm < G2; ++mm) {
+                    const int mi = m0 + mm;
+                    const int row_l = wave_row0 + mi * 32 + li;
+                    if (row_l < rows_valid) {
+                        const size_t off = (seq_base + T.t0 + row_l) * TN + vc0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (acc[mi][4 * q + e] + bv[q][e]) + rs[mm][q][e];
+                            *reinterpret_cast<f32x4*>(p2.y + off + 8 * q) = o;
+                            if (p2.ys) {
+                                f32x4 a;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a[e] = fmaxf(o[e], o[e] * slope_out);
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p2.ys) + off + 8 * q) = a;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
         __syncthreads();  // C: every wave is done reading TS; its region becomes the out-buffer
         {
             float* O = reinterpret_cast<float*>(smem_b + o_off);
@@ -1436,9 +1560,17 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
                     *reinterpret_cast<f32x4*>(&O[(wave_row0 + mi * 32 + li) * OP + wn * 32 + 8 * q + 4 * g]) = v;
                 }
         }
+        }
     }
     __syncthreads();  // Z
-    if (last >= 0) write_out(decode(tile_of(last)), tid, 512);
+    if constexpr (!DOUT) {
+        if (last >= 0) write_out(decode(tile_of(last)), tid, 512);
+    }
+}
+
+template <int MI, int WM, int WN, int NC16>
+__global__ __launch_bounds__(512) void conv_pair_f32do_kernel(const PairParams mp) {
+    conv_pair_body<MI, WM, WN, NC16, true, true>(mp);
 }
 
 template <int MI, int WM, int WN, int NC16>
