@@ -639,9 +639,7 @@ static int engine_setup(hificar_handle* h) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<1, 4, 1, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32do_kernel<4, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32do_kernel<4, 4, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32do_kernel<1, 4, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+
 #define HIFICAR_SET_ATTR(mi, wm, wn, nc)         \
     HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>())); \
     HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>())); \
@@ -1065,6 +1063,10 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     // lock step: 3*MI MFMAs of 32 cycles per 16-channel K slab) plus a fixed per-tile and per-item overhead.
     TileCfg tc = {1, 4, 1, 1, 1, 0};
     double best = 1e300;
+    // Direct output (round 4, conv_f32do_kernel): the dense exact-fp32 launches store their tiles straight from the MFMA waves' accumulators — no LDS
+    // out-buffer (its bytes are free for taller tiles / wider halos below), no output pass in the loader waves.  +1.5 % end to end; HIFICAR_DOUT=0
+    // restores the out-buffer form (A/B runs).
+    static const bool dout_on = !getenv("HIFICAR_DOUT") || atoi(getenv("HIFICAR_DOUT")) != 0;
     // HIFICAR_NB: 0 = never use the register-blocked (NB = 2) wave tiles, 1 = when the cost model prefers them, 2 = whenever one fits, 3 = only the
     // 128-accumulator shape forced (A/B runs: tools/nb_ab.sh; measured in profiles/r04_nb_register_blocking.txt)
     static const int nb_env = getenv("HIFICAR_NB") ? atoi(getenv("HIFICAR_NB")) : -1;
@@ -1092,7 +1094,8 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         } else if (t.NB == 2 && L0.chunk16 == 16) {
             continue;  // (not instantiated)
         }
-        if (2 * round_up_sz((size_t)(TM + halo_all) * RB, 1024) + out_buf_bytes(t) > 160 * 1024) continue;
+        const size_t obuf = (dout_on && f32 && t.KS == 1 && t.NB == 1) ? 0 : out_buf_bytes(t);
+        if (2 * round_up_sz((size_t)(TM + halo_all) * RB, 1024) + obuf > 160 * 1024) continue;
         if (t.NB == 2) {  // a wave's two channel blocks share the activation fragments: same phase of a polyphase (transposed) conv
             bool ok = nb_mode != 0 && L0.n_blocks32 >= 2;
             for (int b = 0; b < nbr; ++b) ok = ok && (layers[b]->n_phase == 1 || layers[b]->nb32_per_phase % 2 == 0);
@@ -1175,9 +1178,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
                         (double)Lb.cin * Lb.cout * Lb.K);
     }
     const size_t buf_bytes = round_up_sz((size_t)(TM + halo_all) * RB, 1024);
-    // HIFICAR_DOUT=1 (dev experiment): exact-fp32 forward launches write their tiles straight from the accumulators (conv_f32do_kernel)
-    static const bool dout_env = getenv("HIFICAR_DOUT") && atoi(getenv("HIFICAR_DOUT")) != 0;
-    const bool dout = dout_env && f32 && tc.KS == 1 && tc.NB == 1;
+    const bool dout = dout_on && f32 && tc.KS == 1 && tc.NB == 1;
     const size_t lds = 2 * buf_bytes + (dout ? 0 : out_buf_bytes(tc));
     mp.n_branches = nbr;
     mp.nseq_tiles = nseq * ((rows + TM - 1) / TM);
@@ -1346,20 +1347,13 @@ static int launch_pair(hificar_handle* h, const ConvLayer* const* l1, const Conv
         if (rc2 != HIFICAR_OK) return rc2;
     }
     char kname[96];
-    static const bool dout_env = getenv("HIFICAR_DOUT") && atoi(getenv("HIFICAR_DOUT")) != 0;  // (dev experiment: direct output, see launch_conv)
-    const bool dout = f32 && dout_env;
-    snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", dout ? "conv_pair_f32do_kernel" : f32 ? "conv_pair_f32_kernel" : "conv_pair_bf16x3_kernel", MI, WM, 4 / WM,
-             C / 16);
+    snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_pair_f32_kernel" : "conv_pair_bf16x3_kernel", MI, WM, 4 / WM, C / 16);
     if (h->profile_detail) {
         const size_t n = strlen(kname);
         snprintf(kname + n, sizeof(kname) - n, "|%s x%d", l1[0]->name.c_str(), nbr);
     }
     ProfScope prof(h, stream, kname, flops, bytes);
-    if (dout) {
-        if (C == 64) hipLaunchKernelGGL((conv_pair_f32do_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
-        else if (small) hipLaunchKernelGGL((conv_pair_f32do_kernel<1, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
-        else hipLaunchKernelGGL((conv_pair_f32do_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
-    } else if (f32) {
+    if (f32) {
         if (C == 64) hipLaunchKernelGGL((conv_pair_f32_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
         else if (small) hipLaunchKernelGGL((conv_pair_f32_kernel<1, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
         else hipLaunchKernelGGL((conv_pair_f32_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);

@@ -218,10 +218,10 @@ __device__ __forceinline__ void pin_slab_step() {
 // (fp32) — MI = 2, NB = 2: 0.25 loads per MFMA against 0.31 at MI = 4, NB = 1 on the same 64 accumulator registers and the same LDS budget
 // (tile = WM*MI*32 rows x WN*NB*32 channels).  Every 16-byte load next to fp32 MFMAs costs ~22 cycles of matrix-pipe time.
 //
-// DOUT = true (dev experiment of round 4, exact fp32 forward launches): the MFMA waves write a finished tile straight from their accumulators
+// DOUT = true (round 4; the default of the dense exact-fp32 launches, HIFICAR_DOUT=0 turns it off): the MFMA waves write a finished tile straight from their accumulators
 // (bias, residual, LeakyReLU, 16-byte stores: lane (li, g) owns row li and four adjacent channels per register quad) — no LDS out-buffer, no
 // output pass in the loader waves, which then only stage.  Trades the loaders' share of the SIMDs' issue slots during the K loop (and the waits
-// at the out-buffer hand-over barriers) for an epilogue the matrix pipe idles through.
+// at the out-buffer hand-over barriers) for an epilogue the matrix pipe idles through: +1.5 % end to end (37.41 -> 37.96 M samples/s).
 template <int MI, int WM, int WN, int NC16, bool F32, int KS = 1, int NB = 1, bool DOUT = false>
 __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     static_assert(!DOUT || (F32 && KS == 1 && NB == 1), "direct output: exact fp32, dense form, one channel block per wave");
@@ -989,7 +989,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     HIFICAR_STAMP(63);
 }
 
-// direct-output form (DOUT, dev experiment): exact fp32 forward launches
+// direct-output form (DOUT): the dense exact-fp32 launches
 template <int MI, int WM, int WN, int NC16>
 __global__ __launch_bounds__((WM * WN + 4) * 64) void conv_f32do_kernel(const MultiConvParams mp) {
     conv_ws_body<MI, WM, WN, NC16, true, 1, 1, true>(mp);
@@ -1060,12 +1060,11 @@ struct PairParams {
     unsigned long long* trace;
 };
 
-// DOUT (exact fp32): conv2's result leaves straight from the accumulators (bias, residual, LeakyReLU, 16-byte stores) — no out-buffer aliasing the
-// intermediate, so barriers F and C and the loader waves' output pass disappear: A (input landed) | conv1 | intermediate -> TS | B | conv2 | store.
-// (The next tile's intermediate overwrites TS only behind the next barrier A, which every wave reaches after its conv2.)
-template <int MI, int WM, int WN, int NC16, bool F32, bool DOUT = false>
+// (Round 4 measured the direct-output epilogue of conv_ws_body here as well — conv2's result stored straight from the accumulators, barriers F and C
+// and the loaders' output pass gone: 119.2-120.0 us per C = 32 launch against 112.2-113.0 us.  The pair tile's K loops are short (C = 32: 2 slabs
+// per tap) and the matrix pipe idles through the epilogue's loads and stores, which the loader waves otherwise hide behind conv1.  Not kept.)
+template <int MI, int WM, int WN, int NC16, bool F32>
 __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
-    static_assert(!DOUT || F32, "direct output: exact fp32");
     static_assert(WM * WN == 4, "4 MFMA waves per workgroup");
     static_assert(NC16 == 2 || NC16 == 4, "C = 32 or 64");
     static_assert(WN * 32 == NC16 * 16, "the workgroup covers all C channels");
@@ -1289,21 +1288,17 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
             HIFICAR_STAMP(4 * it);
             __syncthreads();                 // A: input of tile `it` landed (hipcc drains vmcnt first)
             HIFICAR_STAMP(4 * it + 1);
-            if constexpr (!DOUT) {
-                if (it != first) write_out(Tprev, ltid, 256);  // hidden behind conv1 of this tile
-                HIFICAR_STAMP(4 * it + 2);
-                __syncthreads();             // F: shared region free
-            }
+            if (it != first) write_out(Tprev, ltid, 256);  // hidden behind conv1 of this tile
+            HIFICAR_STAMP(4 * it + 2);
+            __syncthreads();                 // F: shared region free
             __syncthreads();                 // B: TS complete, input buffer free
             HIFICAR_STAMP(4 * it + 3);
             if (itn < my_rounds) stage_in(decode(tile_of(itn)));  // hidden behind conv2
-            if constexpr (!DOUT) __syncthreads();  // C: conv2 done reading TS
+            __syncthreads();                 // C: conv2 done reading TS
             Tprev = T;
         }
         __syncthreads();                     // Z: the last tile's accumulators are in the out-buffer
-        if constexpr (!DOUT) {
-            if (first < my_rounds) write_out(Tprev, tid, 512);  // all eight waves share the final output pass
-        }
+        if (first < my_rounds) write_out(Tprev, tid, 512);  // all eight waves share the final output pass
         return;
     }
 
@@ -1459,7 +1454,7 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
         run_conv(0, wave_row0 + li + (p1.tap_off0[0] - p1.off_min), p1.tap_step, p1.ntaps, stream2(T), k2);
         if constexpr (F32) act_on = false;
         HIFICAR_STAMP(6 * it + 2);
-        if constexpr (!DOUT) __syncthreads();  // F: the loaders are done with the previous tile's out-buffer (same LDS region as TS)
+        __syncthreads();  // F: the loaders are done with the previous tile's out-buffer (same LDS region as TS)
         {   // bias + LeakyReLU + split -> TS (zero outside the sequence: conv2's padding)
             const float slope = mp.slope_mid;
             f32x4 bias4[4];
@@ -1505,48 +1500,6 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
         // ---- conv2 over TS: output row r2 reads TS rows r2 .. r2 + k2 - 1 ----
         run_conv(ts_off, wave_row0 + li, 1, k2, stream1(Tn), mp.p1[Tn.b].ntaps);
         HIFICAR_STAMP(6 * it + 5);
-        if constexpr (DOUT) {
-            const size_t seq_base = (size_t)T.seq * p2.L;
-            const int rows_valid = min(T.tmo, seq_rows(p2, T.seq) - T.t0);
-            const int vc0 = wn * 32 + 4 * g;
-            f32x4 bv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(p2.bias + vc0 + 8 * q);
-            const float slope_out = p2.slope_out;
-            constexpr int G2 = MI >= 2 ? 2 : 1;
-#pragma unroll
-            for (int m0 = 0; m0 < MI; m0 += G2) {
-                f32x4 rs[G2][4];
-#pragma unroll
-                for (int mm = 0; mm < G2; ++mm) {
-                    const int row_l = wave_row0 + (m0 + mm) * 32 + li;
-                    const size_t off = (seq_base + T.t0 + min(row_l, max(rows_valid - 1, 0))) * TN + vc0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rs[mm][q] = *reinterpret_cast<const f32x4*>(p2.res + off + 8 * q);
-                }
-#pragma unroll
-                for (int mm = 0; mm < G2; ++mm) {
-                    const int mi = m0 + mm;
-                    const int row_l = wave_row0 + mi * 32 + li;
-                    if (row_l < rows_valid) {
-                        const size_t off = (seq_base + T.t0 + row_l) * TN + vc0;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (acc[mi][4 * q + e] + bv[q][e]) + rs[mm][q][e];
-                            *reinterpret_cast<f32x4*>(p2.y + off + 8 * q) = o;
-                            if (p2.ys) {
-                                f32x4 a;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) a[e] = fmaxf(o[e], o[e] * slope_out);
-                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p2.ys) + off + 8 * q) = a;
-                            }
-                        }
-                    }
-                }
-            }
-        } else {
         __syncthreads();  // C: every wave is done reading TS; its region becomes the out-buffer
         {
             float* O = reinterpret_cast<float*>(smem_b + o_off);
@@ -1560,17 +1513,9 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
                     *reinterpret_cast<f32x4*>(&O[(wave_row0 + mi * 32 + li) * OP + wn * 32 + 8 * q + 4 * g]) = v;
                 }
         }
-        }
     }
     __syncthreads();  // Z
-    if constexpr (!DOUT) {
-        if (last >= 0) write_out(decode(tile_of(last)), tid, 512);
-    }
-}
-
-template <int MI, int WM, int WN, int NC16>
-__global__ __launch_bounds__(512) void conv_pair_f32do_kernel(const PairParams mp) {
-    conv_pair_body<MI, WM, WN, NC16, true, true>(mp);
+    if (last >= 0) write_out(decode(tile_of(last)), tid, 512);
 }
 
 template <int MI, int WM, int WN, int NC16>
