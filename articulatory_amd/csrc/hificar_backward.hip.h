@@ -338,9 +338,16 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradTapsPair pai
 // One-tap form with a 128 x 128 tile (the discriminators' GEMM-form convs: dW [N x Kg] = dZ^T A with few rows M and wide Kg): a wave owns
 // a 64 x 64 block as 2 x 2 accumulators, so a 64-row chunk staged once (64 KB) feeds 128 MFMAs per wave instead of the 32 of the
 // 64 x 64 tile above, which is bound by the staging traffic at one tap.  Same partial layout, bias sums and z replicas.
+// AJ = 4 (round 4): a 128 x 256 tile — a wave owns 64 x 128 as 2 x 4 accumulators (128 registers; one workgroup per CU, so a wave has 512) and
+// the chunk is 32 rows: 48 KB staged per 128 MFMAs per wave instead of 64 KB (the 128 x 128 tile pulls 8 B per clock and CU through the L2 /
+// MALL: 0.51 of the MFMA peak measured, next to 0.64 for the forward GEMMs of the same layers), six 4-byte LDS reads per eight MFMAs instead of
+// four per four.  For layers at least 256 columns wide (wgrad_gemm_wide).
 constexpr int kWggR = 64;
 
+template <int AJ, int R>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradTapsPair pair) {
+    static_assert((AJ == 2 && R == 64) || (AJ == 4 && R == 32), "128 x 128 tile on 64-row chunks, or 128 x 256 on 32-row chunks");
+    constexpr int AW = AJ * 64;  // columns of the staged A tile
     extern __shared__ __attribute__((aligned(1024))) char wgg_smem[];
     const WgradTapsParams& q = pair.q[blockIdx.z / pair.zg];
     const int zi = blockIdx.z % pair.zg;
@@ -351,42 +358,55 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradTapsPair pai
     const WgradParams& p = q.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hf = lane >> 5;
-    const int at_n = (p.n_ablk + 3) >> 2;
+    const int at_n = (p.n_ablk + 2 * AJ - 1) / (2 * AJ);
     const int at = blockIdx.x % at_n, gt = blockIdx.x / at_n;
     const int split = blockIdx.y;
     const int gw = wave >> 1, aw = wave & 1;
-    constexpr int buf_floats = 2 * kWggR * 128;  // G rows then A rows
-    const int cps = (p.L + kWggR - 1) / kWggR;
+    constexpr int buf_floats = R * (128 + AW);  // G rows then A rows
+    const int cps = (p.L + R - 1) / R;
     const int nchunks = p.nseq * cps;
     const int a_cols = q.acols ? q.acols : p.apitch;
     const size_t a_seq_pitch = q.a_seq_pitch ? (size_t)q.a_seq_pitch : (size_t)p.L * p.apitch;
     const int c_lo = (int)((long long)nchunks * split / p.nsplit), c_hi = (int)((long long)nchunks * (split + 1) / p.nsplit);
-    f32x16 acc[2][2];
+    f32x16 acc[2][AJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < AJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // LDS-DMA: 1 KiB = 2 rows of 128 channels per wave-instruction, lane -> (row 2 i + lane / 32, channels 4 (lane % 32) ..)
+    // LDS-DMA: 1 KiB per wave-instruction = 2 rows of 128 channels (lane -> row 2 i + lane / 32, channels 4 (lane % 32) ..) or 1 row of 256
     auto stage = [&](int c, int b) {
         const int seq = c / cps;
-        const int t0 = (c - seq * cps) * kWggR;
+        const int t0 = (c - seq * cps) * R;
         char* dst = wgg_smem + (size_t)b * buf_floats * 4;
         const int c4 = (lane & 31) * 4;
-        for (int i = wave; i < kWggR / 2; i += 4) {
+        for (int i = wave; i < R / 2; i += 4) {
             const int t = t0 + 2 * i + (lane >> 5);
             const char* gsrc = q.zeros;
-            const char* asrc = q.zeros;
-            const int gch = gt * 128 + c4, ach = at * 128 + c4;
-            if (t < p.L) {
-                if (gch < p.gpitch) gsrc = reinterpret_cast<const char*>(g_base + ((size_t)seq * p.L + t) * p.gpitch + gch);
-                if (ach < a_cols) asrc = reinterpret_cast<const char*>(a_base + (size_t)seq * a_seq_pitch + (size_t)t * p.apitch + ach);
-            }
+            const int gch = gt * 128 + c4;
+            if (t < p.L && gch < p.gpitch) gsrc = reinterpret_cast<const char*>(g_base + ((size_t)seq * p.L + t) * p.gpitch + gch);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)asrc,
-                                             (__attribute__((address_space(3))) void*)(dst + kWggR * 512 + i * 1024), 16, 0, 0);
+        }
+        if constexpr (AJ == 2) {
+            for (int i = wave; i < R / 2; i += 4) {
+                const int t = t0 + 2 * i + (lane >> 5);
+                const char* asrc = q.zeros;
+                const int ach = at * AW + c4;
+                if (t < p.L && ach < a_cols) asrc = reinterpret_cast<const char*>(a_base + (size_t)seq * a_seq_pitch + (size_t)t * p.apitch + ach);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)asrc,
+                                                 (__attribute__((address_space(3))) void*)(dst + R * 512 + i * 1024), 16, 0, 0);
+            }
+        } else {
+            for (int i = wave; i < R; i += 4) {
+                const int t = t0 + i;
+                const char* asrc = q.zeros;
+                const int ach = at * AW + lane * 4;
+                if (t < p.L && ach < a_cols) asrc = reinterpret_cast<const char*>(a_base + (size_t)seq * a_seq_pitch + (size_t)t * p.apitch + ach);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)asrc,
+                                                 (__attribute__((address_space(3))) void*)(dst + R * 512 + i * 1024), 16, 0, 0);
+            }
         }
     };
     const bool do_bias = bias_base && at == 0;
@@ -397,30 +417,36 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradTapsPair pai
         const int b = (c - c_lo) & 1;
         if (c + 1 < c_hi) stage(c + 1, b ^ 1);
         const float* gs = reinterpret_cast<const float*>(wgg_smem) + (size_t)b * buf_floats;
-        const float* as = gs + kWggR * 128;
+        const float* as = gs + R * 128;
         if (do_bias) {
 #pragma unroll 8
-            for (int r = tid >> 7; r < kWggR; r += 2) bsum += gs[r * 128 + (tid & 127)];
+            for (int r = tid >> 7; r < R; r += 2) bsum += gs[r * 128 + (tid & 127)];
         }
         {
             const float* gp = gs + hf * 128 + gw * 64 + li;
-            const float* ap = as + hf * 128 + aw * 64 + li;
-            float g0[2] = {gp[0], gp[32]}, a0[2] = {ap[0], ap[32]}, g1[2], a1[2];
+            const float* ap = as + hf * AW + aw * (AJ * 32) + li;
+            float g0[2] = {gp[0], gp[32]}, a0[AJ], g1[2], a1[AJ];
 #pragma unroll
-            for (int kb = 0; kb < kWggR; kb += 16) {
+            for (int j = 0; j < AJ; ++j) a0[j] = ap[32 * j];
+#pragma unroll
+            for (int kb = 0; kb < R; kb += 16) {
 #pragma unroll
                 for (int k = 0; k < 16; k += 4) {
-                    const int r1 = (kb + k + 2) * 128, r2 = (kb + k + 4) * 128;  // (the last fetch reads two rows past the chunk: unused)
-                    g1[0] = gp[r1], g1[1] = gp[r1 + 32], a1[0] = ap[r1], a1[1] = ap[r1 + 32];
+                    const int r1 = kb + k + 2, r2 = kb + k + 4;  // (the last fetch reads two rows past the chunk: unused)
+                    g1[0] = gp[r1 * 128], g1[1] = gp[r1 * 128 + 32];
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) a1[j] = ap[r1 * AW + 32 * j];
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0[i], a0[j], acc[i][j], 0, 0, 0);
-                    g0[0] = gp[r2], g0[1] = gp[r2 + 32], a0[0] = ap[r2], a0[1] = ap[r2 + 32];
+                        for (int j = 0; j < AJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0[i], a0[j], acc[i][j], 0, 0, 0);
+                    g0[0] = gp[r2 * 128], g0[1] = gp[r2 * 128 + 32];
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) a0[j] = ap[r2 * AW + 32 * j];
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[i], a1[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < AJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[i], a1[j], acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -437,8 +463,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradTapsPair pai
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int gblk = gt * 4 + gw * 2 + i, ablk = at * 4 + aw * 2 + j;
+        for (int j = 0; j < AJ; ++j) {
+            const int gblk = gt * 4 + gw * 2 + i, ablk = at * (2 * AJ) + aw * AJ + j;
             if (gblk >= p.n_gblk || ablk >= p.n_ablk) continue;
             float* dst = partial_base + ((size_t)split * gpad + gblk * 32) * apad + ablk * 32 + li;
 #pragma unroll
