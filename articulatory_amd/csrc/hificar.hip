@@ -161,6 +161,11 @@ struct hificar_handle {
     hipStream_t last_stream = nullptr;
     bool have_last_stream = false;
     hipEvent_t xstream_ev = nullptr;
+    // AR loop of a small batch on two streams (hificar_ar_loop_ragged): the second stream, fork / join / schedule-upload events
+    int ar_dual_min = 17, ar_dual_max = 62;  // HIFICAR_AR_DUAL_MIN / _MAX: the batch sizes the loop splits (max 0: never)
+    hipStream_t ar_side = nullptr;
+    hipEvent_t ar_ev[2] = {nullptr, nullptr};
+    unsigned long long sched_up_seq = 0;  // schedule uploads so far (get_schedule): a schedule is uploaded on the stream that first needs it
     hipEvent_t done_ev = nullptr;  // recorded at the END of the last call on done_stream (calls that mark their end: the discriminators' backward)
     bool done_valid = false;
     hipStream_t done_stream = nullptr;
@@ -298,6 +303,8 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (const char* e = getenv("HIFICAR_XCD_ORDER")) h->xcd_order = atoi(e) != 0;    // (A/B runs)
     if (const char* e = getenv("HIFICAR_LPT")) h->use_lpt = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_KSPLIT")) h->ksplit = atoi(e);
+    if (const char* e = getenv("HIFICAR_AR_DUAL_MIN")) h->ar_dual_min = atoi(e);  // (A/B runs, tests)
+    if (const char* e = getenv("HIFICAR_AR_DUAL_MAX")) h->ar_dual_max = atoi(e);
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -444,6 +451,9 @@ extern "C" void hificar_destroy(hificar_handle* h) {
         (void)hipHostFree(a.h);
     }
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
+    if (h->ar_side) (void)hipStreamDestroy(h->ar_side);
+    for (hipEvent_t e : h->ar_ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->done_ev) (void)hipEventDestroy(h->done_ev);
     for (auto& r : h->rslots) {
         if (r.d) (void)hipFree(r.d);
@@ -784,7 +794,11 @@ static Workspace plan_workspace(const hificar_handle* h, int B, int T, void* bas
 
 extern "C" size_t hificar_workspace_bytes(const hificar_handle* h, int B, int T) {
     if (!h || B < 1 || T < 1) return 0;
-    return plan_workspace(h, B, bucket_frames(T), nullptr).bytes;
+    const int Tb = bucket_frames(T);
+    size_t n = plan_workspace(h, B, Tb, nullptr).bytes;
+    if (B >= 2)  // room for the two halves of the batch side by side (hificar_ar_loop on two streams; buffer sizes round up to 1 KB)
+        n = std::max(n, plan_workspace(h, (B + 1) / 2, Tb, nullptr).bytes + plan_workspace(h, B / 2, Tb, nullptr).bytes);
+    return n;
 }
 
 extern "C" double hificar_macs(const hificar_handle* h, int B, int T) {
@@ -964,6 +978,7 @@ static int get_schedule(hificar_handle* h, const std::string& key, const std::ve
         }
         start[G] = pos;
         HIP_TRY(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, stream));  // pinned source, never rewritten while cached
+        ++h->sched_up_seq;
         hificar_handle::Sched sc;
         sc.d_start = reinterpret_cast<int*>(dp);
         sc.d_tiles = sc.d_start + round_up_sz(n_start, 4);
@@ -1785,6 +1800,58 @@ extern "C" int hificar_ar_loop_ragged(hificar_handle* h, const float* c, const i
         for (int b = 0; b < B; ++b)
             if (lengths_host[b] < 0 || lengths_host[b] > T_total)
                 return fail(HIFICAR_E_INVALID, "lengths[%d]=%d outside [0, %d]", b, lengths_host[b], T_total);
+    // Mid-size batches on TWO streams (round 4).  Utterances do not depend on each other, and a step is a chain of 34 dependent launches whose tile
+    // lists quantise badly between batch 17 and 62 (a 25-frame chunk is ONE 128-row tile per utterance at the widest stage: 6 B tiles of weight
+    // 11 : 7 : 3 for 256 workgroups — batch 44 to 64 all take the same 11 units): the two halves of the batch run their own chains on two streams
+    // and each half's idle workgroups, launch latencies and tails are filled by the other half's kernels.  Measured (10-s clips, chunk 25, fp32,
+    // single / dual ms per step): batch 18 108.2 / 103.4, 22 130.3 / 122.6, 28 146.3 / 135.3, 32 153.1 / 142.2, 36 184.6 / 171.3, 44 224.8 / 201.5,
+    // 48 225.4 / 214.7, 56 263.7 / 239.2, 60 266.2 / 258.8; below the window the halves' launches are less efficient than the whole batch's
+    // (batch 8: 58.1 / 68.1, 4: 44.2 / 48.4, 16: 90.7 / 91.6), at 64 the tile lists are full (269.3 / 276.5).  Same kernels, same per-utterance
+    // arithmetic up to the launch-shape dependence HIFICAR_KSPLIT=0 removes.  Not while profiling or tapping (one stream's events / scratch), not for
+    // ragged batches (their steps shrink the batch prefix).
+    const hipStream_t s0 = static_cast<hipStream_t>(stream);
+    const int Tn_max = std::min(chunk_frames, T_total);
+    const int B0 = (B + 1) / 2, B1 = B - B0;
+    const size_t ws0_bytes = plan_workspace(h, B0, Tn_max, nullptr).bytes;
+    if (!lengths && B >= 2 && B >= h->ar_dual_min && B <= h->ar_dual_max && !h->profiling && h->taps.empty() &&
+        ws0_bytes + plan_workspace(h, B1, Tn_max, nullptr).bytes <= workspace_bytes) {
+        if (!h->ar_side) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->ar_side, hipStreamNonBlocking));
+            for (hipEvent_t& e : h->ar_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const hipStream_t s1 = h->ar_side;
+        HIP_TRY(hipEventRecord(h->ar_ev[0], s0));  // fork: the side stream starts behind the caller's work so far
+        HIP_TRY(hipStreamWaitEvent(s1, h->ar_ev[0], 0));
+        unsigned long long seen = h->sched_up_seq;
+        // a tile schedule first needed by one half is uploaded on that half's stream: the other stream must not use it before it has landed
+        auto publish = [&](hipStream_t from, hipStream_t to, hipEvent_t ev) -> int {
+            if (h->sched_up_seq != seen) {
+                HIP_TRY(hipEventRecord(ev, from));
+                HIP_TRY(hipStreamWaitEvent(to, ev, 0));
+                seen = h->sched_up_seq;
+            }
+            return HIFICAR_OK;
+        };
+        const float* const c1 = c + (size_t)B0 * h->cf * T_total;
+        float* const out1 = out + (size_t)B0 * out_bstride;
+        char* const wsp1 = static_cast<char*>(workspace) + ws0_bytes;
+        for (int f0 = 0; f0 < T_total && rc == HIFICAR_OK; f0 += chunk_frames) {
+            const int Tn = std::min(chunk_frames, T_total - f0);
+            const int64_t pos = (int64_t)h->hop * f0;
+            const int64_t back = f0 == 0 ? 0 : pos - h->cfg.ar_input;
+            rc = forward_impl(h, c + f0, (int64_t)h->cf * T_total, T_total, f0 == 0 ? nullptr : out + back, out_bstride, out + pos, out_bstride, B0, Tn,
+                              plan_workspace(h, B0, Tn, workspace), s0, nullptr, f0);
+            if (rc == HIFICAR_OK) rc = publish(s0, s1, h->ar_ev[0]);
+            if (rc == HIFICAR_OK)
+                rc = forward_impl(h, c1 + f0, (int64_t)h->cf * T_total, T_total, f0 == 0 ? nullptr : out1 + back, out_bstride, out1 + pos, out_bstride, B1, Tn,
+                                  plan_workspace(h, B1, Tn, wsp1), s1, nullptr, f0);
+            if (rc == HIFICAR_OK) rc = publish(s1, s0, h->ar_ev[1]);
+        }
+        // join (also on an error return: the caller's stream must stay ordered behind what the side stream was given)
+        if (hipEventRecord(h->ar_ev[1], s1) != hipSuccess || hipStreamWaitEvent(s0, h->ar_ev[1], 0) != hipSuccess)
+            return rc != HIFICAR_OK ? rc : fail(HIFICAR_E_HIP, "hificar_ar_loop: joining the side stream failed");
+        return rc;
+    }
     for (int f0 = 0; f0 < T_total; f0 += chunk_frames) {
         const int Tn = std::min(chunk_frames, T_total - f0);
         // With the host copy of the lengths the step only covers the utterances still running: the batch prefix up to the

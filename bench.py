@@ -267,7 +267,10 @@ def training_leg(steps=5, traffic_table=None):
     # pass's backward) on side streams, where an event-bracketed launch's duration is an occupancy artefact; a second Trainer with every engine on
     # the caller's stream (HIFICAR_DISC_STREAMS=0, no side-stream overlap in the step) gives launch times that ARE a fraction of something
     del t
-    os.environ["HIFICAR_DISC_STREAMS"] = "0"  # (read when the discriminators' native handle is created: at the first forward)
+    # ... with the tile shapes of the overlapped run (the engine picks them by workgroup-time when its launches overlap: HIFICAR_DISC_PICK /
+    # HIFICAR_MI1_PENALTY pin those rules here, otherwise the serial engine would choose — and this table would describe — different kernels)
+    serial_env = {"HIFICAR_DISC_STREAMS": "0", "HIFICAR_DISC_PICK": "64", "HIFICAR_MI1_PENALTY": "1.3"}
+    os.environ.update(serial_env)  # (read when the discriminators' native handle is created: at the first forward)
     try:
         ts, _ = build(B, 1234, 4321)
         ts.config["overlap_aux_loss"] = ts.config["early_real_gradient"] = False
@@ -280,7 +283,8 @@ def training_leg(steps=5, traffic_table=None):
             serial_iteration()
         torch.cuda.synchronize()
     finally:
-        os.environ.pop("HIFICAR_DISC_STREAMS", None)
+        for k in serial_env:
+            os.environ.pop(k, None)
     ts.G.profile_begin()
     ts.D.profile_begin()
     t1 = time.perf_counter()

@@ -669,6 +669,33 @@ def test_batch_invariance_is_bitwise_without_split_k(monkeypatch, prec):
     assert same_across_shapes(y2, y, XSHAPE_TOL[prec])
 
 
+def test_ar_loop_on_two_streams_equals_one_stream(monkeypatch, prec):
+    """hificar_ar_loop splits mid-size batches into two halves on two streams (csrc/hificar.hip, hificar_ar_loop_ragged): every utterance's
+    waveform equals the single-stream loop's — bit for bit in the batch-invariant mode, to fp32 rounding otherwise (the halves' launches may
+    pick other tile forms) — for an odd batch, a tail chunk and repeated calls (the side stream re-uses the handle's schedules)."""
+    x = synth_features(5, 60, 13, seed=77)
+    feats = torch.from_numpy(x).permute(0, 2, 1).contiguous().cuda()
+    monkeypatch.setenv("HIFICAR_AR_DUAL_MAX", "0")
+    g1, _ = make(dict(E2W_PARAMS), prec)
+    monkeypatch.setenv("HIFICAR_AR_DUAL_MIN", "2")
+    monkeypatch.setenv("HIFICAR_AR_DUAL_MAX", "64")
+    g2, _ = make(dict(E2W_PARAMS), prec)
+    with torch.no_grad():
+        y1 = g1.ar_synthesis(feats, 25)
+        y2 = g2.ar_synthesis(feats, 25)
+        y2b = g2.ar_synthesis(feats, 25)
+        y2c = g2.ar_synthesis(feats[:2].contiguous(), 25)
+    assert torch.equal(y2, y2b)
+    assert same_across_shapes(y2, y1, XSHAPE_TOL[prec])
+    assert same_across_shapes(y2c, y1[:2], XSHAPE_TOL[prec])
+    monkeypatch.setenv("HIFICAR_KSPLIT", "0")
+    g3, _ = make(dict(E2W_PARAMS), prec)
+    monkeypatch.setenv("HIFICAR_AR_DUAL_MAX", "0")
+    g4, _ = make(dict(E2W_PARAMS), prec)
+    with torch.no_grad():
+        assert torch.equal(g3.ar_synthesis(feats, 25), g4.ar_synthesis(feats, 25))
+
+
 def test_ragged_forward_non_ar(prec):
     """hificar_forward_ragged on the non-AR generator: per utterance identical to a forward of that utterance alone."""
     params = dict(E2W_PARAMS, in_channels=12, use_ar=False)
