@@ -117,6 +117,21 @@ def test_batched_and_ragged_ar_loop_vs_oracle():
     assert same_across_shapes(alone[0], y[2, :80 * 51])
 
 
+def test_ar_loop_on_two_streams_equals_one_stream(monkeypatch):
+    """hificar_ar_loop's two-stream form (mid-size batches; forced here for batch 5) on the GBlock engine: per utterance the single-stream result."""
+    p = _params(np.load(os.path.join(GOLDEN, "gold_gblock_small.npz")))
+    x = torch.from_numpy(synth_features(5, 60, 13, seed=932)).permute(0, 2, 1).contiguous().cuda()
+    monkeypatch.setenv("HIFICAR_AR_DUAL_MAX", "0")
+    one, _ = build(p)
+    monkeypatch.setenv("HIFICAR_AR_DUAL_MIN", "2")
+    monkeypatch.setenv("HIFICAR_AR_DUAL_MAX", "64")
+    two, _ = build(p)
+    with torch.no_grad():
+        y1, y2 = one.ar_synthesis(x, 25), two.ar_synthesis(x, 25)
+        assert torch.equal(y2, two.ar_synthesis(x, 25))
+    assert same_across_shapes(y2, y1)
+
+
 def test_nonar_inference_vs_reference_golden():
     g = np.load(os.path.join(GOLDEN, "gold_gblock_nonar.npz"))
     model, _ = build(_params(g))

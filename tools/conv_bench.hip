@@ -34,7 +34,7 @@ static void summarize(const std::vector<unsigned long long>& ht, int G) {
     stat("WG end (abs)", wg_end);
 }
 
-template <int MI, int WM, int WN, int NC16, bool F32 = false, int KS = 1>
+template <int MI, int WM, int WN, int NC16, bool F32 = false, int KS = 1, bool DO = false>
 void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int dil, bool residual, int mode = 0) {
     constexpr int TM = WM * MI * 32;
     const int CH = NC16 * 16;
@@ -111,9 +111,10 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, int 
     hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
     mp.trace = trace;
     void (*kern)(const MultiConvParams) = nullptr;
-    if constexpr (KS == 4) kern = F32 ? conv_sk_f32_kernel<MI, NC16> : conv_sk_bf16x3_kernel<MI, NC16>;  // split-K form (WM = WN = 1)
+    if constexpr (DO) kern = conv_f32do_kernel<MI, WM, WN, NC16>;  // direct output (round 4): no out-buffer
+    else if constexpr (KS == 4) kern = F32 ? conv_sk_f32_kernel<MI, NC16> : conv_sk_bf16x3_kernel<MI, NC16>;  // split-K form (WM = WN = 1)
     else kern = F32 ? conv_f32_kernel<MI, WM, WN, NC16> : conv_bf16x3_kernel<MI, WM, WN, NC16>;
-    const size_t lds_bytes = 2 * (size_t)mp.buf_bytes + (size_t)KS * TM * (WN * 32 + 4) * 4;
+    const size_t lds_bytes = 2 * (size_t)mp.buf_bytes + (DO ? 0 : (size_t)KS * TM * (WN * 32 + 4) * 4);
     const int nthreads = KS == 4 ? 512 : (WM * WN + 4) * 64;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1;
@@ -286,6 +287,18 @@ int main(int argc, char** argv) {
             run<1, 1, 1, 1, true, 4>("stage3 sk<1,1> conv1", B, 2000, 32, 3, k3, 1, false);
             run<1, 4, 1, 1, true>("stage3 <1,4,1,1> conv1", B, 2000, 32, 3, k3, 1, false);
         }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "f32do")) {  // direct-output kernels: the narrow stages, and C = 64 with ONE 64-channel chunk per tile
+        run<4, 1, 4, 4, true, 1, true>("stage0 (4,1,4) conv2+res DO", 64, 125, 256, 3, k3, 1, true);
+        run<4, 2, 2, 2, true, 1, true>("stage2 C64 (4,2,2) conv1 DO", 64, 1000, 64, 3, k3, 1, false);
+        run<4, 2, 2, 2, true, 1, true>("stage2 C64 (4,2,2) conv2+res DO", 64, 1000, 64, 3, k3, 1, true);
+        run<4, 2, 2, 4, true, 1, true>("stage2 C64 chunk64 conv1 DO", 64, 1000, 64, 3, k3, 1, false);
+        run<4, 2, 2, 4, true, 1, true>("stage2 C64 chunk64 conv2+res DO", 64, 1000, 64, 3, k3, 1, true);
+        run<4, 4, 1, 1, true, 1, true>("stage3 C32 (4,4,1) conv1 DO", 64, 2000, 32, 3, k3, 1, false);
+        run<4, 4, 1, 1, true, 1, true>("stage3 C32 (4,4,1) conv2+res DO", 64, 2000, 32, 3, k3, 1, true);
+        run<4, 4, 1, 2, true, 1, true>("stage3 C32 chunk32 conv1 DO", 64, 2000, 32, 3, k3, 1, false);
+        run<4, 4, 1, 2, true, 1, true>("stage3 C32 chunk32 conv2+res DO", 64, 2000, 32, 3, k3, 1, true);
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "f32")) {
