@@ -18,7 +18,7 @@ for prec in ("bf16x3", "f32"):
     g = HiFiGANGenerator(**CAR_PARAMS, precision=prec)
     g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     g.remove_weight_norm(); g = g.eval().cuda()
-    for B, chunk in ((64, 25), (8, 100), (3, 25), (1, 25)):
+    for B, chunk in ((64, 25), (24, 25), (8, 100), (3, 25), (1, 25)):  # (24: the two-stream form of the AR loop)
         x = torch.from_numpy(synth_features(B, a.frames, 13, seed=B)).permute(0, 2, 1).contiguous().cuda()
         with torch.no_grad():
             ref = g.ar_synthesis(x, chunk).clone()
