@@ -1197,7 +1197,10 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
             best_ti = ti;
         }
     }
-    if (cached_pick == h->tile_picks.end()) h->tile_picks.emplace(pick_key, best_ti);
+    if (cached_pick == h->tile_picks.end()) {
+        if (h->tile_picks.size() > 20000) h->tile_picks.clear();  // (a very large number of distinct launch shapes: start over)
+        h->tile_picks.emplace(pick_key, best_ti);
+    }
     const int TM = tc.WM * tc.MI * 32;
     const int chunk_sel = tc.CH ? tc.CH : L0.chunk16, RB = chunk_sel * 4;
     const int nc16 = chunk_sel / 16;
