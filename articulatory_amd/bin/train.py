@@ -476,13 +476,14 @@ def main(argv=None):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
+        from articulatory_amd.utils.affinity import pin_rank
+
+        # ~1000 launches per iteration are enqueued from Python: every rank gets its own cores and a bounded intra-op pool — before the process
+        # group exists, so that RCCL's threads are born inside the slice
+        pinned = pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         torch.distributed.init_process_group("nccl")  # RCCL
         if torch.distributed.get_world_size() != world:
             raise SystemExit(f"WORLD_SIZE={world} but the process group has {torch.distributed.get_world_size()} ranks")
-        from articulatory_amd.utils.affinity import pin_rank
-
-        # ~1000 launches per iteration are enqueued from Python: every rank gets its own cores and a bounded intra-op pool
-        pinned = pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         logging.info(f"rank {rank}/{world}: {pinned or 'host affinity unchanged'}")
     config["distributed"] = world > 1
     hop = hop_of(config)

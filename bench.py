@@ -17,6 +17,12 @@ v_mfma_f32_32x32x2_f32.  The split-bf16 fast mode (`--precision bf16x3`, 16-bit-
 max|y| from fp32) is opt-in and reported as the labelled secondary leg `fast_bf16x3` with the same steps / warm-up
 and its own roofline block.  `batch_sweep` repeats the fp32 measurement at batch 1 and 8 (north_star: 1/8/64).
 
+A plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) launches its own N ranks through
+torch.distributed.run on 127.0.0.1 and forwards rank 0's line; under an outer torchrun it is one of the ranks.
+
+The N = 1 line also carries `nonar` (BASELINE config 2: HiFi-GAN non-AR 12-dim EMA, batch 1 / 8 / 64 — north_star's literal sweep; roofline on
+config 2's batch 8) and `gblock` (the reference's other a2w generator, GBlockGenerator, batch 64 AR synthesis), each with its own roofline block.
+
 Prints ONE JSON line on rank 0.  `roofline` is measured in a second pass of the same K steps with every
 kernel launch bracketed by HIP events on the launch stream (libhificar's profile hooks) so that the
 event traffic does not perturb `value`; `cpu_baseline` times the CPU oracle on a bounded sample.
@@ -86,7 +92,8 @@ def cpu_baseline(params, sd, chunk_frames, seed):
         "value": round(value, 1), "unit": "samples/s", "cores": best, "kind": "port",
         "sample": f"oracle.ar_loop_batched, batch {B} x {T} frames ({T // chunk_frames} chunks of {chunk_frames}), "
                   f"torch {torch.__version__} CPU fp32, best of the thread counts tried = {best} of {all_cores} host threads, {dt:.1f} s",
-        "by_threads": {str(k): round(v, 1) for k, v in by_threads.items()},
+        # (a DIFFERENT, smaller sample than `value`: the thread-count probe, batch 8 x 5 chunks — only there to choose `cores`)
+        "by_threads_probe": {"sample": f"batch 8 x {5 * chunk_frames} frames", "samples_per_s": {str(k): round(v, 1) for k, v in by_threads.items()}},
     }
 
 
@@ -136,7 +143,7 @@ def timed_steps(step, fence, steps, warmup, use_dist=False, device=None):
     return dt, y
 
 
-def roofline_block(stats, precision, wall_s, steps, traffic_table, strict=False):
+def roofline_block(stats, precision, wall_s, steps, traffic_table, strict=False, table_key=None):
     """`roofline` object for the kernel with the largest total time of an event-bracketed pass.
 
     achieved = algorithmic flops (or bytes) of the launches / their summed event time; `bound` is derived from the
@@ -151,13 +158,15 @@ def roofline_block(stats, precision, wall_s, steps, traffic_table, strict=False)
     # machine balance of THIS arithmetic: bf16x3 spends 3 MFMAs per algorithmic MAC, so its matrix roof is peak / 3
     balance = peak_tf / MFMA_PER_MAC[precision] * 1e12 / (PEAK_HBM_GBS * 1e9)
     bound = "mfma" if intensity >= balance else "hbm"
-    traffic = (traffic_table or {}).get(precision, {}).get(dom["name"])
-    if traffic_table is not None and traffic is None:
+    table_key = table_key or precision  # (the secondary legs have their own PMC passes: "nonar_f32", "gblock_f32")
+    have_table = traffic_table is not None and table_key in traffic_table
+    traffic = (traffic_table or {}).get(table_key, {}).get(dom["name"])
+    if (have_table or (strict and traffic_table is not None)) and traffic is None:
         # the table is keyed by kernel name incl. template arguments: a tile picker that changes one silently turned `traffic` into null in
         # round 3's review.  A table that exists but does not know the dominant kernel is a STALE table: the headline leg refuses to print a
         # line on it, the labelled secondary leg shouts on stderr and says so in its block.
-        msg = (f"bench.py: profiles/hbm_traffic.json has no '{precision}' entry for the dominant kernel {dom['name']!r} (it knows "
-               f"{sorted((traffic_table or {}).get(precision, {}))}): re-run tools/collect_profiles.sh and commit the new PMC passes")
+        msg = (f"bench.py: profiles/hbm_traffic.json has no '{table_key}' entry for the dominant kernel {dom['name']!r} (it knows "
+               f"{sorted((traffic_table or {}).get(table_key, {}))}): re-run tools/collect_profiles.sh and commit the new PMC passes")
         if strict:
             raise SystemExit(msg + ", or pass --no-roofline")
         print("WARNING: " + msg, file=sys.stderr, flush=True)
@@ -170,8 +179,8 @@ def roofline_block(stats, precision, wall_s, steps, traffic_table, strict=False)
         "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
         "frac": round((tflops / peak_tf) if bound == "mfma" else (gbs / PEAK_HBM_GBS), 4),
         "traffic": traffic,
-        "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, per launch)" if traffic else
-                          ("STALE TABLE: no entry for this kernel" if traffic_table is not None else None),
+        "traffic_source": f"profiles/hbm_traffic.json[{table_key}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, per launch)" if traffic else
+                          ("STALE TABLE: no entry for this kernel" if have_table else None),
         "algorithmic_bytes": round(alg_bytes),
         "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
         "flops_per_byte": round(intensity, 1), "machine_balance_flops_per_byte": round(balance, 1),
@@ -184,7 +193,7 @@ def roofline_block(stats, precision, wall_s, steps, traffic_table, strict=False)
                          "avg_us": round(s["total_ms"] * 1e3 / s["launches"], 2),
                          "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2),
                          "algorithmic_bytes": round(s["bytes"] / s["launches"]),
-                         "traffic": (traffic_table or {}).get(precision, {}).get(s["name"])} for s in stats],
+                         "traffic": (traffic_table or {}).get(table_key, {}).get(s["name"])} for s in stats],
         "events_pass_ms_per_step": round(wall_s / steps * 1e3, 3),
     }
     return blk
@@ -269,7 +278,11 @@ def training_leg(steps=5, traffic_table=None):
     del t
     # ... with the tile shapes of the overlapped run (the engine picks them by workgroup-time when its launches overlap: HIFICAR_DISC_PICK /
     # HIFICAR_MI1_PENALTY pin those rules here, otherwise the serial engine would choose — and this table would describe — different kernels)
-    serial_env = {"HIFICAR_DISC_STREAMS": "0", "HIFICAR_DISC_PICK": "64", "HIFICAR_MI1_PENALTY": "1.3"}
+    # (a user-set HIFICAR_DISC_PICK / HIFICAR_MI1_PENALTY — documented A/B knobs — also shaped the timed run above: keep it, and put every
+    # variable back afterwards)
+    serial_env = {"HIFICAR_DISC_STREAMS": "0", "HIFICAR_DISC_PICK": os.environ.get("HIFICAR_DISC_PICK", "64"),
+                  "HIFICAR_MI1_PENALTY": os.environ.get("HIFICAR_MI1_PENALTY", "1.3")}
+    saved_env = {k: os.environ.get(k) for k in serial_env}
     os.environ.update(serial_env)  # (read when the discriminators' native handle is created: at the first forward)
     try:
         ts, _ = build(B, 1234, 4321)
@@ -283,8 +296,11 @@ def training_leg(steps=5, traffic_table=None):
             serial_iteration()
         torch.cuda.synchronize()
     finally:
-        for k in serial_env:
-            os.environ.pop(k, None)
+        for k, v in saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     ts.G.profile_begin()
     ts.D.profile_begin()
     t1 = time.perf_counter()
@@ -337,9 +353,48 @@ def training_leg(steps=5, traffic_table=None):
             "first_losses": {k.split("/")[1]: float(v) for k, v in sorted(log.items())}}
 
 
+GBLOCK_PARAMS = dict(in_channels=141, out_channels=1, channels=512, kernel_size=7, g_scales=[5, 1, 4, 1, 1, 2, 1, 2, 1, 1], g_kernel_sizes=[3] * 10,
+                     use_weight_norm=True, use_ar=True, ar_input=512, ar_hidden=256, ar_output=128, use_tanh=True)
+
+
+def self_launch(gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: this process is the launcher.  It starts N ranks of this very file through
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 — the reference's only rendezvous is its training launcher,
+    articulatory/bin/train.py:1459,1610-1615), forwards their output (rank 0 prints the one JSON line) and returns their exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _standin_factory():
+    """Test hook: HIFICAR_BENCH_STANDIN="path/to/file.py:function" names a stand-in synthesis factory, so that a CPU / gloo test can call
+    `python bench.py --gpus 2` exactly as the driver does (tests/test_distributed_gloo.py).  Never set on a GPU box."""
+    spec = os.environ.get("HIFICAR_BENCH_STANDIN")
+    if not spec:
+        return None
+    import importlib.util
+
+    path, fn = spec.rsplit(":", 1)
+    ms = importlib.util.spec_from_file_location("_bench_standin", path)
+    mod = importlib.util.module_from_spec(ms)
+    ms.loader.exec_module(mod)
+    return getattr(mod, fn)
+
+
 def main(argv=None, synth_factory=None):
     """``synth_factory`` is a test hook (tests/test_distributed_gloo.py runs this very function under a 2-process gloo
     torchrun on CPU with a stand-in synthesis function); the product path never passes it."""
+    if synth_factory is None:
+        synth_factory = _standin_factory()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -356,7 +411,17 @@ def main(argv=None, synth_factory=None):
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the batch 1 / 8 legs (N=1 only)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-training", action="store_true", help="skip the training leg (N=1 only): generator train step and GAN iteration")
+    ap.add_argument("--no-nonar", action="store_true", help="skip the non-AR leg (N=1 only): BASELINE config 2, batch 1 / 8 / 64")
+    ap.add_argument("--no-gblock", action="store_true", help="skip the GBlockGenerator leg (N=1 only)")
     args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's command is a plain `python3 bench.py --gpus N ...`: become the launcher of N ranks (one process per GPU)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:] if argv is None else argv))
+
+    from articulatory_amd.utils.affinity import pin_rank
+
+    # N ranks must not share one OpenMP pool / core set; before torch starts any thread (RCCL's watchdog, OpenMP workers inherit the mask)
+    affinity = pin_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
 
     import numpy as np  # noqa: F401
     import torch
@@ -368,9 +433,6 @@ def main(argv=None, synth_factory=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     on_gpu = synth_factory is None
     if on_gpu:
@@ -394,10 +456,6 @@ def main(argv=None, synth_factory=None):
         ranks = dist.get_world_size()  # what the backend (RCCL under "nccl") actually formed, not what the environment promised
         if ranks != args.gpus and not (args.gpus == 1 and ranks == 1):
             raise SystemExit(f"--gpus {args.gpus} but the process group has {ranks} ranks")
-    from articulatory_amd.utils.affinity import pin_rank
-
-    affinity = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))  # N ranks must not share one OpenMP pool / core set
-
     params = dict(CAR_PARAMS)
     sd = synth_state_dict(params, seed=1234)
     g = None
@@ -543,6 +601,64 @@ def main(argv=None, synth_factory=None):
                 leg["roofline"] = roofline_block(stats, "bf16x3", te, args.steps, traffic_table)
             g.set_precision(args.precision)
         out["fast_bf16x3"] = leg
+
+    def secondary_leg(model, call, batch, macs, table_key, note, steps_leg, with_roofline=True):
+        """value + roofline of one more model / configuration on this GPU: 2 warm-up + `steps_leg` timed passes between device syncs, then an
+        event-bracketed pass of the same steps for the per-kernel table.  `call()` runs one pass over `batch` 10-s clips; `macs` = its MACs."""
+        with torch.no_grad():
+            dtl, _ = timed_steps(call, torch.cuda.synchronize, steps_leg, 2)
+            v = batch * T * HOP * steps_leg / dtl
+            tf = 2.0 * macs * steps_leg / dtl / 1e12
+            leg = {"batch": batch, "value": round(v, 1), "unit": "samples/s", "x_realtime": round(v / SAMPLING_RATE, 1), "steps": steps_leg, "warmup": 2,
+                   "ms_per_step": round(dtl / steps_leg * 1e3, 3), "algorithmic_tflops": round(tf, 2), "frac_of_mfma_peak": round(tf / PEAK_TFLOPS["f32"], 4)}
+            if note:
+                leg["note"] = note
+            if with_roofline and not args.no_roofline:
+                model.profile_begin()
+                te0 = time.perf_counter()
+                for _ in range(steps_leg):
+                    call()
+                stats = model.profile_end()
+                leg["roofline"] = roofline_block(stats, "f32", time.perf_counter() - te0, steps_leg, traffic_table, table_key=table_key)
+        return leg
+
+    if solo and args.precision == "f32" and not args.no_nonar:
+        # BASELINE config 2 / north_star's literal sweep: HiFi-GAN (non-AR) 12-dim EMA -> 16 kHz, one forward over whole 10-s clips
+        # (articulatory/models/hifigan.py:298-314 is the reference's per-utterance entry; batched here), batch 1 / 8 / 64, exact fp32
+        from articulatory_amd.models import HiFiGANGenerator as _G
+
+        np_params = dict(CAR_PARAMS, in_channels=12, use_ar=False)
+        gn = _G(**np_params, precision="f32")
+        gn.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(np_params, seed=1234).items()})
+        gn.remove_weight_norm()
+        gn = gn.eval().to(dev)
+        legs = []
+        for b in (1, 8, 64):
+            x12 = torch.from_numpy(synth_features(b, T, 12, seed=20260929 + 2)).permute(0, 2, 1).contiguous().to(dev)
+            legs.append(secondary_leg(gn, lambda: gn(x12), b, gn.macs(b, T), "nonar_f32", None, max(3, min(args.steps, 10 if b < 64 else 5)),
+                                      with_roofline=(b == 8)))
+        out["nonar"] = {"workload": "configs[1]: HiFi-GAN (non-AR) 12-dim EMA -> 16 kHz, 10 s clips, one forward per batch; `roofline` on batch 8 "
+                                    "(the configuration BASELINE.json names)", "dtype": "fp32", "batches": legs}
+        del gn
+
+    if solo and args.precision == "f32" and not args.no_gblock:
+        # the reference's other a2w generator (articulatory/models/gblock_gen.py:111-132) at its runnable shape: ten GBlocks, channels 512, x80,
+        # HiFi-CAR-shaped AR synthesis (13-dim features, chunk 25), exact fp32 only
+        from articulatory_amd.models import GBlockGenerator
+        from articulatory_amd.utils.synth import synth_gblock_state_dict
+
+        gb = GBlockGenerator(**GBLOCK_PARAMS)
+        gb.load_state_dict({k: torch.from_numpy(v) for k, v in synth_gblock_state_dict(GBLOCK_PARAMS, seed=1234).items()})
+        gb.remove_weight_norm()
+        gb = gb.eval().to(dev)
+        nchunk = T // args.chunk_frames
+        gmacs = gb.macs(B, args.chunk_frames) * nchunk + (gb.macs(B, T % args.chunk_frames) if T % args.chunk_frames else 0.0)
+        leg = secondary_leg(gb, lambda: gb.ar_synthesis(feats, args.chunk_frames), B, gmacs, "gblock_f32",
+                            "GBlockGenerator (g_scales 5,1,4,1,1,2,1,2,1,1, kernel 3, channels 512), AR synthesis at chunk 25", max(3, min(args.steps, 5)))
+        leg["workload"] = f"GBlockGenerator 13-dim pitch+EMA -> 16 kHz, batch {B}, {args.seconds:g} s clips, {nchunk} sequential chunks of {args.chunk_frames} frames"
+        leg["dtype"] = "fp32"
+        out["gblock"] = leg
+        del gb
 
     if solo and args.precision == "f32" and not args.no_training:
         out["training"] = training_leg(traffic_table=traffic_table)

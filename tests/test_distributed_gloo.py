@@ -108,6 +108,45 @@ def test_bench_main_world2_gloo(gather):
     assert abs(d["value"] - 2 * 2 * 50 * 80 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
 
 
+def test_bench_self_launches_its_ranks_like_the_driver_calls_it():
+    """The driver's bench command is a plain ``python3 bench.py --gpus N --steps K --warmup W`` (BENCH_rNN.json's `cmd`), no torchrun: with
+    N > 1 bench.py must start its own N ranks (torch.distributed.run on 127.0.0.1) and forward rank 0's single JSON line.  CPU / gloo stand-in
+    for the synthesis through the HIFICAR_BENCH_STANDIN test hook; everything else — argument parsing, the launcher, rendezvous, barriers,
+    MAX-over-ranks timing, the gather and its self-check — is the product code path."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="2", HIFICAR_BENCH_STANDIN=os.path.join(repo, "tests", "dev", "bench_gloo_worker.py") + ":factory")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--seconds", "0.25"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "utterance-sharded x2" and d["config"]["gather"] == "f32"
+    assert abs(d["value"] - 2 * 2 * 50 * 80 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    """A rank that dies must make the launcher exit non-zero (no JSON line, no hang)."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="2", HIFICAR_BENCH_STANDIN=os.path.join(repo, "tests", "dev", "bench_gloo_worker.py") + ":no_such_factory")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "1", "--seconds", "0.25"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=repo)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_shard_items_deals_by_length():
     items = [("a", 5), ("b", 50), ("c", 7), ("d", 40), ("e", 6), ("f", 45)]
     shares = [shard_items(items, 2, r, length_of=lambda kv: kv[1]) for r in range(2)]
