@@ -121,10 +121,18 @@ struct MultiConvParams {
 };
 
 #ifdef HIFICAR_TRACE
+// (dev builds only) s_memtime is a per-XCD shader-clock counter; the first and the last stamp of a workgroup's wave 0 additionally record
+// s_memrealtime (100 MHz, one time base for the whole device) so that a launch's span and the gap to the next launch can be measured
+__device__ unsigned long long g_trace_realtime[2][1024];
+__device__ unsigned long long g_trace_rt_slots[4][64];  // s_memrealtime of every stamp of wave 0 of workgroups 0 .. 3
 #define HIFICAR_STAMP(slot)                                                                            \
     do {                                                                                               \
         if (mp.trace && lane == 0 && (wave == 0 || wave == kFirstLoader) && (slot) < 64)               \
             mp.trace[((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        if (mp.trace && lane == 0 && wave == 0 && ((slot) == 0 || (slot) == 63) && blockIdx.x < 1024)  \
+            g_trace_realtime[(slot) == 63][blockIdx.x] = __builtin_amdgcn_s_memrealtime();             \
+        if (mp.trace && lane == 0 && wave == 0 && (slot) < 64 && blockIdx.x < 4)                       \
+            g_trace_rt_slots[blockIdx.x][(slot)] = __builtin_amdgcn_s_memrealtime();                   \
     } while (0)
 #else
 #define HIFICAR_STAMP(slot) do { } while (0)

@@ -1,0 +1,357 @@
+// Dev tool (round 5): the four-wave conv kernel (conv_f32w4_kernel, csrc/hificar_conv_w4.hip.h) against the shipped direct-output kernel
+// (conv_f32do_kernel) on stage-shaped three-branch launches — same inputs, same LPT tile schedule; outputs compared BIT FOR BIT, both timed.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_w4/conv_w4_bench.hip -o tools/conv_w4/conv_w4_bench.bin
+#include "../../articulatory_amd/csrc/hificar_kernels.hip.h"
+#include "hificar_conv_w4.hip.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <queue>
+#include <vector>
+using namespace hificar;
+
+struct Problem {
+    int nseq, L, C, nbr, ks[3], dil;
+    bool residual;  // conv2 form: residual + y + ys; else conv1 form: ys only
+    float *x = nullptr, *bias = nullptr;
+    char *xs = nullptr, *zeros = nullptr;
+    float* w[3] = {nullptr, nullptr, nullptr};
+    size_t n = 0;
+};
+
+static void make_problem(Problem& P) {
+    P.n = (size_t)P.nseq * P.L * P.C;
+    hipMalloc(&P.x, P.n * 4);
+    hipMalloc(&P.xs, P.n * 4);
+    hipMalloc(&P.zeros, 256);
+    hipMemset(P.zeros, 0, 256);
+    hipMalloc(&P.bias, P.C * 4);
+    std::vector<float> h(P.n);
+    unsigned st = 12345u;
+    for (size_t i = 0; i < P.n; ++i) { st = st * 1664525u + 1013904223u; h[i] = ((st >> 8) & 0xffff) / 32768.f - 1.f; }
+    hipMemcpy(P.xs, h.data(), P.n * 4, hipMemcpyHostToDevice);
+    for (size_t i = 0; i < P.n; ++i) { st = st * 1664525u + 1013904223u; h[i] = ((st >> 8) & 0xffff) / 32768.f - 1.f; }
+    hipMemcpy(P.x, h.data(), P.n * 4, hipMemcpyHostToDevice);
+    std::vector<float> hb(P.C);
+    for (int i = 0; i < P.C; ++i) { st = st * 1664525u + 1013904223u; hb[i] = (((st >> 8) & 0xffff) / 32768.f - 1.f) * 0.1f; }
+    hipMemcpy(P.bias, hb.data(), P.C * 4, hipMemcpyHostToDevice);
+    for (int b = 0; b < P.nbr; ++b) {
+        // fragment order [n_block32][chunk][tap][slab][half][lane][4]: any chunking of the same (block, tap, slab) set is a permutation — the
+        // harness fills the buffer with values keyed by its flat index, so BOTH kernels must be given packs built for their own chunk (below)
+        const size_t wel = ((size_t)(P.C / 32) * (P.C / 16) * P.ks[b] * 2 + 16) * 256;
+        hipMalloc(&P.w[b], wel * 4);
+    }
+}
+
+// weight value of (block nb, tap t, 16-channel slab s, half v, lane, j): independent of the K chunking
+static float wval(int b, int nb, int t, int s, int v, int lane, int j) {
+    unsigned k = (unsigned)((((((b * 64 + nb) * 16 + t) * 64 + s) * 2 + v) * 64 + lane) * 4 + j);
+    k = k * 2654435761u;
+    k ^= k >> 15;
+    return ((int)(k & 0xffff) - 32768) * (0.05f / 32768.f);
+}
+static void fill_weights(const Problem& P, int b, int nc16, float* dst) {
+    const int C = P.C, K = P.ks[b], nslab = C / 16, nchunk = nslab / nc16;
+    std::vector<float> h(((size_t)(C / 32) * nslab * K * 2 + 16) * 256, 0.f);
+    for (int nb = 0; nb < C / 32; ++nb)
+        for (int c = 0; c < nchunk; ++c)
+            for (int t = 0; t < K; ++t)
+                for (int u = 0; u < nc16; ++u)
+                    for (int v = 0; v < 2; ++v) {
+                        float* f = &h[((((((size_t)nb * nchunk + c) * K + t) * nc16 + u) * 2) + v) * 256];
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) f[lane * 4 + j] = wval(b, nb, t, c * nc16 + u, v, lane, j);
+                    }
+    hipMemcpy(dst, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+}
+
+static void lpt(const std::vector<double>& costs, int G, std::vector<int>& start, std::vector<int>& tiles) {
+    const int n = (int)costs.size();
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return costs[a] > costs[b]; });
+    std::vector<std::vector<int>> lists(G);
+    typedef std::pair<double, int> E;
+    std::priority_queue<E, std::vector<E>, std::greater<E>> heap;
+    for (int w = 0; w < G; ++w) heap.push({0.0, w});
+    for (int t : order) {
+        E e = heap.top();
+        heap.pop();
+        lists[e.second].push_back(t);
+        e.first += costs[t];
+        heap.push(e);
+    }
+    start.assign(G + 1, 0);
+    tiles.clear();
+    for (int w = 0; w < G; ++w) {
+        start[w] = (int)tiles.size();
+        for (auto r = lists[w].rbegin(); r != lists[w].rend(); ++r) tiles.push_back(*r);
+    }
+    start[G] = (int)tiles.size();
+}
+
+struct Result {
+    std::vector<float> y[3], ys[3];
+    float us = 0;
+};
+
+template <typename Kern>
+static Result launch(const Problem& P, Kern kern, int TM, int TNB, int nc16, int nthreads, size_t extra_lds, const char* label) {
+    Result R;
+    MultiConvParams mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.zrep = 1;
+    float *y[3], *ys[3];
+    int max_halo = 0;
+    double flops = 0;
+    for (int b = 0; b < P.nbr; ++b) {
+        hipMalloc(&y[b], P.n * 4);
+        hipMemset(y[b], 0xff, P.n * 4);
+        hipMalloc(&ys[b], P.n * 4);
+        hipMemset(ys[b], 0xff, P.n * 4);
+        fill_weights(P, b, nc16, P.w[b]);
+        const int K = P.ks[b], pad = (K - 1) / 2 * P.dil;
+        ConvParams& p = mp.p[b];
+        p.len_const = -1;
+        p.w16 = reinterpret_cast<const bf16x8*>(P.w[b]);
+        p.bias = P.bias;
+        p.res = P.residual ? P.x : nullptr;
+        p.y = P.residual ? y[b] : nullptr;
+        p.xs = P.xs;
+        p.ys = reinterpret_cast<char*>(ys[b]);
+        p.zeros = P.zeros;
+        p.slope_out = 0.1f;
+        p.cout_real = P.C;
+        p.L = P.L;
+        p.tiles_per_seq = (P.L + TM - 1) / TM;
+        p.cin = P.C;
+        p.cout_total = P.C;
+        p.n_blocks32 = P.C / 32;
+        p.nb32_per_phase = P.C / 32;
+        p.ntaps = K;
+        p.off_min = -pad;
+        p.halo = 2 * pad;
+        p.tap_step = P.dil;
+        p.tap_off0[0] = -pad;
+        max_halo = std::max(max_halo, p.halo);
+        flops += 2.0 * P.nseq * P.L * (double)P.C * P.C * K;
+    }
+    mp.n_branches = P.nbr;
+    mp.nseq_tiles = P.nseq * ((P.L + TM - 1) / TM);
+    mp.ngroups = (P.C / 32 + TNB - 1) / TNB;
+    mp.total_tiles = P.nbr * mp.ngroups * mp.nseq_tiles;
+    mp.buf_bytes = ((TM + max_halo) * (nc16 * 64) + 1023) / 1024 * 1024;
+    const int G = std::min(mp.total_tiles, 256);
+    int *d_start = nullptr, *d_tiles = nullptr;
+    if (mp.total_tiles > G) {
+        std::vector<double> costs((size_t)mp.total_tiles);
+        const int tpb = mp.ngroups * mp.nseq_tiles;
+        for (int b = 0; b < P.nbr; ++b)
+            for (int i = 0; i < tpb; ++i) costs[(size_t)b * tpb + i] = P.ks[b] + 1.0;
+        std::vector<int> st, tl;
+        lpt(costs, G, st, tl);
+        hipMalloc(&d_start, st.size() * 4);
+        hipMalloc(&d_tiles, tl.size() * 4);
+        hipMemcpy(d_start, st.data(), st.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(d_tiles, tl.data(), tl.size() * 4, hipMemcpyHostToDevice);
+        mp.sched_start = d_start;
+        mp.sched_tiles = d_tiles;
+    }
+    const size_t lds = 2 * (size_t)mp.buf_bytes + extra_lds;
+    if (lds > 160 * 1024) {
+        printf("%-44s LDS %zu KB: does not fit\n", label, lds / 1024);
+        R.us = -1;
+        return R;
+    }
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float ms = 0, best = 1e9;
+    {   // warm-up: the shader clock needs tens of ms of sustained load after an idle phase (host-side set-up) to reach its top state — 2.1 GHz in
+        // the first ~10 ms against 2.4 GHz later (measured with s_memtime against s_memrealtime) — so every measurement starts behind >= 60 ms of launches
+        hipEventRecord(e0);
+        float w = 0;
+        while (w < 60.f) {
+            for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3(nthreads), lds, 0, mp);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&w, e0, e1);
+        }
+    }
+    for (int it = 0; it < 4; ++it) {
+        hipEventRecord(e0);
+        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3(nthreads), lds, 0, mp);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        if (it) best = std::min(best, ms);
+    }
+    hipError_t err = hipDeviceSynchronize();
+    R.us = best * 100;
+    printf("%-44s tiles=%4d lds=%3zuKB  %7.1f us/launch  %6.1f TF-alg = %.3f of 157.3   %s\n", label, mp.total_tiles, lds / 1024, R.us, flops / (R.us * 1e-6) / 1e12,
+           flops / (R.us * 1e-6) / 1e12 / 157.3, err == hipSuccess ? "" : hipGetErrorString(err));
+#ifdef HIFICAR_TRACE
+    {   // three more launches back to back with the stamps on; s_memrealtime (100 MHz, device-wide) of every workgroup's first and last stamp
+        unsigned long long* trace;
+        hipMalloc(&trace, (size_t)G * 2 * 64 * 8);
+        hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
+        mp.trace = trace;
+        std::vector<unsigned long long> rt[3];
+        for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3(nthreads), lds, 0, mp);
+        hipDeviceSynchronize();
+        // (the three launches overwrite each other's stamps: the arrays hold the LAST launch; run them one at a time for the gaps)
+        std::vector<unsigned long long> ends_prev;
+        for (int r = 0; r < 3; ++r) {
+            hipLaunchKernelGGL(kern, dim3(G), dim3(nthreads), lds, 0, mp);
+        }
+        hipDeviceSynchronize();
+        unsigned long long hrt[2][1024];
+        hipMemcpyFromSymbol(hrt, HIP_SYMBOL(g_trace_realtime), sizeof(hrt));
+        unsigned long long s_min = ~0ull, s_max = 0, e_min = ~0ull, e_max = 0;
+        std::vector<double> dur;
+        for (int w = 0; w < G; ++w) {
+            s_min = std::min(s_min, hrt[0][w]); s_max = std::max(s_max, hrt[0][w]);
+            e_min = std::min(e_min, hrt[1][w]); e_max = std::max(e_max, hrt[1][w]);
+            dur.push_back((double)(hrt[1][w] - hrt[0][w]) * 0.01);
+        }
+        std::sort(dur.begin(), dur.end());
+        printf("    realtime: span %.2f us (first start -> last end); starts spread over %.2f us, ends over %.2f us; per-workgroup duration min %.2f med %.2f max %.2f us\n",
+               (e_max - s_min) * 0.01, (s_max - s_min) * 0.01, (e_max - e_min) * 0.01, dur.front(), dur[dur.size() / 2], dur.back());
+        std::vector<unsigned long long> ht((size_t)G * 2 * 64);
+        hipMemcpy(ht.data(), trace, ht.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long hs[4][64];
+        hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_trace_rt_slots), sizeof(hs));
+        for (int wg : {0}) {
+            const unsigned long long* m = &ht[(size_t)wg * 128];
+            printf("    WG %3d wave 0 [slot: shader ticks | us | GHz over the segment]: ", wg);
+            int prev = 0;
+            for (int i = 1; i < 64; ++i)
+                if (m[i] && hs[wg][i]) {
+                    const double us = (hs[wg][i] - hs[wg][prev]) * 0.01, tk = (double)(m[i] - m[prev]);
+                    printf("%d:%llu|%.2f|%.2f ", i, m[i] - m[0], (hs[wg][i] - hs[wg][0]) * 0.01, us > 0.5 ? tk / us * 1e-3 : 0.0);
+                    prev = i;
+                }
+            printf("\n");
+        }
+        hipFree(trace);
+        mp.trace = nullptr;
+    }
+#endif
+    for (int b = 0; b < P.nbr; ++b) {
+        R.y[b].resize(P.n);
+        R.ys[b].resize(P.n);
+        hipMemcpy(R.y[b].data(), y[b], P.n * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(R.ys[b].data(), ys[b], P.n * 4, hipMemcpyDeviceToHost);
+        hipFree(y[b]);
+        hipFree(ys[b]);
+    }
+    if (d_start) hipFree(d_start);
+    if (d_tiles) hipFree(d_tiles);
+    return R;
+}
+
+static void compare(const Problem& P, const Result& a, const Result& b, const char* what) {
+    if (a.us < 0 || b.us < 0) return;
+    size_t bad = 0, first = 0;
+    for (int br = 0; br < P.nbr; ++br) {
+        if (P.residual && memcmp(a.y[br].data(), b.y[br].data(), P.n * 4)) {
+            for (size_t i = 0; i < P.n; ++i)
+                if (memcmp(&a.y[br][i], &b.y[br][i], 4)) { if (!bad) first = i; ++bad; }
+        }
+        if (memcmp(a.ys[br].data(), b.ys[br].data(), P.n * 4)) {
+            for (size_t i = 0; i < P.n; ++i)
+                if (memcmp(&a.ys[br][i], &b.ys[br][i], 4)) { if (!bad) first = i; ++bad; }
+        }
+    }
+    if (bad) printf("    !!! %s: %zu elements differ (first at %zu: row %zu ch %zu)\n", what, bad, first, first / P.C, first % P.C);
+    else printf("    %s: bit-identical to the reference kernel, %.1f -> %.1f us (%+.1f %%)\n", what, a.us, b.us, 100.0 * (a.us / b.us - 1.0));
+}
+
+template <int MI, int WM, int WN, int NC16>
+static Result ref(const Problem& P, const char* label) {
+    return launch(P, conv_f32do_kernel<MI, WM, WN, NC16>, WM * MI * 32, WN, NC16, (WM * WN + 4) * 64, 0, label);
+}
+template <int MI, int WM, int WN, int NB, int NC16, bool PIPE>
+static Result w4(const Problem& P, const char* label) {
+    if (P.residual) return launch(P, conv_f32w4_kernel<MI, WM, WN, NB, NC16, PIPE, true>, WM * MI * 32, WN * NB, NC16, 256, 0, label);
+    return launch(P, conv_f32w4_kernel<MI, WM, WN, NB, NC16, PIPE, false>, WM * MI * 32, WN * NB, NC16, 256, 0, label);
+}
+
+int main(int argc, char** argv) {
+    const char* which = argc > 1 ? argv[1] : "all";
+    for (int residual = 0; residual < 2; ++residual) {
+        const char* form = residual ? "conv2+res" : "conv1";
+        if (!strcmp(which, "all") || !strcmp(which, "s1")) {  // stage 1 of HiFi-CAR at batch 64 x 25 frames: C = 128, 500 rows per sequence
+            Problem P{64, 500, 128, 3, {11, 7, 3}, 1, residual != 0};
+            make_problem(P);
+            printf("---- stage 1 (C = 128, 64 x 500 rows) %s\n", form);
+            const Result r0 = ref<4, 1, 4, 4>(P, "do<4,1,4,4> 128x128 (shipped)");
+            compare(P, r0, w4<4, 1, 4, 1, 4, false>(P, "w4<4,1,4,NB1,64ch> 128x128"), "w4 NB1");
+            compare(P, r0, w4<4, 1, 4, 1, 4, true>(P, "w4<4,1,4,NB1,64ch,PIPE> 128x128"), "w4 NB1 PIPE");
+            compare(P, r0, w4<4, 2, 2, 2, 4, false>(P, "w4<4,2,2,NB2,64ch> 256x128"), "w4 NB2");
+            compare(P, r0, w4<4, 2, 2, 2, 2, false>(P, "w4<4,2,2,NB2,32ch> 256x128"), "w4 NB2 32ch");
+            compare(P, r0, w4<4, 2, 2, 2, 2, true>(P, "w4<4,2,2,NB2,32ch,PIPE> 256x128"), "w4 NB2 32ch PIPE");
+        }
+        if (!strcmp(which, "all") || !strcmp(which, "s2")) {  // stage 2: C = 64, 1000 rows
+            Problem P{64, 1000, 64, 3, {11, 7, 3}, 1, residual != 0};
+            make_problem(P);
+            printf("---- stage 2 (C = 64, 64 x 1000 rows) %s\n", form);
+            const Result r0 = ref<4, 2, 2, 2>(P, "do<4,2,2,2> 256x64 (shipped)");
+            compare(P, r0, w4<4, 2, 2, 1, 2, false>(P, "w4<4,2,2,NB1,32ch> 256x64"), "w4 NB1");
+            compare(P, r0, w4<4, 2, 2, 1, 2, true>(P, "w4<4,2,2,NB1,32ch,PIPE> 256x64"), "w4 NB1 PIPE");
+            compare(P, r0, w4<4, 2, 2, 1, 4, true>(P, "w4<4,2,2,NB1,64ch,PIPE> 256x64"), "w4 NB1 64ch PIPE");
+            compare(P, r0, w4<4, 4, 1, 2, 2, false>(P, "w4<4,4,1,NB2,32ch> 512x64"), "w4 NB2");
+            compare(P, r0, w4<4, 4, 1, 2, 2, true>(P, "w4<4,4,1,NB2,32ch,PIPE> 512x64"), "w4 NB2 PIPE");
+        }
+        if (!strcmp(which, "all") || !strcmp(which, "s0")) {  // stage 0: C = 256, 125 rows
+            Problem P{64, 125, 256, 3, {11, 7, 3}, 1, residual != 0};
+            make_problem(P);
+            printf("---- stage 0 (C = 256, 64 x 125 rows) %s\n", form);
+            const Result r0 = ref<4, 1, 4, 4>(P, "do<4,1,4,4> 128x128 (shipped)");
+            compare(P, r0, w4<4, 1, 4, 1, 4, false>(P, "w4<4,1,4,NB1,64ch> 128x128"), "w4 NB1");
+            compare(P, r0, w4<4, 1, 4, 1, 4, true>(P, "w4<4,1,4,NB1,64ch,PIPE> 128x128"), "w4 NB1 PIPE");
+        }
+        if (!strcmp(which, "scale")) {  // launch time against the number of sequences: the intercept is a launch's fixed cost
+            for (int nseq : {32, 64, 128, 256}) {
+                Problem P{nseq, 500, 128, 3, {11, 7, 3}, 1, residual != 0};
+                make_problem(P);
+                printf("---- stage 1 (C = 128, %d x 500 rows) %s\n", nseq, form);
+                const Result r0 = ref<4, 1, 4, 4>(P, "do<4,1,4,4> 128x128 (shipped)");
+                compare(P, r0, w4<4, 2, 2, 2, 4, false>(P, "w4<4,2,2,NB2,64ch> 256x128"), "w4 NB2");
+            }
+            for (int nseq : {32, 64, 128, 256}) {
+                Problem P{nseq, 125, 256, 3, {11, 7, 3}, 1, residual != 0};
+                make_problem(P);
+                printf("---- stage 0 (C = 256, %d x 125 rows) %s\n", nseq, form);
+                ref<4, 1, 4, 4>(P, "do<4,1,4,4> 128x128 (shipped)");
+            }
+            for (int nseq : {32, 64, 128, 256}) {
+                Problem P{nseq, 1000, 64, 3, {11, 7, 3}, 1, residual != 0};
+                make_problem(P);
+                printf("---- stage 2 (C = 64, %d x 1000 rows) %s\n", nseq, form);
+                ref<4, 2, 2, 2>(P, "do<4,2,2,2> 256x64 (shipped)");
+            }
+        }
+        if (!strcmp(which, "trace")) {
+            for (int nseq : {64, 256}) {
+                Problem P{nseq, 500, 128, 3, {11, 7, 3}, 1, residual != 0};
+                make_problem(P);
+                printf("---- stage 1 (C = 128, %d x 500 rows) %s\n", nseq, form);
+                ref<4, 1, 4, 4>(P, "do<4,1,4,4> 128x128 (shipped)");
+                w4<4, 2, 2, 2, 4, false>(P, "w4<4,2,2,NB2,64ch> 256x128");
+            }
+        }
+        if (!strcmp(which, "all") || !strcmp(which, "long")) {  // non-AR shape: stage 0 on 10-s clips, batch 8 (C = 256, 10000 rows)
+            Problem P{8, 10000, 256, 3, {11, 7, 3}, 1, residual != 0};
+            make_problem(P);
+            printf("---- stage 0, long sequences (C = 256, 8 x 10000 rows) %s\n", form);
+            const Result r0 = ref<4, 1, 4, 4>(P, "do<4,1,4,4> 128x128 (shipped)");
+            compare(P, r0, w4<4, 1, 4, 1, 4, true>(P, "w4<4,1,4,NB1,64ch,PIPE> 128x128"), "w4 NB1 PIPE");
+            compare(P, r0, w4<4, 2, 2, 2, 4, false>(P, "w4<4,2,2,NB2,64ch> 256x128"), "w4 NB2");
+            compare(P, r0, w4<4, 2, 2, 2, 2, true>(P, "w4<4,2,2,NB2,32ch,PIPE> 256x128"), "w4 NB2 32ch PIPE");
+        }
+    }
+    return 0;
+}
