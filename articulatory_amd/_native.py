@@ -447,6 +447,35 @@ def make_config(params: dict, precision: int) -> HificarConfig:
     return cfg
 
 
+# what hificar_gblock_create accepts (csrc/hificar_gblock.hip.inc); GBlockGenerator.__init__ checks the same numbers so that an unsupported
+# configuration fails at construction, not at the first forward on the device
+GBLOCK_MAX_KERNEL = 11   # odd g_kernel_sizes up to this (the dilation-27 conv's halo against the LDS)
+GBLOCK_MAX_SCALE = 64
+GBLOCK_MAX_CONV_KERNEL = 16  # input / output conv kernel_size (kMaxTaps)
+
+
+def check_gblock_params(params: dict):
+    """ValueError for a configuration libhificar's GBlock engine rejects (the reference's own limits are checked by the class)."""
+    if params["out_channels"] != 1:
+        raise ValueError(f"out_channels={params['out_channels']} unsupported (1 only)")
+    if params["kernel_size"] > GBLOCK_MAX_CONV_KERNEL:
+        raise ValueError(f"kernel_size={params['kernel_size']} > {GBLOCK_MAX_CONV_KERNEL}")
+    if params["channels"] // 8 < 1:
+        raise ValueError(f"channels={params['channels']} leaves no channels for the last GBlocks")
+    for i, (s, k) in enumerate(zip(params["g_scales"], params["g_kernel_sizes"])):
+        if k > GBLOCK_MAX_KERNEL:
+            raise ValueError(f"g_kernel_sizes[{i}]={k} > {GBLOCK_MAX_KERNEL} (the dilation-27 conv's halo must fit the LDS tiles)")
+        if not 1 <= s <= GBLOCK_MAX_SCALE:
+            raise ValueError(f"g_scales[{i}]={s} out of range (1 .. {GBLOCK_MAX_SCALE})")
+    if params.get("use_ar"):
+        if params["ar_input"] < 1 or params["ar_input"] > 1024 or params["ar_hidden"] > 512 or params["ar_output"] > 512:
+            raise ValueError("PastFCEncoder: ar_input must be 1 .. 1024, ar_hidden / ar_output <= 512")
+        if params["ar_hidden"] % 4 or params["ar_output"] % 4:
+            raise ValueError("PastFCEncoder hidden / output dims must be multiples of 4")
+    if params.get("use_spk_id") and (not params.get("num_spk") or (params.get("spk_emb_size") or 0) < 1 or params["in_channels"] > 1024):
+        raise ValueError("use_spk_id needs num_spk and spk_emb_size (and in_channels <= 1024)")
+
+
 def make_gblock_config(params: dict, precision: int) -> HificarGBlockConfig:
     """generator_params of a GBlockGenerator (reference keyword names) -> hificar_gblock_config."""
     cfg = HificarGBlockConfig()

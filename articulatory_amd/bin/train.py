@@ -43,9 +43,10 @@ class WindowCollater:
     (distinct per worker, and per epoch because torch draws a new base seed for every iterator): copies of one parent generator would
     otherwise all replay the same draws."""
 
-    def __init__(self, batch_max_steps, hop_size, ar_len=None, rng=None, seed=None):
+    def __init__(self, batch_max_steps, hop_size, ar_len=None, rng=None, seed=None, use_spk_id=False, use_ph=False):
         assert batch_max_steps % hop_size == 0
         self.batch_max_steps, self.hop_size, self.ar_len = batch_max_steps, hop_size, ar_len
+        self.use_spk_id, self.use_ph = use_spk_id, use_ph  # SpeechCollater's flags (train.py:914-915): items then carry a dict with these keys
         self.batch_max_frames = batch_max_steps // hop_size
         self.seed = seed
         self.rng = rng or np.random.default_rng(seed)
@@ -59,13 +60,17 @@ class WindowCollater:
         return self.rng
 
     def __call__(self, items):
-        """items: [(audio (T,), feats (frames, C))] -> {"x": (B, C, frames), "y": (B, 1, T), "ar": (B, 1, ar_len)}."""
+        """items: [(audio (T,), feats (frames, C))] or [(audio, feats, {"spk_id": int, "ph": (frames,) ints})]
+        -> {"x": (B, C, frames), "y": (B, 1, T), "ar": (B, 1, ar_len), "spk_id": (B,) long, "ph": (B, frames) long}.
+
+        ``ph`` is cut with the window's FRAME starts, exactly like the features (train.py:1028-1031, aux_context_window 0); ``spk_id`` rides
+        along (train.py:990-998)."""
         rng = self._generator()
-        items = [(a, c[: len(a) // self.hop_size]) for a, c in items]
-        items = [(a, c) for a, c in items if len(c) > self.batch_max_frames]
+        items = [(it[0], it[1][: len(it[0]) // self.hop_size], it[2] if len(it) > 2 else {}) for it in items]
+        items = [it for it in items if len(it[1]) > self.batch_max_frames]
         if not items:
             raise ValueError(f"no utterance of the batch is longer than the window ({self.batch_max_frames} frames)")
-        audios, feats = zip(*items)
+        audios, feats, extras = zip(*items)
         starts = np.array([rng.integers(0, len(c) - self.batch_max_frames) for c in feats])
         wav_starts = starts * self.hop_size
         y = np.stack([a[s:s + self.batch_max_steps] for a, s in zip(audios, wav_starts)])
@@ -77,14 +82,52 @@ class WindowCollater:
                 ar = a[max(0, s - self.ar_len):s]
                 ars.append(np.pad(ar, (self.ar_len - len(ar), 0), "constant"))
             batch["ar"] = torch.from_numpy(np.stack(ars).astype(np.float32)).unsqueeze(1)
+        if self.use_spk_id:
+            batch["spk_id"] = torch.tensor([int(e["spk_id"]) for e in extras], dtype=torch.long)
+        if self.use_ph:
+            for e, c in zip(extras, feats):
+                if len(e["ph"]) < len(c):
+                    raise ValueError(f"a phoneme sequence of {len(e['ph'])} frames for {len(c)} feature frames")
+            batch["ph"] = torch.from_numpy(np.stack([np.asarray(e["ph"])[s:s + self.batch_max_frames] for e, s in zip(extras, starts)]).astype(np.int64))
         return batch
+
+
+class Conditioning:
+    """Per-utterance conditioning of the reference's SpeechDataset (audio_mel_dataset.py:403-461, 513-519): ``utt2spk`` (``utt spk`` lines;
+    speaker ids are the ranks in the sorted speaker list, or in ``spks`` when a dev set re-uses the training set's list) and ``ph.scp``
+    (``utt path.npy`` lines: one phoneme index per feature frame)."""
+
+    def __init__(self, utt2spk=None, ph_scp=None, spks=None):
+        def read(p):
+            with open(p) as f:
+                return dict(line.split(None, 1) for line in f.read().splitlines() if line.strip())
+
+        self.utt2spk = {k: v.strip() for k, v in read(utt2spk).items()} if utt2spk else None
+        self.spks = list(spks) if spks is not None else (sorted(set(self.utt2spk.values())) if self.utt2spk else None)
+        self.spk2id = {s: i for i, s in enumerate(self.spks)} if self.spks is not None else None
+        if self.utt2spk is not None:
+            assert all(s in self.spk2id for s in self.utt2spk.values()), "utt2spk names a speaker that is not in the speaker list"
+        self.ph = {k: v.strip() for k, v in read(ph_scp).items()} if ph_scp else None
+
+    def known(self, utt):
+        return (self.utt2spk is None or utt in self.utt2spk) and (self.ph is None or utt in self.ph)
+
+    def extras(self, utt, frames):
+        e = {}
+        if self.utt2spk is not None:
+            e["spk_id"] = self.spk2id[self.utt2spk[utt]]
+        if self.ph is not None:
+            e["ph"] = np.asarray(np.load(self.ph[utt])).reshape(-1)[:frames]
+        return e
 
 
 class NpyPairs(torch.utils.data.Dataset):
     """(audio, features) pairs from two ``utt value`` scp files (values as articulatory_amd/utils/scp.py reads them); utterances shorter than the window are dropped
     (remove_short_samples, audio_mel_dataset.py of the reference)."""
 
-    def __init__(self, audio_scp, feats_scp, hop_size, min_frames):
+    def __init__(self, audio_scp, feats_scp, hop_size, min_frames, cond=None):
+        self.cond = cond
+
         def read(p):
             with open(p) as f:
                 return dict(line.split(None, 1) for line in f.read().splitlines() if line.strip())
@@ -95,10 +138,12 @@ class NpyPairs(torch.utils.data.Dataset):
         a, c = read(audio_scp), read(feats_scp)
         self.items = []
         for utt in sorted(set(a) & set(c)):
+            if cond is not None and not cond.known(utt):
+                continue
             v = c[utt].strip()
             frames = np.load(v, mmap_mode="r").shape[0] if v.endswith(".npy") else self._load(v, "feats").shape[0]
             if frames > min_frames:  # (strictly longer than the window: audio_mel_dataset.py:57-80 keeps lengths > threshold)
-                self.items.append((a[utt].strip(), v))
+                self.items.append((a[utt].strip(), v, utt))
         self.hop_size = hop_size
 
     def __len__(self):
@@ -108,6 +153,8 @@ class NpyPairs(torch.utils.data.Dataset):
         audio = np.asarray(self._load(self.items[i][0], "wave"), np.float32).reshape(-1)
         feats = np.asarray(self._load(self.items[i][1], "feats"), np.float32)
         n = min(len(audio) // self.hop_size, len(feats))
+        if self.cond is not None:
+            return audio[: n * self.hop_size], feats[:n], self.cond.extras(self.items[i][2], n)
         return audio[: n * self.hop_size], feats[:n]
 
 
@@ -115,8 +162,10 @@ class DumpDirPairs(torch.utils.data.Dataset):
     """The reference's dump directory (AudioMelDataset, articulatory/datasets/audio_mel_dataset.py as set up at train.py:1530-1570):
     ``format: hdf5`` -> ``<utt>.h5`` files with "wave" and "feats" datasets; ``format: npy`` -> ``<utt>-wave.npy`` + ``<utt>-feats.npy``."""
 
-    def __init__(self, dumpdir, fmt, hop_size, min_frames):
+    def __init__(self, dumpdir, fmt, hop_size, min_frames, cond=None):
         import glob
+
+        self.cond = cond
 
         from articulatory_amd.utils.hdf5 import read_hdf5
 
@@ -129,8 +178,10 @@ class DumpDirPairs(torch.utils.data.Dataset):
             self.load = lambda f: (np.load(f), np.load(f.replace("-wave.npy", "-feats.npy")))
         else:
             raise ValueError("support only hdf5 or npy format.")
+        # utterance id = the file's base name without its suffix (audio_mel_dataset.py:382-389)
+        self.utt_of = lambda f: os.path.basename(f)[: -len("-wave.npy")] if fmt == "npy" else os.path.splitext(os.path.basename(f))[0]
         self.files = [f for f in files if (read_hdf5(f, "feats") if fmt == "hdf5" else np.load(f.replace("-wave.npy", "-feats.npy"), mmap_mode="r")).shape[0]
-                      > min_frames]
+                      > min_frames and (cond is None or cond.known(self.utt_of(f)))]
 
     def __len__(self):
         return len(self.files)
@@ -139,14 +190,19 @@ class DumpDirPairs(torch.utils.data.Dataset):
         audio, feats = self.load(self.files[i])
         audio, feats = np.asarray(audio, np.float32).reshape(-1), np.asarray(feats, np.float32)
         n = min(len(audio) // self.hop_size, len(feats))
+        if self.cond is not None:
+            return audio[: n * self.hop_size], feats[:n], self.cond.extras(self.utt_of(self.files[i]), n)
         return audio[: n * self.hop_size], feats[:n]
 
 
 class SyntheticPairs(torch.utils.data.Dataset):
-    def __init__(self, n, frames, dims, hop_size, seed=0):
+    def __init__(self, n, frames, dims, hop_size, seed=0, num_spk=0, num_ph=0):
         rng = np.random.default_rng(seed)
         self.items = [((rng.standard_normal(frames * hop_size) * 0.1).astype(np.float32), rng.standard_normal((frames, dims)).astype(np.float32))
                       for _ in range(n)]
+        if num_spk or num_ph:  # random speakers / frame-level phoneme indices (conditioned recipes)
+            self.items = [it + ({**({"spk_id": int(rng.integers(0, num_spk))} if num_spk else {}),
+                                 **({"ph": rng.integers(0, num_ph, size=frames)} if num_ph else {})},) for it in self.items]
 
     def __len__(self):
         return len(self.items)
@@ -208,13 +264,13 @@ class Trainer:
 
     # ------------------------------------------------------------------ one iteration (train.py:241-440)
     def _check_conditioning(self, batch):
-        """The reference's collaters slice ``ph`` with the windows' frame starts and pass ``spk_id`` along (train.py:1029-1032, 248-249); the
-        datasets of this package (NpyPairs / DumpDirPairs / SyntheticPairs) carry neither, so a conditioned generator needs a caller-built batch."""
+        """The reference's collaters slice ``ph`` with the windows' frame starts and pass ``spk_id`` along (train.py:1029-1032, 248-249);
+        WindowCollater does the same when built with ``use_spk_id`` / ``use_ph`` over datasets that carry the side tables (``Conditioning``)."""
         gp = self.config["generator_params"]
         need = [k for k, on in (("spk_id", gp.get("use_spk_id", False)), ("ph", gp.get("use_ph", False) or self.use_ph_loss)) if on and k not in batch]
         if need:
             raise ValueError(f"the generator is conditioned on {' / '.join(need)} (generator_params) but the batch has no such entry: "
-                             f"batch keys {sorted(batch)}.  WindowCollater and this package's datasets do not produce it; build the batch yourself "
+                             f"batch keys {sorted(batch)}.  build WindowCollater with use_spk_id / use_ph over a dataset with a Conditioning table, or add the entries yourself "
                              "(ph: (B, frames) indices sliced with the window's frame starts, spk_id: (B,))")
 
     def train_step(self, batch):
@@ -450,7 +506,8 @@ def hop_of(config):
 
 def feature_dims(config):
     gp = config["generator_params"]
-    return gp["in_channels"] - (gp.get("ar_output", 0) if gp.get("use_ar", False) else 0)
+    # (the phoneme embeddings are appended to the input rows inside the generator, hifigan.py:217-220: they are not feature columns)
+    return gp["in_channels"] - (gp.get("ar_output", 0) if gp.get("use_ar", False) else 0) - (gp.get("ph_emb_size", 0) if gp.get("use_ph", False) else 0)
 
 
 def main(argv=None):
@@ -462,6 +519,10 @@ def main(argv=None):
     ap.add_argument("--train-dumpdir", help="dump directory of <utt>.h5 (wave + feats) or <utt>-wave.npy / <utt>-feats.npy files (config: format)")
     ap.add_argument("--dev-dumpdir", help="dev-set dump directory: evaluated every eval_interval_steps (rank 0)")
     ap.add_argument("--synthetic", type=int, default=0, help="train on this many random utterances instead of a dataset")
+    ap.add_argument("--utt2spk", help="'utt spk' lines (use_spk_id: speaker ids are ranks in the sorted speaker list)")
+    ap.add_argument("--ph-scp", help="'utt path.npy' lines: one phoneme index per feature frame (use_ph / use_ph_loss)")
+    ap.add_argument("--dev-utt2spk", help="the dev set's utt2spk (default: --utt2spk); speaker ids follow the training set's list")
+    ap.add_argument("--dev-ph-scp", help="the dev set's ph.scp (default: --ph-scp)")
     ap.add_argument("--resume", default="")
     ap.add_argument("--max-steps", type=int, default=None, help="override train_max_steps")
     ap.add_argument("--verbose", type=int, default=1)
@@ -490,30 +551,41 @@ def main(argv=None):
     frames = config["batch_max_steps"] // hop
     gp = config["generator_params"]
     ar_len = gp.get("ar_input") if gp.get("use_ar", False) else None
-    if gp.get("use_spk_id", False) or gp.get("use_ph", False) or gp.get("use_ph_loss", False):
-        # the reference's collaters slice ph with the windows' starts and carry spk_id (train.py:1029-1032); the datasets below hold neither
-        raise NotImplementedError("articulatory-train: speaker / phoneme conditioned generators (use_spk_id / use_ph / use_ph_loss) need batches with "
-                                  "'spk_id' / 'ph' entries, which this package's datasets and WindowCollater do not produce; drive Trainer.train_step "
-                                  "with your own batches")
+    # conditioned generators (train.py:1574-1576): spk_id per utterance, ph per frame, sliced with the windows by the collater
+    use_spk_id = bool(gp.get("use_spk_id", False))
+    use_ph = bool(gp.get("use_ph", False) or gp.get("use_ph_loss", False))
+    cond = dev_cond = None
+    if (use_spk_id or use_ph) and not a.synthetic:
+        if use_spk_id and not a.utt2spk:
+            raise SystemExit("generator_params.use_spk_id needs --utt2spk (the reference reads data/<stage>/utt2spk, audio_mel_dataset.py:412-419)")
+        if use_ph and not a.ph_scp:
+            raise SystemExit("generator_params.use_ph / use_ph_loss need --ph-scp (the reference reads data/<stage>/ph.scp, audio_mel_dataset.py:450-461)")
+        cond = Conditioning(a.utt2spk if use_spk_id else None, a.ph_scp if use_ph else None)
+        if use_spk_id and len(cond.spks) != gp["num_spk"]:  # train.py:1584-1585
+            raise SystemExit(f"{len(cond.spks)} speakers in {a.utt2spk} but generator_params.num_spk = {gp['num_spk']}")
+        if a.dev_dumpdir:
+            dev_cond = Conditioning((a.dev_utt2spk or a.utt2spk) if use_spk_id else None, (a.dev_ph_scp or a.ph_scp) if use_ph else None, spks=cond.spks)
     if a.synthetic:
-        data = SyntheticPairs(a.synthetic, 4 * frames, feature_dims(config), hop, seed=rank)
+        data = SyntheticPairs(a.synthetic, 4 * frames, feature_dims(config), hop, seed=rank, num_spk=gp.get("num_spk") if use_spk_id else 0,
+                              num_ph=gp.get("num_ph") if use_ph else 0)
     elif a.train_dumpdir:
-        data = DumpDirPairs(a.train_dumpdir, config.get("format", "hdf5"), hop, frames)
+        data = DumpDirPairs(a.train_dumpdir, config.get("format", "hdf5"), hop, frames, cond)
     else:
         if not (a.audio_scp and a.feats_scp):
             raise SystemExit("give --train-dumpdir, or --audio-scp and --feats-scp, or --synthetic N")
-        data = NpyPairs(a.audio_scp, a.feats_scp, hop, frames)
+        data = NpyPairs(a.audio_scp, a.feats_scp, hop, frames, cond)
     sampler = torch.utils.data.distributed.DistributedSampler(data, world, rank, shuffle=True) if world > 1 else None
     loader = torch.utils.data.DataLoader(data, batch_size=config["batch_size"], shuffle=sampler is None, sampler=sampler, drop_last=True,
-                                         collate_fn=WindowCollater(config["batch_max_steps"], hop, ar_len, seed=1234 + rank),
+                                         collate_fn=WindowCollater(config["batch_max_steps"], hop, ar_len, seed=1234 + rank, use_spk_id=use_spk_id, use_ph=use_ph),
                                          num_workers=config.get("num_workers", 0), pin_memory=config.get("pin_memory", False))
     if len(loader) == 0:
         raise SystemExit(f"fewer utterances ({len(data)}) than one batch ({config['batch_size']})")
     dev_loader = None
     if a.dev_dumpdir and rank == 0:
-        dev = DumpDirPairs(a.dev_dumpdir, config.get("format", "hdf5"), hop, frames)
+        dev = DumpDirPairs(a.dev_dumpdir, config.get("format", "hdf5"), hop, frames, dev_cond)
         dev_loader = torch.utils.data.DataLoader(dev, batch_size=config["batch_size"], shuffle=False, drop_last=False,
-                                                 collate_fn=WindowCollater(config["batch_max_steps"], hop, ar_len, np.random.default_rng(4321)))
+                                                 collate_fn=WindowCollater(config["batch_max_steps"], hop, ar_len, np.random.default_rng(4321),
+                                                                           use_spk_id=use_spk_id, use_ph=use_ph))
     trainer = Trainer(config, device, distributed=world > 1)
     if a.resume:
         trainer.load_checkpoint(a.resume)

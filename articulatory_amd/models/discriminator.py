@@ -465,6 +465,25 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         c.p_slope = _slope(p["period_discriminator_params"])
         return c
 
+    # copy.deepcopy / pickle build a module without running __init__ (see _NativeGenerator): the engine handle, the cached tapes / parameter
+    # lists / side stream and the gradient-sync wiring stay behind; the copy registers with the optimizer post-step hook itself
+    _EPHEMERAL = ("_handle", "_lib", "_grad_sync", "_info_cache", "_sent_sig", "_real_cache", "_early_real", "_gside_done", "_raw_cache", "_early_stream")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._EPHEMERAL:
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        d = self.__dict__
+        d["_handle"] = d["_lib"] = d["_grad_sync"] = None
+        d["_info_cache"] = {}
+        from ..utils.optim_hook import watch
+
+        watch(self)
+
     def _native_handle(self):
         if self._handle is None:
             dev = next(self.parameters()).device

@@ -9,7 +9,11 @@ include/hificar.h): no PyTorch-operator implementation, no CPU fallback.
 
 Which configurations exist.  The reference class only RUNS with ten (or nine) GBlocks and odd ``g_kernel_sizes`` — its defaults
 (four even-sized GBlocks) fail in ``forward`` (oracle/make_golden_gblock.py's header has the details).  This class accepts exactly the
-configurations the reference can run and raises ``ValueError`` at construction for the others instead of failing in ``forward``.
+configurations the reference can run and raises ``ValueError`` at construction for the others instead of failing in ``forward`` — and
+likewise for what libhificar's engine does not take (``_native.check_gblock_params``: ``g_kernel_sizes`` above 11, ``g_scales`` above 64,
+``out_channels`` other than 1, PastFCEncoder widths).  ``g_kernel_sizes`` 9 and 11 run in inference; their dilation-27 conv's weight gradient
+does not fit the LDS staging, so training such a model raises at the first backward.  One arithmetic, exact fp32 (``HIFICAR_PRECISION`` is not
+consulted).
 """
 
 import ctypes
@@ -75,9 +79,10 @@ class GBlockGenerator(_NativeGenerator):
             raise ValueError("g_kernel_sizes must be odd: with an even kernel a GBlock's main path loses samples against its residual path in the "
                              "reference (pytorch_layers.py:24-29, 85-91)")
         if precision is None:
-            precision = os.environ.get("HIFICAR_PRECISION", "f32")
+            precision = "f32"  # (HIFICAR_PRECISION, the HiFi-GAN generators' process-wide default, does not apply: this class has one arithmetic)
         if precision != "f32":
-            raise ValueError("GBlockGenerator runs in the exact-fp32 arithmetic only (precision='f32')")
+            raise ValueError("GBlockGenerator runs in the exact-fp32 arithmetic only (precision='f32'; the environment variable HIFICAR_PRECISION "
+                             "is not consulted by this class)")
 
         self.use_ar = use_ar
         self.use_spk_id = use_spk_id
@@ -89,6 +94,7 @@ class GBlockGenerator(_NativeGenerator):
             g_kernel_sizes=list(g_kernel_sizes), use_tanh=use_tanh, use_ar=use_ar, ar_input=ar_input, ar_hidden=ar_hidden, ar_output=ar_output,
             use_spk_id=use_spk_id, num_spk=num_spk, spk_emb_size=spk_emb_size, ph_emb_size=0, num_ph=None,
         )
+        _native.check_gblock_params(self._params)  # libhificar's own limits: fail here, not at the first forward on the device
         self.hop = int(np.prod(g_scales))
         self.precision = precision
 

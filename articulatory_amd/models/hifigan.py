@@ -323,6 +323,28 @@ class _NativeGenerator(torch.nn.Module):
                 out[name + ".weight"] = m.weight.detach().float().cpu().contiguous()
         return out
 
+    # ------------------------------------------------------------------ copies and pickles
+    # copy.deepcopy / pickle build a module WITHOUT running __init__: the native handle (a raw pointer: two modules must never share one),
+    # the workspaces, the cached parameter lists (they would point at the ORIGINAL's tensors) and the gradient-sync wiring stay behind, and
+    # the copy registers with the optimizer post-step hook itself — a deep-copied generator trained with a fused optimizer (no
+    # Parameter._version bump) would otherwise keep running on the weights it was copied with.
+    _EPHEMERAL = ("_handle", "_lib", "_workspaces", "_grad_slots", "_grad_sync", "_param_sig", "_plist_cache", "_plist_epoch", "_raw_cache")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._EPHEMERAL:
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        d = self.__dict__
+        d["_handle"] = d["_lib"] = d["_grad_slots"] = d["_grad_sync"] = d["_param_sig"] = d["_plist_cache"] = d["_raw_cache"] = None
+        d["_workspaces"] = {}
+        from ..utils.optim_hook import watch
+
+        watch(self)
+
     # ------------------------------------------------------------------ native handle
     def _invalidate(self):
         h = getattr(self, "_handle", None)

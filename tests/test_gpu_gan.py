@@ -251,6 +251,55 @@ def test_train_cli_end_to_end_and_resume(tmp_path):
     assert not torch.equal(state["model"]["generator"][k], state2["model"]["generator"][k])
 
 
+@pytest.mark.parametrize("kind", ["spk", "ph"])
+def test_train_cli_with_conditioned_generators(tmp_path, kind):
+    """use_spk_id / use_ph + use_ph_loss through main(): the datasets read utt2spk / ph.scp (the reference's SpeechDataset side tables,
+    audio_mel_dataset.py:403-461), the collater carries spk_id and slices ph with the windows (train.py:990-998, 1028-1031), and the iterations
+    move the conditioning parameters — from files and from --synthetic utterances."""
+    import yaml
+
+    from articulatory_amd.bin import train as T
+
+    config = make_config(True)
+    if kind == "spk":
+        config["generator_params"] = dict(config["generator_params"], use_spk_id=True, num_spk=3, spk_emb_size=8)
+        watch = "spk_emb_mat.weight"
+    else:
+        config["generator_params"] = dict(config["generator_params"], in_channels=13 + 128 + 8, use_ph=True, num_ph=9, ph_emb_size=8, use_ph_loss=True)
+        config["lambda_ph"] = 3.0
+        watch = "ph_fc.weight"
+    config.update(train_max_steps=3, save_interval_steps=100, log_interval_steps=1, num_workers=0, pin_memory=False)
+    cfg = tmp_path / "conf.yaml"
+    cfg.write_text(yaml.safe_dump(config))
+    rng = np.random.default_rng(0)
+    hop, lines = 20, {"wav.scp": [], "feats.scp": [], "utt2spk": [], "ph.scp": []}
+    for i in range(8):
+        n = 40 + 3 * i
+        for name, arr in (("wave", (rng.standard_normal(n * hop) * 0.1).astype(np.float32)), ("feats", rng.standard_normal((n, 13)).astype(np.float32)),
+                          ("ph", rng.integers(0, 9, size=n))):
+            np.save(tmp_path / f"u{i}-{name}.npy", arr)
+        lines["wav.scp"].append(f"u{i} {tmp_path}/u{i}-wave.npy")
+        lines["feats.scp"].append(f"u{i} {tmp_path}/u{i}-feats.npy")
+        lines["utt2spk"].append(f"u{i} s{i % 3}")
+        lines["ph.scp"].append(f"u{i} {tmp_path}/u{i}-ph.npy")
+    for name, ls in lines.items():
+        (tmp_path / name).write_text("\n".join(ls) + "\n")
+    side = ["--utt2spk", str(tmp_path / "utt2spk")] if kind == "spk" else ["--ph-scp", str(tmp_path / "ph.scp")]
+    for tag, data in (("files", ["--audio-scp", str(tmp_path / "wav.scp"), "--feats-scp", str(tmp_path / "feats.scp")] + side), ("synth", ["--synthetic", "8"])):
+        out = tmp_path / ("exp_" + tag)
+        T.main(["--config", str(cfg), "--outdir", str(out), "--verbose", "0"] + data)
+        state = torch.load(out / "checkpoint-3steps.pkl", map_location="cpu")
+        assert state["steps"] == 3
+        fresh = getattr(__import__("articulatory_amd.models", fromlist=["x"]), "HiFiGANGenerator")(**config["generator_params"]).state_dict()
+        assert state["model"]["generator"][watch].shape == fresh[watch].shape
+        assert bool(torch.isfinite(state["model"]["generator"][watch]).all())
+    if kind == "spk":  # a speaker table that disagrees with num_spk is refused, as train.py:1584-1585 asserts
+        (tmp_path / "utt2spk").write_text("\n".join(f"u{i} s{i % 2}" for i in range(8)) + "\n")
+        with pytest.raises(SystemExit, match="num_spk"):
+            T.main(["--config", str(cfg), "--outdir", str(tmp_path / "x"), "--verbose", "0", "--audio-scp", str(tmp_path / "wav.scp"),
+                    "--feats-scp", str(tmp_path / "feats.scp"), "--utt2spk", str(tmp_path / "utt2spk")])
+
+
 def test_phoneme_conditioned_iteration_with_ph_loss_vs_oracle():
     """A use_ph + use_ph_loss generator through Trainer.train_step (train.py:273-278, 327-331: y_, ph_ = generator(x, ph=ph);
     gen_loss += lambda_ph * cross_entropy(ph_, ph)): the logged losses of the first iteration against the CPU oracle, and the

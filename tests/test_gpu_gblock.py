@@ -235,12 +235,38 @@ def test_unrunnable_configurations_fail_loudly():
     with pytest.raises(ValueError, match="f32"):
         GBlockGenerator(g_scales=[5, 1, 4, 1, 1, 2, 1, 2, 1, 1], g_kernel_sizes=[3] * 10, precision="bf16x3")
     p = _params(np.load(os.path.join(GOLDEN, "gold_gblock_small.npz")))
-    model, _ = build(dict(p, g_kernel_sizes=[9] * 10))
-    with pytest.raises(ValueError, match="> 7"):
-        model(torch.zeros(1, 13, 4).cuda(), ar=torch.zeros(1, 1, 512).cuda())
+    with pytest.raises(ValueError, match="> 11"):  # libhificar's own limits are checked at construction (not at the first forward)
+        GBlockGenerator(**dict(p, g_kernel_sizes=[13] * 10))
+    with pytest.raises(ValueError, match="g_scales"):
+        GBlockGenerator(**dict(p, g_scales=[65, 1, 1, 1, 1, 1, 1, 1, 1, 1]))
+    with pytest.raises(ValueError, match="multiples of 4"):
+        GBlockGenerator(**dict(p, ar_hidden=250))
     cpu = GBlockGenerator(**p)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         cpu(torch.zeros(1, 13, 4), ar=torch.zeros(1, 1, 512))
+
+
+@pytest.mark.parametrize("k,channels", [(9, 64), (11, 64), (9, 512), (11, 256)])
+def test_long_gblock_kernels_vs_oracle(k, channels):
+    """g_kernel_sizes 9 and 11 (pytorch_layers.py:36, 49-81 take any odd size): the dilation-27 conv then reaches 108 / 135 rows either side and
+    the tile picker has to fall back to short tiles for the wide blocks (32 rows + a 270-row halo at k = 11 and 64-channel chunks) — forward and a
+    ragged AR synthesis against the CPU oracle.  Weight gradients of such a conv do not fit the LDS staging: training says so."""
+    p = dict(in_channels=141, out_channels=1, channels=channels, kernel_size=7, g_scales=[5, 1, 4, 1, 1, 2, 1, 2, 1, 1], g_kernel_sizes=[k] * 10,
+             use_weight_norm=True, use_ar=True, ar_input=512, ar_hidden=256, ar_output=128, use_tanh=True)
+    model, sd = build(p, seed=900 + k)
+    w = G.fold_weight_norm(sd)
+    B, T = 2, 9
+    c = torch.from_numpy(synth_features(B, T, 13, seed=910 + k).transpose(0, 2, 1).copy())
+    ar = torch.from_numpy(uniform(920 + k, "ar", (B, 1, 512), -0.3, 0.3))
+    with torch.no_grad():
+        y = model(c.cuda(), ar=ar.cuda())
+        ref = G.generator_forward(w, p, c, ar)
+    assert y.shape == (B, 1, 80 * T)
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < 5e-5  # (42 un-normalised convs deep: the oracle test's own bar for this class, see its header)
+    if channels == 64:
+        trainee, _ = build(p, seed=900 + k, train=True)
+        with pytest.raises((ValueError, RuntimeError), match="inference only"):
+            trainee(c.cuda(), ar=ar.cuda()).sum().backward()
 
 
 def test_gan_iteration_with_a_gblock_generator_vs_oracle():

@@ -275,6 +275,38 @@ def test_fused_adam_without_the_trainer_reaches_the_native_weights():
     assert float((y1 - y0.detach()).abs().max()) > 1e-4
 
 
+def test_deep_copied_generator_with_fused_adam_runs_on_its_own_new_weights():
+    """copy.deepcopy builds a module without running __init__: the copy must get its OWN native handle (never the original's pointer) and its own
+    registration with the optimizer post-step hook — after a fused Adam step (no Parameter._version bump) its forward equals the oracle on ITS
+    updated state_dict, while the original, untouched by that optimizer, still produces what it produced before."""
+    import copy
+
+    params = dict(E2W_PARAMS, channels=64)
+    g, sd = build(params, 5)
+    B, T = 2, 6
+    c = torch.from_numpy(synth_features(B, T, 13, seed=63).transpose(0, 2, 1).copy()).cuda()
+    ar = torch.zeros(B, 1, 512).cuda()
+    with torch.no_grad():
+        y_orig = g(c, ar=ar)  # (the original has a live native handle when it is copied)
+    g2 = copy.deepcopy(g)
+    assert g2._handle is None and g._handle is not None
+    opt = torch.optim.Adam(g2.parameters(), lr=1e-2, fused=True)
+    y0 = g2(c, ar=ar)
+    assert torch.equal(y0.detach(), y_orig)
+    y0.square().mean().backward()
+    opt.step()
+    with torch.no_grad():
+        y1 = g2(c, ar=ar)
+        now = {k: v.detach().cpu().numpy() for k, v in g2.state_dict().items()}
+        ref = O.generator_forward(O.fold_weight_norm(now), params, c.cpu(), ar.cpu())
+        assert rel_err(y1.cpu().numpy(), ref.numpy()) < 2e-5
+        assert float((y1 - y0.detach()).abs().max()) > 1e-4
+        assert torch.equal(g(c, ar=ar), y_orig)
+    del g2  # (destroys the copy's handle only)
+    with torch.no_grad():
+        assert torch.equal(g(c, ar=ar), y_orig)
+
+
 def test_eval_mode_forward_explains_itself_on_backward():
     """model.eval() with gradients enabled stays on the inference kernels (no tape); a backward through its output says why instead of torch's
     bare "does not require grad"; ``eval_autograd = True`` gives torch's semantics (a graph in eval mode too), identical gradients to train()."""

@@ -131,8 +131,8 @@ def test_recipe_values_equal_the_shipped_yaml(recipe, path):
 
 
 def test_conditioned_generators_need_conditioning_batches():
-    """use_spk_id / use_ph / use_ph_loss: the reference's collaters carry spk_id and slice ph (train.py:1029-1032, 248-249); this package's
-    datasets do not — a clear error instead of an AttributeError on None deep inside the step."""
+    """use_spk_id / use_ph / use_ph_loss: a batch built without the conditioning entries (a caller's own collater; WindowCollater carries them when
+    its flags are on) gets a clear error instead of an AttributeError on None deep inside the step."""
     import types
 
     from articulatory_amd.bin.train import Trainer
@@ -143,3 +143,53 @@ def test_conditioned_generators_need_conditioning_batches():
     Trainer._check_conditioning(t, {"x": None, "y": None, "spk_id": None, "ph": None})
     t = types.SimpleNamespace(config={"generator_params": {}}, use_ph_loss=False)
     Trainer._check_conditioning(t, {"x": None})
+
+
+def test_window_collater_carries_spk_id_and_slices_ph_with_the_windows(tmp_path):
+    """use_spk_id / use_ph (reference SpeechCollater, train.py:990-998, 1028-1031): ``ph`` is cut with the SAME frame starts as the features and
+    the audio, ``spk_id`` rides along, and an utterance too short for a window drops out of all of them together."""
+    hop, frames_w = 20, 5
+    items = []
+    for i, n in enumerate((9, 30, 6, 5)):
+        feats = np.stack([np.arange(n, dtype=np.float32), np.full(n, 100.0 * i, np.float32)], 1)   # column 0 = the frame's index
+        audio = np.arange(n * hop, dtype=np.float32)
+        items.append((audio, feats, {"spk_id": 10 + i, "ph": 7 * np.arange(n + 2)}))              # ph may be longer than the features
+    col = T.WindowCollater(frames_w * hop, hop, None, np.random.default_rng(3), use_spk_id=True, use_ph=True)
+    for _ in range(20):
+        b = col(items)
+        assert b["spk_id"].dtype == torch.long and b["spk_id"].tolist() == [10, 11, 12]            # the 5-frame utterance is left out
+        assert b["ph"].dtype == torch.long and b["ph"].shape == (3, frames_w)
+        assert torch.equal(b["ph"], 7 * b["x"][:, 0, :].long())                                     # same frames as the features
+        assert torch.equal(b["y"][:, 0, 0].long(), b["x"][:, 0, 0].long() * hop)                     # ... and as the audio
+    with pytest.raises(ValueError, match="phoneme sequence"):
+        col([(items[0][0], items[0][1], {"spk_id": 0, "ph": np.arange(3)})])
+    plain = T.WindowCollater(frames_w * hop, hop, None, np.random.default_rng(3))                   # flags off: extras are ignored
+    assert set(plain(items)) == {"x", "y"}
+
+    # the side tables of the reference's SpeechDataset: utt2spk (ids = ranks in the sorted speaker list) and ph.scp
+    d = tmp_path
+    lines_w, lines_f, lines_s, lines_p = [], [], [], []
+    for utt, spk, n in (("u1", "zoe", 12), ("u2", "amy", 20), ("u3", "zoe", 14), ("u4", "bob", 16)):
+        np.save(d / f"{utt}-wave.npy", np.arange(n * hop, dtype=np.float32))
+        np.save(d / f"{utt}-feats.npy", np.stack([np.arange(n, dtype=np.float32)] * 2, 1))
+        lines_w.append(f"{utt} {d / (utt + '-wave.npy')}")
+        lines_f.append(f"{utt} {d / (utt + '-feats.npy')}")
+        if utt != "u4":  # u4 has no speaker / phoneme entry: it is not part of the conditioned set
+            np.save(d / f"{utt}-ph.npy", np.arange(n) % 5)
+            lines_s.append(f"{utt} {spk}")
+            lines_p.append(f"{utt} {d / (utt + '-ph.npy')}")
+    for name, lines in (("wav.scp", lines_w), ("feats.scp", lines_f), ("utt2spk", lines_s), ("ph.scp", lines_p)):
+        (d / name).write_text("\n".join(lines) + "\n")
+    cond = T.Conditioning(str(d / "utt2spk"), str(d / "ph.scp"))
+    assert cond.spks == ["amy", "zoe"]
+    ds = T.NpyPairs(str(d / "wav.scp"), str(d / "feats.scp"), hop, min_frames=5, cond=cond)
+    assert len(ds) == 3
+    got = {int(ds[i][2]["spk_id"]) for i in range(3)}
+    assert got == {0, 1} and all(len(ds[i][2]["ph"]) == len(ds[i][1]) for i in range(3))
+    dd = T.DumpDirPairs(str(d), "npy", hop, min_frames=5, cond=T.Conditioning(str(d / "utt2spk"), None, spks=["amy", "bob", "zoe"]))
+    assert len(dd) == 3 and sorted(int(dd[i][2]["spk_id"]) for i in range(3)) == [0, 2, 2]         # a dev set on the training set's speaker list
+    b = T.WindowCollater(frames_w * hop, hop, 8, np.random.default_rng(1), use_spk_id=True, use_ph=True)([ds[i] for i in range(3)])
+    assert torch.equal(b["ph"], b["x"][:, 0, :].long() % 5) and b["ar"].shape == (3, 1, 8)
+    syn = T.SyntheticPairs(3, 12, 4, hop, seed=0, num_spk=4, num_ph=9)
+    sb = T.WindowCollater(frames_w * hop, hop, None, np.random.default_rng(1), use_spk_id=True, use_ph=True)([syn[i] for i in range(3)])
+    assert sb["ph"].shape == (3, frames_w) and int(sb["ph"].max()) < 9 and int(sb["spk_id"].max()) < 4
