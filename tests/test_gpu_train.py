@@ -292,7 +292,8 @@ def test_deep_copied_generator_with_fused_adam_runs_on_its_own_new_weights():
     assert g2._handle is None and g._handle is not None
     opt = torch.optim.Adam(g2.parameters(), lr=1e-2, fused=True)
     y0 = g2(c, ar=ar)
-    assert torch.equal(y0.detach(), y_orig)
+    # (same weights; the graph forward folds the weight norm on the device, the no_grad one on the host: equal to fp32 rounding, not bit for bit)
+    assert rel_err(y0.detach().cpu().numpy(), y_orig.cpu().numpy()) < 2e-6
     y0.square().mean().backward()
     opt.step()
     with torch.no_grad():
