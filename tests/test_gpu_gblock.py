@@ -370,15 +370,18 @@ def test_random_gblock_gradients_on_kink_free_inputs(case):
     w64 = G.fold_weight_norm(sd, dtype=torch.float64)
     B, T = int(rng.integers(1, 3)), (int(rng.integers(1, 4)) if hop > 40 else int(rng.integers(2, 12)))
     spk = rng.integers(0, 5, size=B) if p["use_spk_id"] else None
-    for attempt in range(12):
-        c_np = synth_features(B, T, cf, seed=9000 + 13 * case + attempt).transpose(0, 2, 1).copy()
-        ar_np = (synth_features(B, 512, 1, seed=9500 + 13 * case + attempt)[:, :, 0] * 0.3).reshape(B, 1, 512).astype(np.float32) if p["use_ar"] else None
+    for attempt in range(60):
+        if attempt in (20, 40):  # still no kink-free input: fewer activations (round 4: two of eight cases skipped on the driver's box after 12 seeds)
+            B, T = 1, max(1, T // 2)
+            spk = spk[:1] if spk is not None else None
+        c_np = synth_features(B, T, cf, seed=9000 + 61 * case + attempt).transpose(0, 2, 1).copy()
+        ar_np = (synth_features(B, 512, 1, seed=9500 + 61 * case + attempt)[:, :, 0] * 0.3).reshape(B, 1, 512).astype(np.float32) if p["use_ar"] else None
         m = G.relu_margin(w64, p, torch.from_numpy(c_np).double(), torch.from_numpy(ar_np).double() if ar_np is not None else None,
                           spk_id=torch.from_numpy(spk) if spk is not None else None)
         if m >= 2e-6:
             break
     else:
-        pytest.skip("no kink-free input among 12 seeds")
+        pytest.skip("no kink-free input among 60 seeds")
     cot = uniform(700 + case, "cotangent", (B, 1, hop * T), -1.0, 1.0)
     c = torch.from_numpy(c_np).cuda().requires_grad_(True)
     ar = torch.from_numpy(ar_np).cuda().requires_grad_(True) if ar_np is not None else None

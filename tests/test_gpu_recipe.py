@@ -76,7 +76,7 @@ def test_full_recipe_iteration_vs_reference_train_step(recipe, aux):
         assert abs(log[k] - ref) < 1e-4 * max(abs(ref), 1e-3) + slack, (k, log[k], ref)
     # ---- gradients left in .grad and parameters after the Adam step, for the fixture's tensors
     lr = config["generator_optimizer_params"]["lr"]
-    k_med, k_max = (8.0, 5.0) if recipe == "car_lin" else (20.0, 10.0)  # (measured: <= 3.2 / 1.9 and <= 12.2 / 3.8)
+    k_med, k_max = (6.5, 4.0) if recipe == "car_lin" else (20.0, 8.0)  # (twice what was measured — <= 3.2 / 1.9 and <= 12.2 / 3.8 — or less)
     for net, names, module, sd in (("generator", G_TENSORS, t.G, gsd), ("discriminator", D_TENSORS, t.D, dsd)):
         params = dict(module.named_parameters())
         for n in names:
