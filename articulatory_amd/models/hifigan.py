@@ -120,6 +120,13 @@ def _send_parameters(module, names, tensors, stream):
     """Hand every RAW parameter over in one call (hificar_set_parameters_device: weight norm folded and every pack refreshed on the
     device, two launches).  Returns the tensors actually read (kept alive by the caller until the stream has consumed them)."""
     lib, handle = module._lib, module._handle
+    # Nothing changed since the last hand-over to THIS handle (same tensors at the same addresses with the same version counters, and no
+    # invalidate_parameters() in between — which is what a fused optimizer's step triggers): skip the fold + 166 packs.  The graph forward of an
+    # iteration sees the weights the previous iteration's second (no-graph) forward already sent (train.py:389: "re-compute y_").
+    direct = all(t.dtype == torch.float32 and t.is_contiguous() for t in tensors)
+    sig = (id(handle), names, tuple(t.data_ptr() for t in tensors), tuple(t._version for t in tensors))
+    if direct and module.__dict__.get("_sent_sig") == sig:
+        return module.__dict__["_sent_held"]
     # (the parameters themselves are read when they are fp32 and contiguous — the normal case; a converted copy otherwise)
     held = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous() for t in tensors]
     cnames = getattr(module, "_raw_cnames", None)
@@ -128,6 +135,10 @@ def _send_parameters(module, names, tensors, stream):
         cnames = module._raw_cnames = (names, arr)
     ptrs = (ctypes.c_void_p * len(held))(*[t.data_ptr() for t in held])
     _native.check(lib.hificar_set_parameters_device(handle, cnames[1], ptrs, len(held), stream), "hificar_set_parameters_device")
+    if direct:
+        module.__dict__["_sent_sig"], module.__dict__["_sent_held"] = sig, held
+    else:
+        module.__dict__.pop("_sent_sig", None)
     return held
 
 
@@ -328,7 +339,8 @@ class _NativeGenerator(torch.nn.Module):
     # the workspaces, the cached parameter lists (they would point at the ORIGINAL's tensors) and the gradient-sync wiring stay behind, and
     # the copy registers with the optimizer post-step hook itself — a deep-copied generator trained with a fused optimizer (no
     # Parameter._version bump) would otherwise keep running on the weights it was copied with.
-    _EPHEMERAL = ("_handle", "_lib", "_workspaces", "_grad_slots", "_grad_sync", "_param_sig", "_plist_cache", "_plist_epoch", "_raw_cache")
+    _EPHEMERAL = ("_handle", "_lib", "_workspaces", "_grad_slots", "_grad_sync", "_param_sig", "_plist_cache", "_plist_epoch", "_raw_cache", "_sent_sig",
+                  "_sent_held", "_raw_cnames")
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -354,6 +366,8 @@ class _NativeGenerator(torch.nn.Module):
         self._workspaces = {}
         self._grad_slots = None
         self.__dict__["_plist_cache"] = None
+        self.__dict__.pop("_sent_sig", None)
+        self.__dict__.pop("_sent_held", None)
 
     def __del__(self):
         try:
@@ -371,6 +385,7 @@ class _NativeGenerator(torch.nn.Module):
         The module registers itself with ``articulatory_amd.utils.optim_hook.watch`` at construction, so every ``optimizer.step()`` of an
         optimizer that holds one of its parameters calls this — no wiring by the training loop."""
         self._param_sig = None
+        self.__dict__.pop("_sent_sig", None)
 
     def set_precision(self, precision):
         if precision not in _native.PRECISIONS:
