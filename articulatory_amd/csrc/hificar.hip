@@ -287,8 +287,8 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (c.out_channels != 1) return fail(HIFICAR_E_INVALID, "out_channels=%d unsupported (PQMF multi-band output is out of scope)", c.out_channels);
     if (c.kernel_size % 2 != 1) return fail(HIFICAR_E_INVALID, "Kernel size must be odd number.");
     if (c.n_stages < 1 || c.n_stages > HIFICAR_MAX_STAGES) return fail(HIFICAR_E_INVALID, "n_stages=%d out of range", c.n_stages);
-    if (c.n_blocks < 1 || c.n_blocks > 3) return fail(HIFICAR_E_INVALID, "n_blocks=%d unsupported (1..3 residual blocks per stage)", c.n_blocks);
-    if (!c.use_additional_convs) return fail(HIFICAR_E_INVALID, "use_additional_convs=false is unsupported");
+    if (c.n_blocks < 1 || c.n_blocks > HIFICAR_MAX_BLOCKS)
+        return fail(HIFICAR_E_INVALID, "n_blocks=%d unsupported (1..%d residual blocks per stage)", c.n_blocks, HIFICAR_MAX_BLOCKS);
     if (c.use_ar && (c.ar_input > 1024 || c.ar_hidden > 512 || c.ar_output > 512 || c.ar_input < 1))
         return fail(HIFICAR_E_INVALID, "PastFCEncoder: ar_input must be <= 1024, ar_hidden / ar_output <= 512");
     if (c.use_ar && (c.ar_hidden % 4 != 0 || c.ar_output % 4 != 0))
@@ -401,12 +401,14 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
                 c2.dilation = 1;
                 c2.padding = (k - 1) / 2;
                 if (rc == HIFICAR_OK) rc = plan_layer(c2);
+                // use_additional_convs = false (residual_block.py:151, 191-205): no convs2, a layer is x = x + conv1(LeakyReLU(x))
                 for (const ConvLayer* l : {&c1, &c2}) {
+                    if (l == &c2 && !c.use_additional_convs) continue;
                     expect(l->name + ".weight", {l->cout, l->cin, k});
                     if (l->has_bias) expect(l->name + ".bias", {l->cout});
                 }
                 h->convs1.push_back(c1);
-                h->convs2.push_back(c2);
+                if (c.use_additional_convs) h->convs2.push_back(c2);
             }
         }
     }
@@ -745,15 +747,17 @@ extern "C" int hificar_set_precision(hificar_handle* h, int precision) {
 // ------------------------------------------------------------------------------------------------
 // workspace plan
 // ------------------------------------------------------------------------------------------------
+constexpr int kMaxBlk = HIFICAR_MAX_BLOCKS;  // residual blocks per stage (hifigan.py:134-145: one per resblock_kernel_sizes entry)
+
 struct Workspace {
     // "activated rows" = LeakyReLU(x) as split rows (bf16x3) or plain fp32 rows (exact fp32): 4 bytes per element either way
     float* xin;    // (B, T, cin_pad) assembled input rows (no activation in front of the input conv)
     float* h0;     // input conv output, activated rows
     float* u;      // upsample output, fp32 (residual of the first ResBlock layer)
-    float* x[3];   // per-branch residual stream, fp32
-    float* xt[3];  // conv1 output, activated rows ([0] also holds the activated MRF mean for the next upsampler)
-    char* u_s;     // activated rows of u
-    char* x_s[3];  // activated rows of x_j
+    float* x[kMaxBlk];   // per-branch residual stream, fp32
+    float* xt[kMaxBlk];  // conv1 output, activated rows ([0] also holds the activated MRF mean for the next upsampler)
+    char* u_s;           // activated rows of u
+    char* x_s[kMaxBlk];  // activated rows of x_j
     size_t bytes;
 };
 
@@ -787,10 +791,11 @@ static Workspace plan_workspace(const hificar_handle* h, int B, int T, void* bas
     w.h0 = take((size_t)B * T * stage_pad(h->cfg, 0));
     const size_t se = stage_elems(h, B, T);
     w.u = take(se);
-    for (int j = 0; j < 3; ++j) w.x[j] = take(se);
-    for (int j = 0; j < 3; ++j) w.xt[j] = take(se);
+    const int nbw = std::max(3, h->cfg.n_blocks);  // (three sets at least: the GBlock engine and the MRF-mean ping-pong use them by index)
+    for (int j = 0; j < kMaxBlk; ++j) w.x[j] = j < nbw ? take(se) : nullptr;
+    for (int j = 0; j < kMaxBlk; ++j) w.xt[j] = j < nbw ? take(se) : nullptr;
     w.u_s = reinterpret_cast<char*>(take(se));
-    for (int j = 0; j < 3; ++j) w.x_s[j] = reinterpret_cast<char*>(take(se));
+    for (int j = 0; j < kMaxBlk; ++j) w.x_s[j] = j < nbw ? reinterpret_cast<char*>(take(se)) : nullptr;
     w.bytes = off;
     return w;
 }
@@ -822,7 +827,7 @@ extern "C" double hificar_macs(const hificar_handle* h, int B, int T) {
         const double cin = stage_channels(c, i), cout = stage_channels(c, i + 1);
         m += L * cin * cout * c.upsample_kernel_sizes[i];
         L *= c.upsample_scales[i];
-        for (int j = 0; j < c.n_blocks; ++j) m += L * cout * cout * c.resblock_kernel_sizes[j] * 2.0 * c.n_dilations[j];
+        for (int j = 0; j < c.n_blocks; ++j) m += L * cout * cout * c.resblock_kernel_sizes[j] * (c.use_additional_convs ? 2.0 : 1.0) * c.n_dilations[j];
     }
     m += L * stage_channels(c, c.n_stages) * c.kernel_size;
     if (c.use_ar) m += (double)c.ar_input * c.ar_hidden + 3.0 * c.ar_hidden * c.ar_hidden + (double)c.ar_hidden * c.ar_output;
@@ -841,10 +846,10 @@ struct Tape {
     char* h0_s = nullptr;                                              // activated input-conv output
     char* upin_s[HIFICAR_MAX_STAGES] = {};                             // activated input of upsample i (i = 0: h0_s)
     char* u_s[HIFICAR_MAX_STAGES] = {};                                // activated upsample output
-    char* xt_s[HIFICAR_MAX_STAGES][3][HIFICAR_MAX_DILATIONS] = {};     // activated conv1 output (= conv2 input)
-    char* x_s[HIFICAR_MAX_STAGES][3][HIFICAR_MAX_DILATIONS] = {};      // activated residual stream after pair d (= next conv1 input)
+    char* xt_s[HIFICAR_MAX_STAGES][kMaxBlk][HIFICAR_MAX_DILATIONS] = {};     // activated conv1 output (= conv2 input)
+    char* x_s[HIFICAR_MAX_STAGES][kMaxBlk][HIFICAR_MAX_DILATIONS] = {};      // activated residual stream after pair d (= next conv1 input)
     float* mlp = nullptr;                                              // (B, 5, 1024) PastFCEncoder layer inputs
-    float* fin[3] = {nullptr, nullptr, nullptr};                       // fp32 ResBlock outputs of the LAST stage (output conv backward)
+    float* fin[kMaxBlk] = {};                                          // fp32 ResBlock outputs of the LAST stage (output conv backward)
     // GBlockGenerator (arch 1), per GBlock: the raw and the ReLU'd input at the block's OUTPUT rate (nearest-upsampled copies: the weight
     // gradients of res1 / conv1's first conv contract over them), and the ReLU'd inputs of the other three convs
     char* g_xu[HIFICAR_MAX_GBLOCKS] = {};
@@ -1474,6 +1479,7 @@ static int launch_output_conv(hificar_handle* h, const float* const* fin, int ni
     op.x0 = fin[0];
     op.x1 = nin > 1 ? fin[1] : nullptr;
     op.x2 = nin > 2 ? fin[2] : nullptr;
+    op.x3 = nin > 3 ? fin[3] : nullptr;
     op.nin = nin;
     op.w = h->d_out_w;
     op.bias = h->out_bias;
@@ -1584,7 +1590,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     if (tapping) {
         for (auto& kv : h->taps) tap_convs1 = tap_convs1 || kv.first.find(".convs1.") != std::string::npos;
         // pre-activation copies that the normal path never writes: 3 stage-sized scratch buffers
-        const size_t need = 3 * stage_elems(h, B, T) + (size_t)B * T * stage_pad(cfg, 0);
+        const size_t need = kMaxBlk * stage_elems(h, B, T) + (size_t)B * T * stage_pad(cfg, 0);
         if (need > h->tap_scratch_elems) {
             if (h->tap_scratch) HIP_TRY(hipFree(h->tap_scratch));
             h->tap_scratch = nullptr;
@@ -1600,21 +1606,32 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     const size_t tap_se = tapping ? stage_elems(h, B, T) : 0;
     const int nbk = cfg.n_blocks;
     // residual blocks of a stage run side by side, heaviest kernel size first
-    int order[3] = {0, 1, 2};
+    int order[kMaxBlk] = {0, 1, 2, 3};
     std::sort(order, order + nbk, [&](int a, int b) { return cfg.resblock_kernel_sizes[a] > cfg.resblock_kernel_sizes[b]; });
     int max_d = 0;
     for (int j = 0; j < nbk; ++j) max_d = std::max(max_d, cfg.n_dilations[j]);
+    int rows_of_launch = 0;  // (conv_n: the stage's row count at the time of the call)
+    const bool add_convs = cfg.use_additional_convs != 0;  // false: a ResBlock layer is x = x + conv1(LeakyReLU(x)) (residual_block.py:217-221)
+    // a launch carries up to three branches (MultiConvParams / PairParams): a fourth residual block rides in a second launch
+    auto conv_n = [&](const ConvLayer* const* lay, int n, const ConvIO* io) -> int {
+        for (int q0 = 0; q0 < n; q0 += 3) {
+            const int r = launch_conv(h, lay + q0, std::min(3, n - q0), B, rows_of_launch, io + q0, cfg.lrelu_slope, rg, stream);
+            if (r != HIFICAR_OK) return r;
+        }
+        return HIFICAR_OK;
+    };
 
-    const float* fin[3] = {ws.x[0], ws.x[1], ws.x[2]};  // where each branch's ResBlock output of the current stage lives
+    const float* fin[kMaxBlk] = {ws.x[0], ws.x[1], ws.x[2], ws.x[3]};  // where each branch's ResBlock output of the current stage lives
     {
         // Activations travel between layers already activated — split rows (bf16x3) or plain fp32 rows (exact fp32), the
         // "_s" buffers — and are staged by LDS-DMA; the layer's own fp32 value only where a residual / the MRF mean needs it
         char* xin_s = tp ? reinterpret_cast<char*>(tp->xin) : reinterpret_cast<char*>(ws.xin);
         char* h0_s = tp ? tp->h0_s : reinterpret_cast<char*>(ws.h0);
-        char* xt_s[3] = {reinterpret_cast<char*>(ws.xt[0]), reinterpret_cast<char*>(ws.xt[1]), reinterpret_cast<char*>(ws.xt[2])};
+        char* xt_s[kMaxBlk] = {reinterpret_cast<char*>(ws.xt[0]), reinterpret_cast<char*>(ws.xt[1]), reinterpret_cast<char*>(ws.xt[2]),
+                               reinterpret_cast<char*>(ws.xt[3])};
         {   // 2. input conv (no activation in front of it: hifigan.py:221); its consumer applies LeakyReLU(slope)
             const ConvLayer* lay[1] = {&h->input_conv};
-            float* y_tap = tap_wanted(h, "input_conv") ? h->tap_scratch + 3 * tap_se : nullptr;
+            float* y_tap = tap_wanted(h, "input_conv") ? h->tap_scratch + kMaxBlk * tap_se : nullptr;
             const ConvIO io[1] = {{xin_s, nullptr, y_tap, h0_s}};
             if ((rc = launch_conv(h, lay, 1, B, T, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
             if (y_tap && (rc = emit_tap(h, "input_conv", y_tap, stage_pad(cfg, 0), 0, cfg.channels, B, T, 0, stream)) != HIFICAR_OK) return rc;
@@ -1627,6 +1644,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 mq.x0 = fin[0];
                 mq.x1 = nbk > 1 ? fin[1] : nullptr;
                 mq.x2 = nbk > 2 ? fin[2] : nullptr;
+                mq.x3 = nbk > 3 ? fin[3] : nullptr;
                 mq.out = fin[0] == ws.xt[0] ? ws.x_s[0] : xt_s[0];  // a buffer none of the inputs lives in
                 if (tp) mq.out = tp->upin_s[i];
                 mq.nin = nbk;
@@ -1647,8 +1665,8 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             // kernel activates + splits its input while staging), ping-ponging between x[j] and xt[j]; no activated copies
             // are written at all.  Otherwise: activated copies ("_s") travel next to the fp32 stream.
             static const bool f32in = !getenv("HIFICAR_PAIR_F32IN") || atoi(getenv("HIFICAR_PAIR_F32IN")) != 0;  // A/B runs
-            bool all_pairs = f32in && !tap_convs1 && !tp;
-            for (int j = 0; j < nbk; ++j)
+            bool all_pairs = f32in && !tap_convs1 && !tp && add_convs;
+            for (int j = 0; j < nbk && all_pairs; ++j)
                 for (int d = 0; d < cfg.n_dilations[j]; ++d) {
                     const int ci = conv_index(h, i, j, d);
                     all_pairs = all_pairs && pair_eligible(h, h->convs1[ci], h->convs2[ci], B, rows * cfg.upsample_scales[i]);
@@ -1669,11 +1687,11 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 return r;
             };
             if (all_pairs) {
-                const float* cur_f[3] = {ws.u, ws.u, ws.u};
+                const float* cur_f[kMaxBlk] = {ws.u, ws.u, ws.u, ws.u};
                 for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
-                    const ConvLayer* l1[3];
-                    const ConvLayer* l2[3];
-                    PairIOB iop[3];
+                    const ConvLayer* l1[kMaxBlk];
+                    const ConvLayer* l2[kMaxBlk];
+                    PairIOB iop[kMaxBlk];
                     int n = 0;
                     for (int oj = 0; oj < nbk; ++oj) {
                         const int j = order[oj];
@@ -1687,7 +1705,8 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                         cur_f[j] = out_f;
                         ++n;
                     }
-                    if ((rc = launch_pair(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    for (int q0 = 0; q0 < n; q0 += 3)
+                        if ((rc = launch_pair(h, l1 + q0, l2 + q0, std::min(3, n - q0), B, rows, iop + q0, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
                     for (int j = 0; j < nbk; ++j)
                         if (d < cfg.n_dilations[j] && (rc = tap_block(j, d, cur_f[j])) != HIFICAR_OK) return rc;
                 }
@@ -1695,30 +1714,30 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 continue;
             }
             // fp32 residual streams; training keeps the LAST stage's (the output conv's backward needs the MRF mean) in the tape
-            float* xres[3] = {ws.x[0], ws.x[1], ws.x[2]};
+            float* xres[kMaxBlk] = {ws.x[0], ws.x[1], ws.x[2], ws.x[3]};
             if (tp && i + 1 == cfg.n_stages)
-                for (int j = 0; j < 3; ++j) xres[j] = tp->fin[j];
+                for (int j = 0; j < nbk; ++j) xres[j] = tp->fin[j];
             for (int j = 0; j < nbk; ++j) fin[j] = xres[j];
             // activated stream of each branch: where the next conv1 reads its input.  It alternates between x_s[j] and
             // xt_s[j]: a launch never writes the buffer it (or a neighbouring tile, through the halo) reads.
             const char* u_act = tp ? tp->u_s[i] : ws.u_s;
-            const char* cur_s[3] = {u_act, u_act, u_act};
+            const char* cur_s[kMaxBlk] = {u_act, u_act, u_act, u_act};
             for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
-                const ConvLayer* l1[3];
-                const ConvLayer* l2[3];
-                ConvIO io1[3], io2[3];
-                PairIOB iop[3];
-                int jn[3];
-                char* pair_out[3];
-                char* lbl_out[3];
+                const ConvLayer* l1[kMaxBlk];
+                const ConvLayer* l2[kMaxBlk];
+                ConvIO io1[kMaxBlk], io2[kMaxBlk];
+                PairIOB iop[kMaxBlk];
+                int jn[kMaxBlk];
+                char* pair_out[kMaxBlk];
+                char* lbl_out[kMaxBlk];
                 int n = 0;
-                bool fuse = true;
+                bool fuse = add_convs;
                 for (int oj = 0; oj < nbk; ++oj) {
                     const int j = order[oj];
                     if (d >= cfg.n_dilations[j]) continue;
                     const int ci = conv_index(h, i, j, d);
                     l1[n] = &h->convs1[ci];
-                    l2[n] = &h->convs2[ci];
+                    l2[n] = add_convs ? &h->convs2[ci] : nullptr;
                     fuse = fuse && !tap_convs1 && !tp && pair_eligible(h, *l1[n], *l2[n], B, rows);
                     const bool last = d + 1 == cfg.n_dilations[j];
                     // fused pair: cur -> the other buffer.  Layer by layer: cur -> mid -> the buffer that is not mid.
@@ -1731,20 +1750,30 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     }
                     io1[n] = {cur_s[j], nullptr, tap_convs1 ? h->tap_scratch + (size_t)n * tap_se : nullptr, mid};
                     io2[n] = {mid, d == 0 ? ws.u : xres[j], xres[j], last ? nullptr : lbl_out[n]};
+                    if (!add_convs) {  // one conv per layer: conv1 carries the residual epilogue; its activated output is the next layer's input
+                        char* nxt = tp ? tp->x_s[i][j][d] : pair_out[n];
+                        io1[n] = {cur_s[j], d == 0 ? ws.u : xres[j], xres[j], last ? nullptr : nxt};
+                        lbl_out[n] = nxt;
+                    }
                     iop[n] = {nullptr, cur_s[j], d == 0 ? ws.u : xres[j], xres[j], last ? nullptr : pair_out[n]};
                     jn[n] = j;
                     ++n;
                 }
                 if (fuse) {
-                    if ((rc = launch_pair(h, l1, l2, n, B, rows, iop, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    for (int q0 = 0; q0 < n; q0 += 3)
+                        if ((rc = launch_pair(h, l1 + q0, l2 + q0, std::min(3, n - q0), B, rows, iop + q0, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                } else if (!add_convs) {
+                    rows_of_launch = rows;
+                    if ((rc = conv_n(l1, n, io1)) != HIFICAR_OK) return rc;
                 } else {
-                    if ((rc = launch_conv(h, l1, n, B, rows, io1, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    rows_of_launch = rows;
+                    if ((rc = conv_n(l1, n, io1)) != HIFICAR_OK) return rc;
                     if (tap_convs1)
                         for (int q = 0; q < n; ++q)
                             if ((rc = emit_tap(h, "blocks." + std::to_string(i * nbk + jn[q]) + ".convs1." + std::to_string(d), io1[q].y, Cp, 0, Cs,
                                                B, rows, 0, stream)) != HIFICAR_OK)
                                 return rc;
-                    if ((rc = launch_conv(h, l2, n, B, rows, io2, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
+                    if ((rc = conv_n(l2, n, io2)) != HIFICAR_OK) return rc;
                 }
                 for (int q = 0; q < n; ++q)
                     if ((rc = tap_block(jn[q], d, xres[jn[q]])) != HIFICAR_OK) return rc;
@@ -1758,6 +1787,7 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
         pq.x0 = fin[0];
         pq.x1 = nbk > 1 ? fin[1] : nullptr;
         pq.x2 = nbk > 2 ? fin[2] : nullptr;
+        pq.x3 = nbk > 3 ? fin[3] : nullptr;
         pq.nin = nbk;
         pq.w = h->d_phfc_w;
         pq.bias = h->d_phfc_b;

@@ -717,6 +717,7 @@ struct OutBwdParams {
     const float* x0;
     const float* x1;
     const float* x2;
+    const float* x3;
     int nin;
     const float* w;     // [k][Cp]
     const float* dout;  // (B, L) gradient of the waveform, row pitch dout_bstride
@@ -733,6 +734,7 @@ __device__ __forceinline__ float mrf_mean_at(const OutBwdParams& p, size_t off) 
     float v = p.x0[off];
     if (p.nin == 2) v = (v + p.x1[off]) / 2.0f;
     else if (p.nin == 3) v = ((v + p.x1[off]) + p.x2[off]) / 3.0f;
+    else if (p.nin == 4) v = (((v + p.x1[off]) + p.x2[off]) + p.x3[off]) / 4.0f;
     return v;
 }
 
@@ -835,8 +837,8 @@ __global__ __launch_bounds__(256) void vreduce_kernel(const VreduceParams p) {
     }
 }
 
-// out = a + b + c (the three ResBlock branches' gradients with respect to the upsample output)
-__global__ __launch_bounds__(256) void add3_kernel(const float* a, const float* b, const float* c, float* out, long long n4, int nin) {
+// out = ((a + b) + c) + d (the up to four ResBlock branches' gradients with respect to the upsample output)
+__global__ __launch_bounds__(256) void add3_kernel(const float* a, const float* b, const float* c, const float* d, float* out, long long n4, int nin) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         f32x4 v = reinterpret_cast<const f32x4*>(a)[i];
         if (nin >= 2) {
@@ -845,6 +847,10 @@ __global__ __launch_bounds__(256) void add3_kernel(const float* a, const float* 
         }
         if (nin >= 3) {
             const f32x4 w = reinterpret_cast<const f32x4*>(c)[i];
+            v = v + w;
+        }
+        if (nin >= 4) {
+            const f32x4 w = reinterpret_cast<const f32x4*>(d)[i];
             v = v + w;
         }
         reinterpret_cast<f32x4*>(out)[i] = v;
@@ -963,6 +969,7 @@ struct PhHeadBwdParams {
     const float* x0;
     const float* x1;
     const float* x2;
+    const float* x3;
     int nin;
     const float* w;        // ph_fc.weight (num_ph, C)
     const float* dph_out;  // (B, num_ph, T)
@@ -988,6 +995,8 @@ __global__ __launch_bounds__(256) void ph_head_bwd_kernel(const PhHeadBwdParams 
                 float v = p.x0[off];
                 if (p.nin == 2) v = (v + p.x1[off]) / 2.0f;
                 else if (p.nin == 3) v = ((v + p.x1[off]) + p.x2[off]) / 3.0f;
+                else if (p.nin == 4) v = (((v + p.x1[off]) + p.x2[off]) + p.x3[off]) / 4.0f;
+    else if (p.nin == 4) v = (((v + p.x1[off]) + p.x2[off]) + p.x3[off]) / 4.0f;
                 s += v;
             }
         part[rs][c0 + ch] = s;

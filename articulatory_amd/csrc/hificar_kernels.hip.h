@@ -1538,12 +1538,14 @@ __global__ __launch_bounds__(512) void conv_pair_f32_kernel(const PairParams mp)
     conv_pair_body<MI, WM, WN, NC16, true>(mp);
 }
 
-// MRF mean + LeakyReLU + split for the upsample convs' input: out = split(lrelu(((x0 + x1) + x2) / n, slope)).
+// MRF mean + LeakyReLU + split for the upsample convs' input: out = split(lrelu((((x0 + x1) + x2) + x3) / n, slope)) over the n <= 4 blocks
+// (hifigan.py:226-230: cs = 0.0; cs += block_j(c) in order; c = cs / n).
 // Elementwise, HBM-bound; one thread = 8 channels (2 x 16 B in per input, 16 B hi + 16 B lo out).
 struct MrfSplitParams {
     const float* x0;
     const float* x1;
     const float* x2;
+    const float* x3;  // (a fourth residual block per stage: hifigan.py:134-145 builds one per resblock_kernel_sizes entry)
     char* out;
     int nin;
     int C;
@@ -1565,7 +1567,12 @@ __global__ __launch_bounds__(256) void mrf_split_kernel(const MrfSplitParams p) 
             f32x4 a = *reinterpret_cast<const f32x4*>(p.x0 + off + 4 * h);
             if (p.nin >= 2) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(p.x1 + off + 4 * h);
-                if (p.nin == 3) {
+                if (p.nin == 4) {
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.x2 + off + 4 * h);
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(p.x3 + off + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = (((a[e] + b[e]) + c[e]) + d[e]) / 4.0f;
+                } else if (p.nin == 3) {
                     const f32x4 c = *reinterpret_cast<const f32x4*>(p.x2 + off + 4 * h);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[e] = ((a[e] + b[e]) + c[e]) / 3.0f;
@@ -1756,7 +1763,8 @@ struct OutConvParams {
     const float* x0;
     const float* x1;
     const float* x2;
-    int nin;           // inputs averaged (1..3), as in ConvParams
+    const float* x3;
+    int nin;           // inputs averaged (1..4), as in MrfSplitParams
     const float* w;    // [k][C]
     float bias;
     const float* bias_ptr;  // training: the bias lives on the device (overrides `bias`)
@@ -1799,7 +1807,12 @@ __global__ __launch_bounds__(256) void output_conv_kernel(const OutConvParams p)
             v = *reinterpret_cast<const f32x4*>(p.x0 + off);
             if (p.nin >= 2) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(p.x1 + off);
-                if (p.nin == 3) {
+                if (p.nin == 4) {
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.x2 + off);
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(p.x3 + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (((v[e] + b[e]) + c[e]) + d[e]) / 4.0f;
+                } else if (p.nin == 3) {
                     const f32x4 c = *reinterpret_cast<const f32x4*>(p.x2 + off);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ((v[e] + b[e]) + c[e]) / 3.0f;
@@ -1867,7 +1880,8 @@ struct PhHeadParams {
     const float* x0;
     const float* x1;
     const float* x2;
-    int nin;          // ResBlock outputs averaged (1..3)
+    const float* x3;
+    int nin;          // ResBlock outputs averaged (1..4)
     const float* w;   // ph_fc.weight (num_ph, C)
     const float* bias;
     float* out;       // (B, num_ph, T)
@@ -1899,6 +1913,7 @@ __global__ __launch_bounds__(256) void ph_head_kernel(const PhHeadParams p) {
                 float v = p.x0[off];
                 if (p.nin == 2) v = (v + p.x1[off]) / 2.0f;
                 else if (p.nin == 3) v = ((v + p.x1[off]) + p.x2[off]) / 3.0f;
+                else if (p.nin == 4) v = (((v + p.x1[off]) + p.x2[off]) + p.x3[off]) / 4.0f;
                 s += v;
             }
         part[rs][c0 + ch] = s;

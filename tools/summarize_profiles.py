@@ -43,11 +43,15 @@ try:
     allt = json.load(open("profiles/hbm_traffic.json"))
 except Exception:
     allt = {}
-for prec in ("f32", "bf16x3"):
+# (file prefix / directory key, key in hbm_traffic.json, the profiled command): the two arithmetics of the headline leg, then the secondary legs
+LEGS = [("f32", "f32", "python bench.py --precision f32 --steps 3 --warmup 1 --no-cpu-baseline --no-fast-leg --no-batch-sweep --no-training --no-nonar --no-gblock"),
+        ("bf16x3", "bf16x3", "python bench.py --precision bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-fast-leg --no-batch-sweep --no-training --no-nonar --no-gblock"),
+        ("nonar", "nonar_f32", "python tools/leg_bench.py --leg nonar --steps 3 --warmup 1  (BASELINE config 2: non-AR 12-dim, batch 8)"),
+        ("gblock", "gblock_f32", "python tools/leg_bench.py --leg gblock --steps 3 --warmup 1  (GBlockGenerator, batch 64, chunk 25)")]
+for prec, tkey, cmd in LEGS:
     base = f"gpurun_out/prof_{tag}_{prec}"
     if not os.path.isdir(base + "_stats"):
         continue
-    cmd = f"python bench.py --precision {prec} --steps 3 --warmup 1 --no-cpu-baseline --no-fast-leg --no-batch-sweep"
     rows = list(csv.DictReader(open(find(base + "_stats", "*kernel_stats.csv"))))
     with open(f"profiles/{tag}_{prec}_kernel_stats.csv", "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats -f csv -- {cmd}  ({tag}, {prec}); durations in ns\n")
@@ -60,8 +64,8 @@ for prec in ("f32", "bf16x3"):
     wr, _ = counters(base + "_WRITE_SIZE")
     traffic = {}
     with open(f"profiles/{tag}_{prec}_pmc_hbm.csv", "w") as f:
-        f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --precision {prec} --steps 1 "
-                "--warmup 0 --no-cpu-baseline --no-roofline --no-fast-leg --no-batch-sweep\n# counter units KiB; gfx950 correction "
+        f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- {cmd.replace('--steps 3 --warmup 1', '--steps 1 --warmup 0')}"
+                "\n# counter units KiB; gfx950 correction "
                 "(MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of wide coalesced reads) applied in the last column = (2*FETCH + WRITE)*1024\n")
         f.write("Kernel,Launches,FETCH_SIZE_KiB_per_launch_raw,WRITE_SIZE_KiB_per_launch,HBM_bytes_per_launch_corrected\n")
         for k in fe:
@@ -71,11 +75,11 @@ for prec in ("f32", "bf16x3"):
             if "hificar" in k:
                 f.write(f"\"{k}\",{n},{v / n:.1f},{v2 / max(n2, 1):.1f},{b:.0f}\n")
                 traffic[short(k)] = round(b)
-    allt[prec] = traffic
+    allt[tkey] = traffic
     mf, dur = counters(base + "_mfma")
     with open(f"profiles/{tag}_{prec}_pmc_mfma.csv", "w") as f:
         f.write(f"# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace "
-                f"-- python bench.py --precision {prec} --steps 1 --warmup 0 ... ({tag}); per-launch averages.\n"
+                f"-- {cmd.replace('--steps 3 --warmup 1', '--steps 1 --warmup 0')} ({tag}); per-launch averages.\n"
                 "# Counter values are sums over the 8 XCDs.  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 1024 SIMDs): the share of\n"
                 "# SIMD-cycles in which the matrix pipe is busy (rocprofv3's MfmaUtil expression; gfx950 has no derived-counter section,\n"
                 "# MI355X_MICROARCH.md).  SQ_VALU_MFMA_BUSY_CYCLES / 1024 equals 64 x (fp32 MFMAs per SIMD) resp. 32 x (bf16 MFMAs) exactly.\n"
