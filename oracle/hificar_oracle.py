@@ -136,8 +136,11 @@ def generator_forward(w, params, c, ar=None, taps=None, spk_id=None, ph=None):
             taps[f"upsample{i}"] = c
         cs = 0.0
         for j in range(nb):
-            cs = cs + residual_block(w, f"blocks.{i * nb + j}", c, p["resblock_kernel_sizes"][j],
-                                     p["resblock_dilations"][j], slope, p["use_additional_convs"])
+            bj = residual_block(w, f"blocks.{i * nb + j}", c, p["resblock_kernel_sizes"][j],
+                                p["resblock_dilations"][j], slope, p["use_additional_convs"])
+            if taps is not None:
+                taps[f"blocks.{i * nb + j}"] = bj
+            cs = cs + bj
         c = cs / nb
         if taps is not None:
             taps[f"stage{i}"] = c

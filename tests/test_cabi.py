@@ -130,7 +130,6 @@ def test_set_weight_validation(lib):
     (dict(kernel_size=6), b"odd"),
     (dict(upsample_scales=[5, 4, 2, 2], upsample_kernel_sizes=[11, 8, 4, 4]), b"L_out"),
     (dict(channels=8), b"halvings"),
-    (dict(resblock_kernel_sizes=[3, 7, 11, 13], resblock_dilations=[[1]] * 4), b"n_blocks"),
 ])
 def test_create_rejects_unsupported(lib, over, msg):
     cfg = _native.make_config(_full_params(**over), _native.PREC_F32)
@@ -138,6 +137,22 @@ def test_create_rejects_unsupported(lib, over, msg):
     rc = lib.hificar_create(ctypes.byref(cfg), ctypes.byref(h))
     assert rc == -1
     assert msg in lib.hificar_last_error(), lib.hificar_last_error()
+
+
+def test_create_accepts_four_blocks_and_single_conv_layers(lib):
+    """Up to HIFICAR_MAX_BLOCKS = 4 residual blocks per stage (hifigan.py:134-145) and use_additional_convs = false (residual_block.py:191-205):
+    accepted since round 5; a fifth block is refused before the C ABI is reached."""
+    for over in (dict(resblock_kernel_sizes=[3, 7, 11, 13], resblock_dilations=[[1]] * 4), dict(use_additional_convs=False)):
+        cfg = _native.make_config(_full_params(**over), _native.PREC_F32)
+        h = ctypes.c_void_p()
+        assert lib.hificar_create(ctypes.byref(cfg), ctypes.byref(h)) == 0, lib.hificar_last_error()
+        w = np.zeros((256, 256, 3), dtype=np.float32)
+        shp = (ctypes.c_int64 * 3)(256, 256, 3)
+        rc = lib.hificar_set_weight(h, b"blocks.0.convs2.0.1.weight", w.ctypes.data, shp, 3)
+        assert rc == (0 if "resblock_kernel_sizes" in over else -1)  # no convs2 tensors without the additional convs
+        lib.hificar_destroy(h)
+    with pytest.raises(ValueError):
+        _native.make_config(_full_params(resblock_kernel_sizes=[3, 5, 7, 9, 11], resblock_dilations=[[1]] * 5), _native.PREC_F32)
 
 
 def test_create_accepts_any_width(lib):

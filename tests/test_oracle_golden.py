@@ -258,3 +258,42 @@ def test_oracle_conditioned_gradients_vs_reference(tag):
     assert sorted(grads) == sorted(k[6:].rsplit("::", 1)[0] for k in gold.files if k.startswith("grad::") and k.endswith(("::full", "::sum")))
     worst = max(O.check_packed(gold, "grad::" + k, v, 1e-4) for k, v in grads.items())
     assert worst < 2e-4, worst
+
+
+@pytest.mark.parametrize("tag", ["noadd", "blocks4"])
+def test_oracle_constructor_variants_vs_reference(tag):
+    """use_additional_convs=False (residual_block.py:191-205, 217-221) and four residual blocks per stage with unequal dilation counts
+    (hifigan.py:134-145, 226-230), fixtures of the REAL reference class (oracle/make_golden_variants.py): forward with every upsampler / ResBlock
+    output, the reference's ar_loop, the state_dict key list and the gradients of every parameter."""
+    import ast
+
+    from articulatory_amd.models import HiFiGANGenerator
+    from articulatory_amd.utils.synth import synth_state_dict
+
+    g = np.load(os.path.join(GOLDEN, f"gold_variant_{tag}.npz"))
+    params = dict(ast.literal_eval(str(g["params"])))
+    sd = synth_state_dict(params, seed=1234)
+    keys = [ln.split()[0] for ln in str(g["keys"]).splitlines()]
+    assert list(sd.keys()) == keys
+    model = HiFiGANGenerator(**params)  # the plugin class builds the same parameters (no convs2 / a fourth block per stage)
+    assert list(model.state_dict().keys()) == keys
+    assert all(tuple(v.shape) == sd[k].shape for k, v in model.state_dict().items())
+    w = O.fold_weight_norm(sd)
+    taps = {}
+    with torch.no_grad():
+        y = O.generator_forward(w, params, torch.from_numpy(g["c"]), torch.from_numpy(g["ar"]), taps=taps)
+    assert rel_err(y.numpy(), g["out"]) < 2e-6
+    nb = len(params["resblock_kernel_sizes"])
+    for i in range(4):
+        assert rel_err(taps[f"upsample{i}"].numpy(), g[f"tap::upsamples.{i}"]) < 2e-6
+    for b in range(4 * nb):
+        assert rel_err(taps[f"blocks.{b}"].numpy(), g[f"tap::blocks.{b}"]) < 2e-6
+    with torch.no_grad():
+        ya = O.ar_loop(w, params, torch.from_numpy(g["arloop_x"]), 2000, 80)
+    assert rel_err(ya.numpy(), g["arloop_out"]) < 2e-6
+    gp = dict(params, nonlinear_activation_params={"negative_slope": 1.0})
+    gsd = synth_state_dict(gp, seed=int(g["gseed"]))
+    out, grads = O.gradients(gsd, gp, g["gc"], g["gar"], g["gcot"])
+    assert O.check_packed(g, "gout", out, 2e-6) < 2e-6
+    for k, v in grads.items():
+        assert O.check_packed(g, "grad::" + k, v, 2e-4) < 2e-4, k
