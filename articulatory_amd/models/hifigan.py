@@ -766,8 +766,19 @@ class HiFiGANGenerator(_NativeGenerator):
             # spk_fc maps to in_channels values but is added before the phoneme channels are appended (hifigan.py:212-220):
             # the reference fails with a shape mismatch in forward; fail at construction here
             raise ValueError("use_spk_id together with use_ph is ill-formed in the reference (shape mismatch at hifigan.py:216)")
-        if nonlinear_activation != "LeakyReLU":
-            raise NotImplementedError(f"nonlinear_activation={nonlinear_activation!r}: only LeakyReLU is built")
+        # the reference builds getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params) (hifigan.py:121-123, 142-143).  The kernels'
+        # activation is max(x, slope * x) with 0 <= slope <= 1: LeakyReLU, and with it ReLU (slope 0) and Identity (slope 1); other modules are not built
+        nonlinear_activation_params = dict(nonlinear_activation_params or {})
+        if nonlinear_activation == "ReLU":
+            if set(nonlinear_activation_params) - {"inplace"}:
+                raise ValueError(f"ReLU takes no parameters besides inplace: {nonlinear_activation_params}")
+            nonlinear_activation_params = {"negative_slope": 0.0}
+        elif nonlinear_activation == "Identity":
+            nonlinear_activation_params = {"negative_slope": 1.0}
+        elif nonlinear_activation != "LeakyReLU":
+            raise NotImplementedError(f"nonlinear_activation={nonlinear_activation!r}: LeakyReLU, ReLU and Identity are built")
+        elif set(nonlinear_activation_params) - {"negative_slope", "inplace"}:
+            raise ValueError(f"LeakyReLU parameters: {nonlinear_activation_params}")
         for name, val in (("paddings", paddings), ("output_paddings", output_paddings)):
             if val is not None and any(v != "default" for v in val):
                 raise NotImplementedError(f"{name}: only None / 'default' entries are supported (as in the reference)")

@@ -78,7 +78,13 @@ def _cfg(params):
         use_spk_id=False, num_spk=None, spk_emb_size=32, use_ph=False, num_ph=None, ph_emb_size=8, use_ph_loss=False,
     )
     p.update({k: v for k, v in params.items() if k in p})
-    assert p["nonlinear_activation"] == "LeakyReLU"
+    # hifigan.py:121-123: getattr(torch.nn, nonlinear_activation)(**params); ReLU and Identity are LeakyReLU at slope 0 / 1
+    if p["nonlinear_activation"] == "ReLU":
+        p["nonlinear_activation_params"] = {"negative_slope": 0.0}
+    elif p["nonlinear_activation"] == "Identity":
+        p["nonlinear_activation_params"] = {"negative_slope": 1.0}
+    else:
+        assert p["nonlinear_activation"] == "LeakyReLU"
     return p
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors of the REAL reference generator for two constructor options no shipped YAML uses (round 5):
   noadd    use_additional_convs=False (articulatory/layers/residual_block.py:151, 191-205, 217-221: a ResBlock layer is x = x + convs1[d](x))
+  relu     nonlinear_activation="ReLU" (hifigan.py:40-41, 121-123: any torch.nn activation module by name); forward fixtures only
   blocks4  FOUR residual blocks per stage (articulatory/models/hifigan.py:134-145 builds one per resblock_kernel_sizes entry; the MRF mean
            is cs / 4, :226-230) with unequal numbers of dilations per block
 Per variant: a forward of the width-64 model with every ResBlock output and every upsampler output tapped (eval, weight norm removed, as
@@ -27,6 +28,9 @@ from make_golden_grad import pack  # noqa: E402
 VARIANTS = {
     "noadd": dict(channels=64, use_additional_convs=False),
     "blocks4": dict(channels=64, resblock_kernel_sizes=[3, 5, 7, 11], resblock_dilations=[[1, 3], [1, 3, 5], [1], [1, 3, 5]]),
+    # another activation module by name (hifigan.py:40-41, 121-123): torch.nn.ReLU — forward fixtures only (its kinks make element-wise gradient
+    # fixtures a coin flip; the GPU test compares gradients with the float64 oracle flip-robustly)
+    "relu": dict(channels=64, nonlinear_activation="ReLU", nonlinear_activation_params={}),
 }
 
 
@@ -66,6 +70,10 @@ def main():
         with torch.no_grad():
             out["arloop_x"] = x
             out["arloop_out"] = ref_ar_loop(g, torch.from_numpy(x), dict(cfg, generator_params=params, batch_max_steps=2000)).numpy()  # chunks of 25 frames + a 10-frame tail
+        if params["nonlinear_activation"] != "LeakyReLU":
+            np.savez_compressed(os.path.join(outdir, f"gold_variant_{tag}.npz"), **out)
+            print(f"gold_variant_{tag}.npz", os.path.getsize(os.path.join(outdir, f"gold_variant_{tag}.npz")), "(forward only)")
+            continue
         # gradients: weight norm in the graph, slope 1
         gparams = dict(params, nonlinear_activation_params={"negative_slope": 1.0})
         for seed in range(880, 920):

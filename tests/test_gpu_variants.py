@@ -1,6 +1,6 @@
 """Constructor options of the reference's HiFiGANGenerator that no shipped YAML uses, on a MI355X through the C ABI (round 5):
-``use_additional_convs=False`` (articulatory/layers/residual_block.py:151, 191-205, 217-221) and a FOURTH residual block per stage with unequal
-dilation counts (articulatory/models/hifigan.py:134-145, 226-230) — against golden vectors of the REAL reference class
+``use_additional_convs=False`` (articulatory/layers/residual_block.py:151, 191-205, 217-221), a FOURTH residual block per stage with unequal
+dilation counts (articulatory/models/hifigan.py:134-145, 226-230) and ``nonlinear_activation="ReLU"`` (:40-41, 121-123) — against golden vectors of the REAL reference class
 (oracle/make_golden_variants.py) and against the CPU oracle.  ``pytest -m gpu``."""
 import ast
 import os
@@ -16,6 +16,7 @@ from oracle import hificar_oracle as O
 
 pytestmark = pytest.mark.gpu
 TAGS = ["noadd", "blocks4"]
+FWD_TAGS = TAGS + ["relu"]  # nonlinear_activation="ReLU" (hifigan.py:40-41, 121-123): forward fixtures; its gradients against the float64 oracle below
 
 
 def load(tag):
@@ -34,7 +35,7 @@ def build(params, seed, precision="f32", train=False):
     return m.eval().to("cuda:0"), sd
 
 
-@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("tag", FWD_TAGS)
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_forward_every_block_and_ar_loop_vs_reference_golden(tag, precision):
     g, params = load(tag)
@@ -96,7 +97,7 @@ def test_full_width_ragged_batch_vs_oracle(tag):
         assert float(y[b, 80 * n:].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("tag", FWD_TAGS)
 def test_training_iterations_move_the_variant(tag):
     """A few Adam steps through the autograd node: the loss falls, every parameter has a finite gradient — and, with real LeakyReLU slope, the
     gradients agree with the float64 oracle in L2 (flip-robust)."""
