@@ -79,7 +79,7 @@ typedef struct hificar_config {
     int32_t resblock_kernel_sizes[HIFICAR_MAX_BLOCKS];
     int32_t n_dilations[HIFICAR_MAX_BLOCKS];
     int32_t resblock_dilations[HIFICAR_MAX_BLOCKS][HIFICAR_MAX_DILATIONS];
-    int32_t use_additional_convs; /* must be 1 */
+    int32_t use_additional_convs; /* 0: a ResBlock layer is x + convs1[d](x) (residual_block.py:191-205, 217-221), no convs2 tensors */
     int32_t bias;                 /* ResBlock conv bias flag */
     float lrelu_slope;            /* nonlinear_activation_params.negative_slope */
     int32_t use_tanh;
