@@ -240,7 +240,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
 #ifndef HIFICAR_SPLIT_PASS
 #define HIFICAR_SPLIT_PASS 0  // (A/B: measured equal on every stage shape — the loader waves' work per tile, not its placement, is the co-bottleneck)
 #endif
-    constexpr bool kSplitPass = KS == 1 && HIFICAR_SPLIT_PASS != 0;  // the previous tile's output pass spread over all items (one more barrier per tile)
+    // the previous tile's output pass spread over all items (one more barrier per tile) — an out-buffer form: the direct-output kernels have no
+    // out-buffer (and no LDS behind the staging ring) for it to read
+    constexpr bool kSplitPass = KS == 1 && !DOUT && HIFICAR_SPLIT_PASS != 0;
     constexpr int NTHR = (NW + 4) * 64;
     constexpr int kFirstLoader = NW;
     (void)kFirstLoader;
