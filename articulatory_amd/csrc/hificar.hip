@@ -138,6 +138,18 @@ struct hificar_handle {
         int* d_tiles = nullptr;
     };
     std::map<std::string, Sched> scheds;
+    // chained launches (conv_f32chain_kernel: the layers of a ResBlock stage in one launch): per launch shape the per-tile counters (arena memory,
+    // zeroed once) and how many launches have counted on them
+    struct ChainState {
+        unsigned* d_flags = nullptr;
+        unsigned epoch = 0;
+    };
+    std::map<std::string, ChainState> chains;
+    bool use_chain = false;        // HIFICAR_CHAIN=1: the layers of a chainable ResBlock stage as one launch (round 5: built, bit-identical, 1.8 % SLOWER —
+                                   // the write-through stores / L2-bypassing loads the hand-off needs cost more than the launches it removes:
+                                   // profiles/r05_chain_launch.txt)
+    int* chain_err = nullptr;      // pinned host memory the device writes when a chained launch gave up waiting (never in a correct run)
+    int* d_chain_err = nullptr;
     std::map<std::string, int> tile_picks;  // launch shape -> index into kTileCfgs (launch_conv's choice, cached: it simulates the LPT assignment)
     struct Arena {
         char* d = nullptr;
@@ -305,6 +317,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (const char* e = getenv("HIFICAR_PAIR_SMALL")) h->pair_small = atoi(e) != 0;  // (A/B runs)
     if (const char* e = getenv("HIFICAR_XCD_ORDER")) h->xcd_order = atoi(e) != 0;    // (A/B runs)
     if (const char* e = getenv("HIFICAR_LPT")) h->use_lpt = atoi(e) != 0;
+    if (const char* e = getenv("HIFICAR_CHAIN")) h->use_chain = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_KSPLIT")) h->ksplit = atoi(e);
     if (const char* e = getenv("HIFICAR_AR_DUAL_MIN")) h->ar_dual_min = atoi(e);  // (A/B runs, tests)
     if (const char* e = getenv("HIFICAR_AR_DUAL_MAX")) h->ar_dual_max = atoi(e);
@@ -631,6 +644,11 @@ static hipError_t set_lds_attr_f() {
 // the register-blocked (NB = 2) shapes: (MI, WM, WN)
 #define HIFICAR_FOR_NB_TILES(X, nc) X(2, 2, 2, nc) X(2, 4, 1, nc) X(2, 1, 4, nc)
 #define HIFICAR_FOR_ALL_NB_TILES(X) HIFICAR_FOR_NB_TILES(X, 2) HIFICAR_FOR_NB_TILES(X, 4) X(4, 1, 4, 1)
+// chained ResBlock-stage launches (conv_f32chain_kernel): the shapes whose tiles are at least as tall as the widest halo of the shipped stages
+#define HIFICAR_FOR_CHAIN_TILES(X) \
+    X(4, 1, 4, 1) X(4, 2, 2, 1) X(4, 4, 1, 1) X(2, 1, 4, 1) X(2, 2, 2, 1) X(2, 4, 1, 1) \
+    X(4, 1, 4, 2) X(4, 2, 2, 2) X(4, 4, 1, 2) X(2, 1, 4, 2) X(2, 2, 2, 2) X(2, 4, 1, 2) \
+    X(4, 1, 4, 4) X(4, 2, 2, 4) X(4, 4, 1, 4) X(2, 1, 4, 4) X(2, 2, 2, 4) X(2, 4, 1, 4)
 // split-K forms: (MI, NC16)
 #define HIFICAR_FOR_SK_TILES(X) X(1, 1) X(2, 1) X(4, 1) X(1, 2) X(2, 2) X(4, 2) X(1, 4) X(2, 4) X(4, 4)
 
@@ -673,6 +691,19 @@ static int engine_setup(hificar_handle* h) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_f32_kernel<mi, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIFICAR_FOR_SK_TILES(HIFICAR_SET_ATTR_SK)
 #undef HIFICAR_SET_ATTR_SK
+#define HIFICAR_SET_ATTR_CH(mi, wm, wn, nc) \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32chain_kernel<mi, wm, wn, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIFICAR_FOR_CHAIN_TILES(HIFICAR_SET_ATTR_CH)
+#undef HIFICAR_SET_ATTR_CH
+    if (!h->chain_err) {
+        void* p = nullptr;
+        HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocMapped));
+        h->chain_err = static_cast<int*>(p);
+        *h->chain_err = 0;
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, p, 0));
+        h->d_chain_err = static_cast<int*>(dp);
+    }
     if (h->arenas.empty()) {
         int rca = arena_add(h, 0);
         if (rca != HIFICAR_OK) return rca;
@@ -931,6 +962,7 @@ static int arena_take(hificar_handle* h, size_t bytes, char** d, char** hm) {
             // the device first (rare, off the hot path; hificar_forward buckets non-AR lengths so that keys repeat)
             HIP_TRY(hipDeviceSynchronize());
             h->scheds.clear();
+            h->chains.clear();
             for (auto& a : h->arenas) a.used = 0;
             std::sort(h->arenas.begin(), h->arenas.end(), [](const hificar_handle::Arena& x, const hificar_handle::Arena& y) { return x.cap < y.cap; });
             if (bytes > h->arenas.back().cap) return fail(HIFICAR_E_INVALID, "tile schedule of %zu bytes exceeds the arena", bytes);
@@ -1075,12 +1107,34 @@ struct ConvRep {
     long long zs_x = 0, zs_w = 0, zs_y = 0, zs_b = 0;
 };
 
+// A chained launch under construction (launch_chain): launch_conv is called once in PICK mode (the tile shape for the chain's widest halo) and
+// once per layer in FILL mode (parameters instead of a launch).
+struct ChainBuild {
+    enum { PICK, FILL } phase = PICK;
+    int halo_all = 0;     // widest halo over every layer of the chain
+    TileCfg tc = {0, 0, 0, 0, 0, 0};
+    int nc16 = 0;
+    int layer = 0;        // FILL: which layer this call describes
+    MultiConvParams mp;   // FILL, layer 0: the chain's common parameters (shapes, lengths, tile list)
+    ChainCtx cx;
+    dim3 grid;
+    size_t lds = 0;
+    double flops = 0.0, bytes = 0.0;
+    std::string key;
+};
+
+static bool dout_enabled() {
+    static const bool on = !getenv("HIFICAR_DOUT") || atoi(getenv("HIFICAR_DOUT")) != 0;
+    return on;
+}
+
 static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows, const ConvIO* io,
-                              float slope_out, const Ragged& rg, hipStream_t stream, const ConvRep& zr = ConvRep()) {
+                              float slope_out, const Ragged& rg, hipStream_t stream, const ConvRep& zr = ConvRep(), ChainBuild* cb = nullptr) {
     const ConvLayer& L0 = *layers[0];
     const bool f32 = h->precision == HIFICAR_PREC_F32;  // rows are plain fp32 LeakyReLU(x) instead of split rows
     int halo_all = 0;
     for (int b = 0; b < nbr; ++b) halo_all = std::max(halo_all, layers[b]->off_max - layers[b]->off_min);
+    if (cb) halo_all = std::max(halo_all, cb->halo_all);  // (one staging-buffer size and one tile shape for every layer of a chain)
     // Tile shape: simulate the kernel's static tile walk (workgroup w takes tiles w, w+G, ...; branch-major order) and
     // take the shape with the smallest makespan.  A tile costs its MFMA issue cycles (all four MFMA waves run in
     // lock step: 3*MI MFMAs of 32 cycles per 16-channel K slab) plus a fixed per-tile and per-item overhead.
@@ -1090,7 +1144,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     // Direct output (round 4, conv_f32do_kernel): the dense exact-fp32 launches store their tiles straight from the MFMA waves' accumulators — no LDS
     // out-buffer (its bytes are free for taller tiles / wider halos below), no output pass in the loader waves.  +1.5 % end to end; HIFICAR_DOUT=0
     // restores the out-buffer form (A/B runs).
-    static const bool dout_on = !getenv("HIFICAR_DOUT") || atoi(getenv("HIFICAR_DOUT")) != 0;
+    const bool dout_on = dout_enabled();
     // HIFICAR_NB: 0 = never use the register-blocked (NB = 2) wave tiles, 1 = when the cost model prefers them, 2 = whenever one fits, 3 = only the
     // 128-accumulator shape forced (A/B runs: tools/nb_ab.sh; measured in profiles/r04_nb_register_blocking.txt)
     static const int nb_env = getenv("HIFICAR_NB") ? atoi(getenv("HIFICAR_NB")) : -1;
@@ -1119,8 +1173,10 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         pick_key += layers[b]->name;
     }
     pick_key += '|' + std::to_string(nseq) + 'x' + std::to_string(rows) + 'z' + std::to_string(zr.n);
+    if (cb) pick_key += "|chain" + std::to_string(halo_all);
     const auto cached_pick = h->tile_picks.find(pick_key);
-    if (cached_pick != h->tile_picks.end()) tc = kTileCfgs[cached_pick->second];
+    if (cb && cb->phase == ChainBuild::FILL) tc = cb->tc;
+    else if (cached_pick != h->tile_picks.end()) tc = kTileCfgs[cached_pick->second];
     else
     for (int ti = 0; ti < 16; ++ti) {
         const TileCfg& t = kTileCfgs[ti];
@@ -1144,6 +1200,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         if (fc1 == L0.cin_pad && nbr == 1 && zr.n == 1 && !(t.KS == 1 && t.MI == fmi1 && t.WM == fwm1 && t.WN == fwn1)) continue;
         if (t.KS == 4 && (h->ksplit == 0 || nsteps_min < 2)) continue;
         if (t.KS == 1 && h->ksplit == 2 && nsteps_min >= 2) continue;
+        if (cb && (t.KS != 1 || t.NB != 1 || t.MI < 2 || t.CH)) continue;  // (the shapes conv_f32chain_kernel is built for)
         const long long tiles_per_branch = (long long)nseq * ((rows + TM - 1) / TM) * ((L0.n_blocks32 + t.WN * t.NB - 1) / (t.WN * t.NB));
         const long long total = tiles_per_branch * nbr * zr.n;
         const int G = (int)std::min<long long>(total, h->num_cus);
@@ -1202,9 +1259,14 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
             best_ti = ti;
         }
     }
-    if (cached_pick == h->tile_picks.end()) {
+    if (cached_pick == h->tile_picks.end() && !(cb && cb->phase == ChainBuild::FILL)) {
         if (h->tile_picks.size() > 20000) h->tile_picks.clear();  // (a very large number of distinct launch shapes: start over)
         h->tile_picks.emplace(pick_key, best_ti);
+    }
+    if (cb && cb->phase == ChainBuild::PICK) {
+        cb->tc = tc;
+        cb->nc16 = (tc.CH ? tc.CH : L0.chunk16) / 16;
+        return HIFICAR_OK;
     }
     const int TM = tc.WM * tc.MI * 32;
     const int chunk_sel = tc.CH ? tc.CH : L0.chunk16, RB = chunk_sel * 4;
@@ -1275,6 +1337,35 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         int rc2 = get_schedule(h, key, costs, (int)grid.x, stream, &mp.sched_start, &mp.sched_tiles);
         if (rc2 != HIFICAR_OK) return rc2;
     }
+    if (cb) {  // FILL: this layer's per-branch fields go into the chain's table; layer 0 also provides the common parameters
+        if (!dout) return fail(HIFICAR_E_INVALID, "internal: chained layers need the direct-output form");
+        if (cb->layer == 0) {
+            cb->mp = mp;
+            cb->grid = grid;
+            cb->lds = lds;
+            cb->key = pick_key;
+        }
+        for (int b = 0; b < 3; ++b) {
+            ChainLayerBranch& q = cb->cx.lb[cb->layer][b];
+            memset(&q, 0, sizeof(q));
+            if (b >= nbr) continue;
+            const ConvParams& pb = mp.p[b];
+            q.w16 = pb.w16;
+            q.bias = pb.bias;
+            q.res = pb.res;
+            q.y = pb.y;
+            q.xs = pb.xs;
+            q.ys = pb.ys;
+            q.ntaps = pb.ntaps;
+            q.off_min = pb.off_min;
+            q.halo = pb.halo;
+            q.tap_step = pb.tap_step;
+            q.tap_off0 = pb.tap_off0[0];
+        }
+        cb->flops += flops;
+        cb->bytes += bytes;
+        return HIFICAR_OK;
+    }
     char kname[96];
     if (dout) snprintf(kname, sizeof(kname), "conv_f32do_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, nc16);
     else if (tc.KS == 4) snprintf(kname, sizeof(kname), "%s<%d,%d>", f32 ? "conv_sk_f32_kernel" : "conv_sk_bf16x3_kernel", tc.MI, nc16);
@@ -1300,6 +1391,83 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     HIFICAR_FOR_SK_TILES(HIFICAR_DISPATCH_SK)
 #undef HIFICAR_DISPATCH_SK
     if (e != hipSuccess) return fail(HIFICAR_E_HIP, "conv launch (%s, %s) failed: %s", L0.name.c_str(), kname, hipGetErrorString(e));
+    return HIFICAR_OK;
+}
+
+template <int MI, int WM, int WN, int NC16>
+static hipError_t launch_chain_t(const MultiConvParams& mp, const ChainCtx& cx, dim3 grid, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((conv_f32chain_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp, cx);
+    return hipGetLastError();
+}
+
+// The layers of a ResBlock stage as ONE launch (conv_f32chain_kernel, ChainCtx in hificar_kernels.hip.h): lay[l] / io[l] are layer l's branches —
+// the same blocks in the same order in every layer, every layer C -> C on the same rows.  Returns HIFICAR_OK with *done = false when the stage is
+// not chainable (the caller then launches layer by layer).
+static int launch_chain(hificar_handle* h, const ConvLayer* const (*lay)[3], const ConvIO (*io)[3], int nlayers, int nbr, int nseq, int rows,
+                        float slope_out, const Ragged& rg, hipStream_t stream, bool* done) {
+    *done = false;
+    if (!h->use_chain || h->precision != HIFICAR_PREC_F32 || !dout_enabled() || h->shared_chip || h->train || nlayers < 2 || nlayers > kMaxChain || nbr > 3)
+        return HIFICAR_OK;
+    ChainBuild cb;
+    memset(&cb.cx, 0, sizeof(cb.cx));
+    for (int l = 0; l < nlayers; ++l)
+        for (int b = 0; b < nbr; ++b) {
+            const ConvLayer& L = *lay[l][b];
+            if (L.n_phase != 1 || L.cin_pad != lay[0][0]->cin_pad || L.cout_total != lay[0][0]->cout_total || L.chunk16 != lay[0][0]->chunk16 || L.cin_pad / L.chunk16 < 2 ||
+                io[l][b].x_up > 1 || io[l][b].x_rows || io[l][b].x_row_bytes || io[l][b].x_seq_bytes || io[l][b].mask_src)
+                return HIFICAR_OK;
+            cb.halo_all = std::max(cb.halo_all, L.off_max - L.off_min);
+        }
+    int rc;
+    cb.phase = ChainBuild::PICK;
+    if ((rc = launch_conv(h, lay[0], nbr, nseq, rows, io[0], slope_out, rg, stream, ConvRep(), &cb)) != HIFICAR_OK) return rc;
+    const TileCfg tc = cb.tc;
+    const int TM = tc.WM * tc.MI * 32;
+    // a tile's writes land in a buffer the PREVIOUS layer's neighbouring tiles read as halo; the counters it waits for cover exactly the row tiles
+    // next to it, so every halo has to stay inside one neighbouring tile
+    if (tc.KS != 1 || tc.NB != 1 || tc.MI < 2 || TM < cb.halo_all) return HIFICAR_OK;
+    cb.phase = ChainBuild::FILL;
+    for (int l = 0; l < nlayers; ++l) {
+        cb.layer = l;
+        if ((rc = launch_conv(h, lay[l], nbr, nseq, rows, io[l], slope_out, rg, stream, ConvRep(), &cb)) != HIFICAR_OK) return rc;
+    }
+    const MultiConvParams& mp = cb.mp;
+    // per-tile counters of this launch shape: [layer][branch][sequence x row tile], cumulative over launches
+    const size_t nflags = (size_t)nlayers * mp.n_branches * mp.nseq_tiles;
+    const std::string key = cb.key + "|L" + std::to_string(nlayers);
+    auto it = h->chains.find(key);
+    if (it == h->chains.end()) {
+        char *dp = nullptr, *hp = nullptr;
+        if ((rc = arena_take(h, nflags * sizeof(unsigned), &dp, &hp)) != HIFICAR_OK) return rc;
+        HIP_TRY(hipMemsetAsync(dp, 0, nflags * sizeof(unsigned), stream));
+        hificar_handle::ChainState st;
+        st.d_flags = reinterpret_cast<unsigned*>(dp);
+        it = h->chains.emplace(key, st).first;
+    }
+    hificar_handle::ChainState& st = it->second;
+    if ((unsigned long long)(st.epoch + 2) * (unsigned)mp.ngroups >= 0xF0000000ull) {  // (after ~10^9 launches: start the counters over, in stream order)
+        HIP_TRY(hipMemsetAsync(st.d_flags, 0, nflags * sizeof(unsigned), stream));
+        st.epoch = 0;
+    }
+    cb.cx.nlayers = nlayers;
+    cb.cx.flags = st.d_flags;
+    cb.cx.want = (st.epoch + 1) * (unsigned)mp.ngroups;
+    cb.cx.err = h->d_chain_err;
+    ++st.epoch;
+    char kname[96];
+    snprintf(kname, sizeof(kname), "conv_f32chain_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, cb.nc16);
+    if (h->profile_detail) {
+        const size_t n = strlen(kname);
+        snprintf(kname + n, sizeof(kname) - n, "|%s x%d L%d", lay[0][0]->name.c_str(), nbr, nlayers);
+    }
+    ProfScope prof(h, stream, kname, cb.flops, cb.bytes);
+    hipError_t e = hipErrorInvalidValue;
+#define HIFICAR_DISPATCH_CH(mi, wm, wn, nc) \
+    if (tc.MI == mi && tc.WM == wm && tc.WN == wn && cb.nc16 == nc) e = launch_chain_t<mi, wm, wn, nc>(mp, cb.cx, cb.grid, cb.lds, stream);
+    HIFICAR_FOR_CHAIN_TILES(HIFICAR_DISPATCH_CH)
+#undef HIFICAR_DISPATCH_CH
+    if (e != hipSuccess) return fail(HIFICAR_E_HIP, "chained conv launch (%s) failed: %s", kname, hipGetErrorString(e));
+    *done = true;
     return HIFICAR_OK;
 }
 
@@ -1721,6 +1889,14 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             // activated stream of each branch: where the next conv1 reads its input.  It alternates between x_s[j] and
             // xt_s[j]: a launch never writes the buffer it (or a neighbouring tile, through the halo) reads.
             const char* u_act = tp ? tp->u_s[i] : ws.u_s;
+            // The stage's layers, conv1(d0), conv2(d0), conv1(d1), ...: first collected (`collect`), so that a chainable stage — inference, exact fp32,
+            // every block with the same number of dilations, no fused pairs, no taps — runs as ONE launch (launch_chain); otherwise launched one by one.
+            const ConvLayer* ch_lay[kMaxChain][3];
+            ConvIO ch_io[kMaxChain][3];
+            int ch_n = 0, ch_nbr = -1;
+            bool ch_ok = !tp && !tapping && add_convs && nbk <= 3 && 2 * max_d <= kMaxChain;
+            for (int j = 0; j < nbk; ++j) ch_ok = ch_ok && cfg.n_dilations[j] == max_d;
+            auto run_layers = [&](bool collect) -> int {
             const char* cur_s[kMaxBlk] = {u_act, u_act, u_act, u_act};
             for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
                 const ConvLayer* l1[kMaxBlk];
@@ -1759,6 +1935,22 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     jn[n] = j;
                     ++n;
                 }
+                if (collect) {
+                    if (fuse || n < 1 || n > 3 || (ch_nbr >= 0 && n != ch_nbr)) {
+                        ch_ok = false;
+                        return HIFICAR_OK;
+                    }
+                    ch_nbr = n;
+                    for (int q = 0; q < n; ++q) {
+                        ch_lay[ch_n][q] = l1[q];
+                        ch_io[ch_n][q] = io1[q];
+                        ch_lay[ch_n + 1][q] = l2[q];
+                        ch_io[ch_n + 1][q] = io2[q];
+                    }
+                    ch_n += 2;
+                    for (int q = 0; q < n; ++q) cur_s[jn[q]] = lbl_out[q];
+                    continue;
+                }
                 if (fuse) {
                     for (int q0 = 0; q0 < n; q0 += 3)
                         if ((rc = launch_pair(h, l1 + q0, l2 + q0, std::min(3, n - q0), B, rows, iop + q0, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
@@ -1779,6 +1971,14 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     if ((rc = tap_block(jn[q], d, xres[jn[q]])) != HIFICAR_OK) return rc;
                 for (int q = 0; q < n; ++q) cur_s[jn[q]] = fuse ? pair_out[q] : lbl_out[q];
             }
+            return HIFICAR_OK;
+            };
+            bool chained = false;
+            if (ch_ok && h->use_chain) {
+                if ((rc = run_layers(true)) != HIFICAR_OK) return rc;
+                if (ch_ok && ch_n >= 2 && (rc = launch_chain(h, ch_lay, ch_io, ch_n, ch_nbr, B, rows, cfg.lrelu_slope, rg, stream, &chained)) != HIFICAR_OK) return rc;
+            }
+            if (!chained && (rc = run_layers(false)) != HIFICAR_OK) return rc;
         }
     }
     if (cfg.use_ph_loss && cond.ph_out) {  // phoneme-loss head on the last stage's MRF mean (hifigan.py:232-237)
@@ -1812,6 +2012,11 @@ static int check_ready(hificar_handle* h, int B, int T, void* ws, size_t ws_byte
     if (!h) return fail(HIFICAR_E_INVALID, "null handle");
     if (!h->finalized) return fail(HIFICAR_E_STATE, "hificar_finalize has not been called");
     if (B < 1 || T < 1) return fail(HIFICAR_E_INVALID, "B=%d, T=%d must be positive", B, T);
+    if (h->chain_err && *h->chain_err) {  // (written by the device: a chained launch of an earlier call gave up waiting for a producer tile)
+        *h->chain_err = 0;
+        return fail(HIFICAR_E_HIP, "an earlier chained conv launch timed out waiting for another workgroup's tile (two chained launches competing for the "
+                    "CUs?); its output is invalid.  HIFICAR_CHAIN=0 runs one launch per layer");
+    }
     const size_t need = hificar_workspace_bytes(h, B, T);
     if (!ws || ws_bytes < need) return fail(HIFICAR_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
     if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) return fail(HIFICAR_E_INVALID, "workspace must be 256-byte aligned");

@@ -120,6 +120,35 @@ struct MultiConvParams {
     int xcd_order;  // 1 (gridDim.x == total_tiles, no schedule): XCD-contiguous tile order, see tile_of
 };
 
+// A CHAINED launch (round 5, conv_f32chain_kernel): the layers of a ResBlock stage — conv1(d0), conv2(d0), conv1(d1), ... each with up to three
+// branches — as ONE persistent launch.  A workgroup walks the same tile list once per layer; layer l + 1's tile (branch, sequence, row tile) only waits
+// for the row tiles of (branch, sequence) in layer l that its input window touches — per-tile counters, no grid barrier — so the fill / drain of a
+// launch (first DMA, tail imbalance, kernel boundary: ~10 us of a 180-us launch) is paid once per stage instead of once per layer.
+//   producer: write-through (sc1) stores -> s_waitcnt vmcnt(0) in front of a later item barrier -> one relaxed agent-scope atomic add on the tile's counter
+//   consumer: a loader lane polls the counters of the row tiles it needs, then stages with sc1 LDS-DMA (never served from a stale L2 line)
+// (the hand-off recipe of MI355X_MICROARCH.md, "handoff-flag" / "publish-large"; tools/chain_probe.hip measured the same data flow).
+// Counters are cumulative over launches: a tile's counter reads (launches so far) x ngroups once all its channel groups are stored.
+constexpr int kMaxChain = 8;  // 2 x HIFICAR_MAX_DILATIONS layers of a stage
+// what differs from layer to layer of a chain, per branch (everything else — shapes, lengths, the tile list — is the chain's common MultiConvParams).
+// Kernel-argument memory: scalar loads, pointers known to be global (a table in device memory would turn every weight load into a flat load).
+struct ChainLayerBranch {
+    const bf16x8* w16;
+    const float* bias;
+    const float* res;
+    float* y;
+    const char* xs;
+    char* ys;
+    int ntaps, off_min, halo, tap_step, tap_off0;
+    int pad_;
+};
+struct ChainCtx {
+    ChainLayerBranch lb[kMaxChain][3];
+    int nlayers;
+    unsigned* flags;   // [nlayers][n_branches][nseq_tiles]
+    unsigned want;     // a complete row tile's counter after THIS launch
+    int* err;          // host-visible: set when a wait gave up (never in a correct run; the host raises on its next call)
+};
+
 #ifdef HIFICAR_TRACE
 // (dev builds only) s_memtime is a per-XCD shader-clock counter; the first and the last stamp of a workgroup's wave 0 additionally record
 // s_memrealtime (100 MHz, one time base for the whole device) so that a launch's span and the gap to the next launch can be measured
@@ -139,6 +168,17 @@ __device__ unsigned long long g_trace_rt_slots[4][64];  // s_memrealtime of ever
 #endif
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+// 16-byte output store; WT: write-through (sc1) — the rows are read by other workgroups of the same launch (chained layers)
+template <bool WT>
+__device__ __forceinline__ void store16(float* p, f32x4 v) {
+#ifdef HIFICAR_CHAIN_PLAIN  // (dev timing experiment: plain stores / nt loads inside a chained launch — results are NOT valid)
+    *reinterpret_cast<f32x4*>(p) = v;
+#else
+    if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
 
 // Software-pipeline pin for one K-slab step of the conv kernels.  The source issues the NEXT slab's LDS fragment reads (and the weight
 // fragment loads two taps ahead) before the CURRENT slab's MFMAs, but hipcc's scheduler sinks every ds_read to just above its first use
@@ -230,9 +270,10 @@ __device__ __forceinline__ void pin_slab_step() {
 // (bias, residual, LeakyReLU, 16-byte stores: lane (li, g) owns row li and four adjacent channels per register quad) — no LDS out-buffer, no
 // output pass in the loader waves, which then only stage.  Trades the loaders' share of the SIMDs' issue slots during the K loop (and the waits
 // at the out-buffer hand-over barriers) for an epilogue the matrix pipe idles through: +1.5 % end to end (37.41 -> 37.96 M samples/s).
-template <int MI, int WM, int WN, int NC16, bool F32, int KS = 1, int NB = 1, bool DOUT = false>
-__device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
+template <int MI, int WM, int WN, int NC16, bool F32, int KS = 1, int NB = 1, bool DOUT = false, bool CHAIN = false>
+__device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const ChainCtx* cx = nullptr, int layer = 0) {
     static_assert(!DOUT || (F32 && KS == 1 && NB == 1), "direct output: exact fp32, dense form, one channel block per wave");
+    static_assert(!CHAIN || DOUT, "chained layers: the direct-output form");
     static_assert(NB == 1 || (NB == 2 && KS == 1), "one or two channel blocks per MFMA wave");
     static_assert(KS == 1 || (KS == 4 && WM == 1 && WN == 1), "split-K: four waves share one 32-channel block");
     static_assert(KS == 4 || WM * WN == 4 || WM * WN == 8, "4 or 8 MFMA waves per workgroup");
@@ -267,6 +308,18 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     const int nchunks = mp.p[0].cin / CH;  // identical for all branches of a launch
     const int tiles_per_branch = mp.ngroups * mp.nseq_tiles;
     const int buf_bytes = mp.buf_bytes;
+    // per-layer fields of branch b: the launch's own ConvParams, or — chained layers — this layer's entry of the chain's table (kernel arguments)
+    auto L_w16 = [&](const ConvParams& p, int b) { if constexpr (CHAIN) return cx->lb[layer][b].w16; else return p.w16; };
+    auto L_bias = [&](const ConvParams& p, int b) { if constexpr (CHAIN) return cx->lb[layer][b].bias; else return p.bias; };
+    auto L_res = [&](const ConvParams& p, int b) { if constexpr (CHAIN) return cx->lb[layer][b].res; else return p.res; };
+    auto L_y = [&](const ConvParams& p, int b) { if constexpr (CHAIN) return cx->lb[layer][b].y; else return p.y; };
+    auto L_xs = [&](const ConvParams& p, int b) { if constexpr (CHAIN) return cx->lb[layer][b].xs; else return p.xs; };
+    auto L_ys = [&](const ConvParams& p, int b) { if constexpr (CHAIN) return cx->lb[layer][b].ys; else return p.ys; };
+    auto L_ntaps = [&](const ConvParams& p, int b) { if constexpr (CHAIN) return cx->lb[layer][b].ntaps; else return p.ntaps; };
+    auto L_off_min = [&](const ConvParams& p, int b) { if constexpr (CHAIN) return cx->lb[layer][b].off_min; else return p.off_min; };
+    auto L_halo = [&](const ConvParams& p, int b) { if constexpr (CHAIN) return cx->lb[layer][b].halo; else return p.halo; };
+    auto L_tap_step = [&](const ConvParams& p, int b) { if constexpr (CHAIN) return cx->lb[layer][b].tap_step; else return p.tap_step; };
+    auto L_tap_off0 = [&](const ConvParams& p, int b, int phase) { if constexpr (CHAIN) return cx->lb[layer][b].tap_off0; else return p.tap_off0[phase]; };
 
     struct Tile {
         int b, z, ng, seq, t0;
@@ -519,27 +572,36 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
 
         auto dma_item = [&](const Tile& T, int c, int jj) {
             const ConvParams& p = mp.p[T.b];
-            const int R = TM + p.halo;
+            const int R = TM + L_halo(p, T.b);
             const int ninstr = (R * SPR + 63) >> 6;  // 1 KiB of LDS per wave-instruction
             const int Ls = p.x_rows ? p.x_rows : seq_rows(p, T.seq);
             const int row_bytes = p.x_row_bytes ? p.x_row_bytes : p.cin * 4;
-            const char* const xs_z = p.xs + (size_t)T.z * mp.zs_x + (size_t)T.seq * (p.x_seq_bytes ? (size_t)p.x_seq_bytes : (size_t)p.L * p.cin * 4);
+            const char* const xs_z = L_xs(p, T.b) + (size_t)T.z * mp.zs_x + (size_t)T.seq * (p.x_seq_bytes ? (size_t)p.x_seq_bytes : (size_t)p.L * p.cin * 4);
             char* dst = smem_b + (jj & 1) * buf_bytes;
             const int c0b = c * CH * 2;  // byte offset of this chunk inside the hi (and lo) half of a row
             for (int i = lw; i < ninstr; i += 4) {
                 const int n = i * 64 + lane;
                 const int r = n >> LOG_SPR;
                 const int sl = (n & (SPR - 1)) ^ ((r >> LOG_RPB) & (SPR - 1));  // logical slot stored at this position
-                const int t = T.t0 + p.off_min + r;
+                const int t = T.t0 + L_off_min(p, T.b) + r;
                 const char* src = p.zeros;
                 if (r < R && t >= 0 && t < Ls) {
                     const int ts = p.x_up > 1 ? (int)__umulhi((unsigned)t, p.x_up_rcp) : t;  // (nearest upsample: out[t] = in[t / s])
                     if constexpr (F32) src = xs_z + (size_t)ts * row_bytes + 2 * c0b + sl * 16;
                     else src = xs_z + (size_t)ts * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
                 }
-                // aux = 2: non-temporal — an activation row is staged by one or two CUs only (+2.3 % end to end)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
+                // aux = 2: non-temporal — an activation row is staged by one or two CUs only (+2.3 % end to end); chained layers: sc1 (aux 16),
+                // rows another workgroup of THIS launch wrote must not come out of a stale L2 line
+#ifdef HIFICAR_CHAIN_PLAIN
+                if constexpr (false)
+#else
+                if constexpr (CHAIN)
+#endif
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 16);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
             }
         };
         // items are numbered j = 0.. over (tile, chunk); the DMA of item j+1 runs while the MFMA waves compute item j
@@ -572,6 +634,58 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                 have_prev = true;
                 it = itn;
             }
+        } else if constexpr (CHAIN) {
+            // counters of this layer's tiles / of the previous layer's (the producers)
+            unsigned* const my_flags = cx->flags + (size_t)layer * mp.n_branches * mp.nseq_tiles;
+            const unsigned* const in_flags = my_flags - (size_t)mp.n_branches * mp.nseq_tiles;
+            const unsigned want = cx->want;
+            auto flag_index = [&](const Tile& T) { return (size_t)T.b * mp.nseq_tiles + (size_t)T.seq * mp.p[0].tiles_per_seq + T.t0 / TM; };
+            auto publish = [&](const Tile& T) {  // one channel group of row tile (T.b, T.seq, T.t0) is stored (or skipped: past the sequence's end)
+                if (lw == 0 && lane == 0) __hip_atomic_fetch_add(my_flags + flag_index(T), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            auto wait_inputs = [&](const Tile& T) {  // the previous layer's row tiles under this tile's input window
+                if (layer == 0 || lane != 0) return;
+                const ConvParams& p = mp.p[T.b];
+                const int valid = seq_rows(p, T.seq);
+                const int lo = max(T.t0 + L_off_min(p, T.b), 0), hi = min(T.t0 + TM - 1 + L_off_min(p, T.b) + L_halo(p, T.b), valid - 1);
+                const unsigned* f = in_flags + (size_t)T.b * mp.nseq_tiles + (size_t)T.seq * p.tiles_per_seq;
+                for (int rt = lo / TM; rt <= hi / TM; ++rt) {
+                    int spins = 0;
+                    while (__hip_atomic_load(f + rt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1 << 18)) {  // (never in a correct run: every workgroup of the launch is resident; a second chained launch
+                            *cx->err = 1;           //  competing for the CUs could starve it — give up rather than hang the device)
+                            break;
+                        }
+                    }
+                }
+            };
+            // ragged batches: a tile past its sequence's end is skipped by everybody — its counter still has to advance
+            auto nxt_pub = [&](int i) {
+                if (is_ragged(mp.p[0]))
+                    while (i < my_rounds) {
+                        const Tile T = decode(tile_of(i));
+                        if (T.t0 < seq_rows(mp.p[T.b], T.seq)) break;
+                        publish(T);
+                        ++i;
+                    }
+                return i;
+            };
+            for (int it = nxt_pub(0); it < my_rounds; it = nxt_pub(it + 1)) {
+                const Tile T = decode(tile_of(it));
+                for (int c = 0; c < nchunks; ++c, ++j) {
+                    if (c == 0) wait_inputs(T);
+                    dma_item(T, c, j);
+                    __syncthreads();
+                    // the MFMA waves drained their stores of the previous tile in front of this barrier (c == 1: one item after its epilogue)
+                    if (c == 1 && have_prev) publish(Tprev);
+                }
+                Tprev = T;
+                have_prev = true;
+            }
+            __syncthreads();  // the MFMA waves drained the last tile's stores in front of this barrier
+            if (have_prev) publish(Tprev);
+            return;
         } else {
             for (int it = nxt(0); it < my_rounds; it = nxt(it + 1)) {
                 const Tile T = decode(tile_of(it));
@@ -610,7 +724,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
     auto wstream = [&](const Tile& T) {
         const ConvParams& p = mp.p[T.b];
         const int nb = (T.ng * WN + wn) * NB;
-        return reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(p.w16) + (size_t)T.z * mp.zs_w) + (size_t)(nb < p.n_blocks32 ? nb : 0) * p.ntaps * (p.cin / 16) * 128 + lane;
+        return reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(L_w16(p, T.b)) + (size_t)T.z * mp.zs_w) + (size_t)(nb < p.n_blocks32 ? nb : 0) * L_ntaps(p, T.b) * (p.cin / 16) * 128 + lane;
     };
     // NB = 2: the second channel block's stream lies one block's worth of fragments behind the first's (0 when the layer has no such block:
     // a partial channel group — the wave then multiplies the first block twice and the output pass ignores the columns)
@@ -639,7 +753,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             wp2 += NC16 * 128;
         }
         wp += NC16 * 128;
-        groups_left = nchunks * mp.p[T.b].ntaps - 1;
+        groups_left = nchunks * L_ntaps(mp.p[T.b], T.b) - 1;
     };
     const int wave_row0 = wm * (MI * 32);
 
@@ -718,6 +832,8 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
 
     int j = 0;
     int last = -1;  // position of the last tile computed
+    int last_done = -1;  // (chained layers) position of the tile whose epilogue was issued last
+    (void)last_done;
     HIFICAR_STAMP(0);
     if constexpr (KS == 4) {
         // ---------------- split-K: wave ks computes the steps s = ks, ks + 4, ... of every item ----------------
@@ -829,15 +945,15 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
         const int nb = (T.ng * WN + wn) * NB;
         const bool active = nb < p.n_blocks32;
         const int phase = active ? nb / p.nb32_per_phase : 0;
-        const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
-        const int tap_step = p.tap_step;
-        const int ntaps = p.ntaps;
+        const int roff0 = __builtin_amdgcn_readfirstlane(L_tap_off0(p, T.b, phase) - L_off_min(p, T.b));
+        const int tap_step = L_tap_step(p, T.b);
+        const int ntaps = L_ntaps(p, T.b);
         // after this tile's stream is exhausted the loads continue with the NEXT tile's first tap-groups, so its ring is
         // primed when it starts (the last tile re-reads its own head: harmless)
         const Tile Tn = decode(tile_of(itn < my_rounds ? itn : it));
         const frag_t* wp_next = wstream(Tn);
         const long long wst_next = NB == 2 ? wstride(Tn) : 0LL;
-        const int groups_next = nchunks * mp.p[Tn.b].ntaps;
+        const int groups_next = nchunks * L_ntaps(mp.p[Tn.b], Tn.b);
         if (active && !primed) prime(T);  // first tile, or this wave sat out the previous tile (partial channel group)
 #pragma unroll
         for (int q = 0; q < NB; ++q)
@@ -848,6 +964,11 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
 
         for (int c = 0; c < nchunks; ++c, ++j) {
             HIFICAR_STAMP(1 + 3 * j);
+            if constexpr (CHAIN) {
+                // the previous tile's write-through stores have left: the loader publishes the tile behind this barrier (one item after the
+                // epilogue, so the wait finds them done; it also drains the weight ring's loads, issued a slab step ago)
+                if (c == 1 && last_done >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __syncthreads();  // item j is staged
             HIFICAR_STAMP(2 + 3 * j);
             if (!active) continue;  // partial channel group: this wave only keeps the barriers
@@ -916,6 +1037,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
             }
         }
         HIFICAR_STAMP(3 * j);
+        last_done = it;
         primed = active;  // an active tile ends with the ring holding the next tile's head
         if constexpr (kSplitPass) __syncthreads();  // X: the loader waves have finished the previous tile's output pass
         if constexpr (DOUT) {
@@ -923,9 +1045,12 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                 const int vc0 = nb * 32 + 4 * g;  // this lane's first virtual channel
                 const size_t seq_base = (size_t)T.seq * p.L;
                 const int rows_valid = min(TM, seq_rows(p, T.seq) - T.t0);
-                const float* const bias_z = p.bias + (size_t)T.z * mp.zs_b;
-                float* const y_z = p.y ? p.y + (size_t)T.z * mp.zs_y : nullptr;
-                float* const ys_z = p.ys ? reinterpret_cast<float*>(p.ys) + (size_t)T.z * mp.zs_y : nullptr;
+                const float* const bias_z = L_bias(p, T.b) + (size_t)T.z * mp.zs_b;
+                float* const y_p = L_y(p, T.b);
+                char* const ys_p = L_ys(p, T.b);
+                const float* const res_p = L_res(p, T.b);
+                float* const y_z = y_p ? y_p + (size_t)T.z * mp.zs_y : nullptr;
+                float* const ys_z = ys_p ? reinterpret_cast<float*>(ys_p) + (size_t)T.z * mp.zs_y : nullptr;
                 f32x4 bv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(bias_z + vc0 + 8 * q);
@@ -942,7 +1067,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                         const size_t off = (seq_base + T.t0 + min(row_l, max(rows_valid - 1, 0))) * p.cout_total + vc0;  // (clamped: rows past the end are not stored)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            rs[mm][q] = p.res ? *reinterpret_cast<const f32x4*>(p.res + off + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                            rs[mm][q] = res_p ? *reinterpret_cast<const f32x4*>(res_p + off + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
                             if (p.mask_src) mk[mm][q] = *reinterpret_cast<const f32x4*>(p.mask_src + off + 8 * q);
                         }
                     }
@@ -962,12 +1087,12 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) o[e] = (acc[0][mi][4 * q + e] + bv[q][e]) + rs[mm][q][e];
                                 }
-                                if (y_z) *reinterpret_cast<f32x4*>(y_z + off + 8 * q) = o;
+                                if (y_z) store16<CHAIN>(y_z + off + 8 * q, o);
                                 if (ys_z) {
                                     f32x4 a;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) a[e] = fmaxf(o[e], o[e] * slope_out);
-                                    *reinterpret_cast<f32x4*>(ys_z + off + 8 * q) = a;
+                                    store16<CHAIN>(ys_z + off + 8 * q, a);
                                 }
                             }
                         }
@@ -991,6 +1116,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                     }
         }
     }
+    if constexpr (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's stores, in front of the barrier behind which it is published
     __syncthreads();  // matches the loader waves' final barrier
     HIFICAR_STAMP(62);
     if constexpr (!DOUT) {
@@ -1003,6 +1129,12 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
 template <int MI, int WM, int WN, int NC16>
 __global__ __launch_bounds__((WM * WN + 4) * 64) void conv_f32do_kernel(const MultiConvParams mp) {
     conv_ws_body<MI, WM, WN, NC16, true, 1, 1, true>(mp);
+}
+
+// chained layers of a ResBlock stage in one launch (ChainCtx)
+template <int MI, int WM, int WN, int NC16>
+__global__ __launch_bounds__((WM * WN + 4) * 64) void conv_f32chain_kernel(const MultiConvParams mp, const ChainCtx cx) {
+    for (int l = 0; l < cx.nlayers; ++l) conv_ws_body<MI, WM, WN, NC16, true, 1, 1, true, true>(mp, &cx, l);
 }
 
 template <int MI, int WM, int WN, int NC16>
