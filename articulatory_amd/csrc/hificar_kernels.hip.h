@@ -284,6 +284,13 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
     // the previous tile's output pass spread over all items (one more barrier per tile) — an out-buffer form: the direct-output kernels have no
     // out-buffer (and no LDS behind the staging ring) for it to read
     constexpr bool kSplitPass = KS == 1 && !DOUT && HIFICAR_SPLIT_PASS != 0;
+#ifndef HIFICAR_DOUT_ROWMAJOR
+#define HIFICAR_DOUT_ROWMAJOR 1  // (A/B: 0 = the round-4 direct epilogue, 16-byte stores of four channels of one row per lane)
+#endif
+    // Direct output with the accumulators transposed (round 5): lane (li, g) owns channel li of its block and rows 8 q + 4 g + e (register 4 q + e),
+    // so one 4-byte wave-store writes two whole 128-byte rows of the block where the 16-byte form touched 32 rows with 32 bytes each (one request
+    // per lane in the CU's vector-memory path: ~70 cycles per wave-store, 4.5 k cycles per tile and CU with the matrix pipe idle).
+    constexpr bool kRowMajorAcc = DOUT && HIFICAR_DOUT_ROWMAJOR != 0;
     constexpr int NTHR = (NW + 4) * 64;
     constexpr int kFirstLoader = NW;
     (void)kFirstLoader;
@@ -789,13 +796,21 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
 #pragma unroll
                 for (int q = 0; q < NB; ++q)
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[q][s4], xh[mi][s4], acc[q][mi], 0, 0, 0);
+                    for (int mi = 0; mi < MI; ++mi) {
+                        // direct output (kRowMajorAcc): activations as the A operand, so that a lane ends up with ONE channel and 16 time rows per
+                        // block — the same products summed in the same order, D = X W^T instead of D^T = W X^T
+                        if constexpr (kRowMajorAcc) acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(xh[mi][s4], wh[q][s4], acc[q][mi], 0, 0, 0);
+                        else acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[q][s4], xh[mi][s4], acc[q][mi], 0, 0, 0);
+                    }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
                 for (int q = 0; q < NB; ++q)
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[q][s4], xl[mi][s4], acc[q][mi], 0, 0, 0);
+                    for (int mi = 0; mi < MI; ++mi) {
+                        if constexpr (kRowMajorAcc) acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(xl[mi][s4], wl[q][s4], acc[q][mi], 0, 0, 0);
+                        else acc[q][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[q][s4], xl[mi][s4], acc[q][mi], 0, 0, 0);
+                    }
         } else {
 #pragma unroll
             for (int q = 0; q < NB; ++q)
@@ -1040,7 +1055,84 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         last_done = it;
         primed = active;  // an active tile ends with the ring holding the next tile's head
         if constexpr (kSplitPass) __syncthreads();  // X: the loader waves have finished the previous tile's output pass
-        if constexpr (DOUT) {
+        if constexpr (kRowMajorAcc) {
+            if (active) {
+                // the wave's share of the tile as raw buffers over its VALID rows: accesses to rows past a sequence's end fall outside the range (loads
+                // return 0, stores are dropped) — no per-row branches.  Descriptors are built from wave-uniform scalars right here.
+                const int rows_valid = min(TM, seq_rows(p, T.seq) - T.t0);
+                const int rows_w = max(min(rows_valid - wave_row0, MI * 32), 0);
+                const unsigned pitch_b = (unsigned)p.cout_total * 4u;
+                const unsigned nbytes = (unsigned)rows_w * pitch_b;
+                const size_t first = ((size_t)T.seq * p.L + T.t0 + wave_row0) * p.cout_total;
+                const float* const bias_z = L_bias(p, T.b) + (size_t)T.z * mp.zs_b;
+                float* const y_p = L_y(p, T.b);
+                char* const ys_p = L_ys(p, T.b);
+                const float* const res_p = L_res(p, T.b);
+                auto uni64 = [](unsigned long long v) {
+                    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+                    return ((unsigned long long)hi << 32) | lo;
+                };
+                auto rsrc_of = [&](const void* base, bool present) {
+                    return __builtin_amdgcn_make_buffer_rsrc((void*)uni64((unsigned long long)base), 0, __builtin_amdgcn_readfirstlane(present ? nbytes : 0u), 0x00020000);
+                };
+                const bool has_y = y_p != nullptr, has_ys = ys_p != nullptr, has_res = res_p != nullptr, has_mask = p.mask_src != nullptr;
+                const __amdgpu_buffer_rsrc_t r_y = rsrc_of(has_y ? y_p + (size_t)T.z * mp.zs_y + first : nullptr, has_y);
+                const __amdgpu_buffer_rsrc_t r_ys = rsrc_of(has_ys ? reinterpret_cast<float*>(ys_p) + (size_t)T.z * mp.zs_y + first : nullptr, has_ys);
+                const __amdgpu_buffer_rsrc_t r_res = rsrc_of(has_res ? res_p + first : nullptr, has_res);
+                const __amdgpu_buffer_rsrc_t r_mask = rsrc_of(has_mask ? p.mask_src + first : nullptr, has_mask);
+                constexpr int kAux = CHAIN ? 16 : 0;  // chained layers: write-through stores (sc1)
+                const int voff = (int)((4u * g * p.cout_total + nb * 32 + li) * 4u);  // (row 4 g, this lane's channel)
+                const float bias_l = bias_z[nb * 32 + li];
+                const float slope_out = p.slope_out, mask_slope = p.mask_slope;
+                // one straight-line pass per combination of operands (HR residual, HM mask, HY fp32 rows, HS activated rows): a pass compiled for all
+                // four with per-element uniform branches is slower than the 16-byte form it replaces.  An operand a pass was compiled with but the
+                // layer lacks has an empty range.
+                auto pass = [&](auto HR, auto HM, auto HY, auto HS) {
+                    constexpr bool kRes = decltype(HR)::value, kMask = decltype(HM)::value, kY = decltype(HY)::value, kYs = decltype(HS)::value;
+                    constexpr int G2 = MI >= 2 ? 2 : 1;
+#pragma unroll
+                    for (int m0 = 0; m0 < MI; m0 += G2) {
+                        float rs[G2][16], mk[G2][16];
+                        if constexpr (kRes || kMask) {
+#pragma unroll
+                            for (int mm = 0; mm < G2; ++mm)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int off = voff + (int)(((m0 + mm) * 32 + 8 * (r >> 2) + (r & 3)) * pitch_b);
+                                    if constexpr (kRes) rs[mm][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_res, off, 0, 0));
+                                    if constexpr (kMask) mk[mm][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_mask, off, 0, 0));
+                                }
+                        }
+#pragma unroll
+                        for (int mm = 0; mm < G2; ++mm) {
+                            const int mi = m0 + mm;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int off = voff + (int)((mi * 32 + 8 * (r >> 2) + (r & 3)) * pitch_b);
+                                float o = acc[0][mi][r] + bias_l;
+                                if constexpr (kMask) o *= mk[mm][r] > 0.f ? 1.f : mask_slope;  // backward: act'(x) * dgrad + skip gradient
+                                if constexpr (kRes) o += rs[mm][r];
+                                else o += 0.f;  // (the 16-byte form adds the absent residual as 0: -0 becomes +0)
+                                if constexpr (kY) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), r_y, off, 0, kAux);
+                                if constexpr (kYs) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(o, o * slope_out)), r_ys, off, 0, kAux);
+                            }
+                        }
+                    }
+                };
+                constexpr std::true_type Y{};
+                constexpr std::false_type N{};
+                if (has_mask) pass(Y, Y, Y, Y);
+                else if (has_res) {
+                    if (has_y && has_ys) pass(Y, N, Y, Y);
+                    else if (has_y) pass(Y, N, Y, N);
+                    else pass(Y, N, N, Y);
+                } else {
+                    if (has_y && has_ys) pass(N, N, Y, Y);
+                    else if (has_y) pass(N, N, Y, N);
+                    else pass(N, N, N, Y);
+                }
+            }
+        } else if constexpr (DOUT) {
             if (active) {
                 const int vc0 = nb * 32 + 4 * g;  // this lane's first virtual channel
                 const size_t seq_base = (size_t)T.seq * p.L;
