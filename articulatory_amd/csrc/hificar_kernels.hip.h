@@ -26,6 +26,7 @@ namespace hificar {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -290,7 +291,18 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
     // Direct output with the accumulators transposed (round 5): lane (li, g) owns channel li of its block and rows 8 q + 4 g + e (register 4 q + e),
     // so one 4-byte wave-store writes two whole 128-byte rows of the block where the 16-byte form touched 32 rows with 32 bytes each (one request
     // per lane in the CU's vector-memory path: ~70 cycles per wave-store, 4.5 k cycles per tile and CU with the matrix pipe idle).
+#ifndef HIFICAR_LIGHT_BARRIER
+#define HIFICAR_LIGHT_BARRIER 1  // (A/B: 0 = __syncthreads() in the MFMA waves of the direct-output kernels)
+#endif
+    constexpr bool kLightBarrier = DOUT && HIFICAR_LIGHT_BARRIER != 0;
     constexpr bool kRowMajorAcc = DOUT && HIFICAR_DOUT_ROWMAJOR != 0;
+#ifndef HIFICAR_EPI_OVERLAP
+#define HIFICAR_EPI_OVERLAP 0  // (A/B, measured slower — profiles/r05_epilogue_layouts.txt: 1 = the epilogue of row blocks 0 .. MI - 2 between the MFMAs of the tile's last tap)
+#endif
+    // Built, bit-identical and NOT the default: the stores an MFMA wave issues between its own MFMAs hold up its in-order issue whenever the CU's
+    // vector-memory path is backed up (four waves x one 4-byte store per two MFMAs is 2/3 of what that path takes), and the tap grows by more
+    // (+5.3 k cycles at C = 128) than the epilogue it hides (3.2 k).  Not in the chained form (compile time).
+    constexpr bool kEpiOverlap = kRowMajorAcc && NC16 % 2 == 0 && MI >= 2 && !CHAIN && HIFICAR_EPI_OVERLAP != 0;
     constexpr int NTHR = (NW + 4) * 64;
     constexpr int kFirstLoader = NW;
     (void)kFirstLoader;
@@ -845,6 +857,167 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         HIFICAR_PIN_BARRIER();
     };
 
+    // Direct output with transposed accumulators (kRowMajorAcc): the epilogue of one tile.
+    //   OVL = false: after the tile's K loop.
+    //   OVL = true (kEpiOverlap): called in place of the tile's LAST tap (`ad`: its fragment addresses).  The tap's MFMAs run row block by row block — the ring holds the whole tap's weights, so the order inside a tap is free — and the epilogue of
+    //   block mi (bias, residual, LeakyReLU, stores) is issued between the MFMAs of block mi + 1: only the last block's epilogue is left with the
+    //   matrix pipe idle.  Same products in the same order per accumulator: results unchanged.
+    auto epilogue_rm = [&](const Tile& T, const ConvParams& p, int nb, int rows_valid, auto OVL, const int (&ad)[NC16][2]) {
+        if constexpr (kRowMajorAcc) {
+            // a row block of the wave's share of the tile as raw buffers over its VALID rows: accesses to rows past a sequence's end fall outside the
+            // range (loads return 0, stores are dropped) — no per-row branches.  Descriptors are built from wave-uniform scalars where they are used
+            // (carried across a loop they end up in vector registers and every access in a readfirstlane loop).
+            const int rows_w = __builtin_amdgcn_readfirstlane(max(min(rows_valid - wave_row0, MI * 32), 0));
+            const unsigned pitch_b = __builtin_amdgcn_readfirstlane((unsigned)p.cout_total * 4u);
+            const size_t first = ((size_t)T.seq * p.L + T.t0 + wave_row0) * p.cout_total;
+            const float* const bias_z = L_bias(p, T.b) + (size_t)T.z * mp.zs_b;
+            float* const y_p = L_y(p, T.b);
+            char* const ys_p = L_ys(p, T.b);
+            const float* const res_p = L_res(p, T.b);
+            auto uni64 = [](unsigned long long v) {
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+                return ((unsigned long long)hi << 32) | lo;
+            };
+            const bool has_y = y_p != nullptr, has_ys = ys_p != nullptr, has_res = res_p != nullptr, has_mask = p.mask_src != nullptr;
+            const unsigned long long b_y = uni64((unsigned long long)(has_y ? y_p + (size_t)T.z * mp.zs_y + first : nullptr));
+            const unsigned long long b_ys = uni64((unsigned long long)(has_ys ? reinterpret_cast<float*>(ys_p) + (size_t)T.z * mp.zs_y + first : nullptr));
+            const unsigned long long b_res = uni64((unsigned long long)(has_res ? res_p + first : nullptr));
+            const unsigned long long b_mask = uni64((unsigned long long)(has_mask ? p.mask_src + first : nullptr));
+            auto rsrc_of = [&](unsigned long long base, bool present, int mi) {  // row block mi of an operand
+                const unsigned rows = (unsigned)max(min(rows_w - mi * 32, 32), 0);
+                return __builtin_amdgcn_make_buffer_rsrc((void*)uni64(base + (unsigned long long)(mi * 32) * pitch_b), 0,
+                                                         __builtin_amdgcn_readfirstlane(present ? rows * pitch_b : 0u), 0x00020000);
+            };
+            constexpr int kAux = CHAIN ? 16 : 0;  // chained layers: write-through stores (sc1)
+            const int voff = (int)((4u * g * p.cout_total + nb * 32 + li) * 4u);  // (row 4 g, this lane's channel)
+            int off16[16];  // byte offset of register r's element inside a row block: row 8 (r >> 2) + (r & 3) + 4 g
+#pragma unroll
+            for (int r = 0; r < 16; ++r) off16[r] = voff + (int)((8 * (r >> 2) + (r & 3)) * pitch_b);
+            const float bias_l = bias_z[nb * 32 + li];
+            const float slope_out = p.slope_out, mask_slope = p.mask_slope;
+            // one straight-line pass per combination of operands (HR residual, HM mask, HY fp32 rows, HS activated rows): a pass compiled for all
+            // four with per-element uniform branches is slower than the 16-byte form it replaces.  An operand a pass was compiled with but the
+            // layer lacks has an empty range.
+            auto pass = [&](auto HR, auto HM, auto HY, auto HS) {
+                constexpr bool kRes = decltype(HR)::value, kMask = decltype(HM)::value, kY = decltype(HY)::value, kYs = decltype(HS)::value;
+                auto fetch1 = [&](int mi, int r, float (&rs)[16], float (&mk)[16]) {  // residual / mask value of element r of row block mi
+                    if constexpr (kRes) rs[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_of(b_res, has_res, mi), off16[r], 0, 0));
+                    if constexpr (kMask) mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_of(b_mask, has_mask, mi), off16[r], 0, 0));
+                };
+                auto finish = [&](int mi, int r, const float (&rs)[16], const float (&mk)[16]) {  // element r of row block mi
+                    float o = acc[0][mi][r] + bias_l;
+                    if constexpr (kMask) o *= mk[r] > 0.f ? 1.f : mask_slope;  // backward: act'(x) * dgrad + skip gradient
+                    if constexpr (kRes) o += rs[r];
+                    else o += 0.f;  // (an absent residual is added as 0: -0 becomes +0, as in the out-buffer form)
+                    if constexpr (kY) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsrc_of(b_y, has_y, mi), off16[r], 0, kAux);
+                    if constexpr (kYs) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(o, o * slope_out)), rsrc_of(b_ys, has_ys, mi), off16[r], 0, kAux);
+                };
+                if constexpr (decltype(OVL)::value) {
+                    constexpr int RPS = 16 / NC16;  // epilogue elements per slab step
+                    float rs[16], mk[16];           // one rolling set: element r of block mi + 1 is requested right behind block mi's element r
+                    frag_t xf_h[2], xf_l[2];
+                    xf_h[0] = *reinterpret_cast<const frag_t*>(smem_b + ad[0][0]);
+                    xf_l[0] = *reinterpret_cast<const frag_t*>(smem_b + ad[0][1]);
+#pragma unroll
+                    for (int s = 0; s < (MI + 1) * NC16; ++s) {
+                        const int mi = s / NC16, u = s % NC16;
+                        if (mi < MI) {
+                            if (s + 1 < MI * NC16) {  // the next step's fragments, read while this step multiplies
+                                const int mn = (s + 1) / NC16, un = (s + 1) % NC16;
+                                xf_h[(s + 1) & 1] = *reinterpret_cast<const frag_t*>(smem_b + ad[un][0] + mn * 32 * RB);
+                                xf_l[(s + 1) & 1] = *reinterpret_cast<const frag_t*>(smem_b + ad[un][1] + mn * 32 * RB);
+                            }
+                            if constexpr (kRes || kMask) {
+                                if (mi == 0) {
+#pragma unroll
+                                    for (int r = u * RPS; r < (u + 1) * RPS; ++r) fetch1(0, r, rs, mk);
+                                }
+                            }
+                            const frag_t wh = wr[0][u][0], wl = wr[0][u][1];
+                            if (mi == MI - 1) {  // the ring moves on to the next tile's head behind the last block
+                                wr[0][u][0] = wp[u * 128];
+                                wr[0][u][1] = wp[u * 128 + 64];
+                            }
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) acc[0][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf_h[s & 1][s4], wh[s4], acc[0][mi], 0, 0, 0);
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) acc[0][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf_l[s & 1][s4], wl[s4], acc[0][mi], 0, 0, 0);
+                        }
+                        if (mi > 0) {
+#pragma unroll
+                            for (int r = u * RPS; r < (u + 1) * RPS; ++r) {
+                                finish(mi - 1, r, rs, mk);
+                                if constexpr (kRes || kMask) {
+                                    if (mi < MI) fetch1(mi, r, rs, mk);
+                                }
+                            }
+                        }
+                        // pin the step: each MFMA is followed by its share of the step's other instructions (left alone, hipcc issues the MFMAs of
+                        // all four blocks first and the epilogues behind them), and nothing moves across a step's end
+                        if (mi < MI) {
+                            constexpr int kVmem = RPS * ((kY ? 1 : 0) + (kYs ? 1 : 0) + (kRes ? 1 : 0) + (kMask ? 1 : 0));
+                            constexpr int kValu = RPS * (4 + (kRes ? 1 : 0) + (kMask ? 2 : 0));
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                if (i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // the next step's two fragment reads
+                                if (mi > 0 || kRes || kMask) {
+                                    __builtin_amdgcn_sched_group_barrier(0x002, (kValu + 7) / 8, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x010, (kVmem + 7) / 8, 0);
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    constexpr int G2 = MI >= 2 ? 2 : 1;
+#pragma unroll
+                    for (int m0 = 0; m0 < MI; m0 += G2) {
+                        float rs[G2][16], mk[G2][16];
+                        if constexpr (kRes || kMask) {
+#pragma unroll
+                            for (int mm = 0; mm < G2; ++mm)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) fetch1(m0 + mm, r, rs[mm], mk[mm]);
+                        }
+#pragma unroll
+                        for (int mm = 0; mm < G2; ++mm)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) finish(m0 + mm, r, rs[mm], mk[mm]);
+                    }
+                }
+            };
+            constexpr std::true_type Y{};
+            constexpr std::false_type N{};
+            if constexpr (!decltype(OVL)::value) {  // (a data-gradient launch — mask — keeps its whole epilogue behind the K loop: two more sets of 16 registers)
+                if (has_mask) {
+                    pass(Y, Y, Y, Y);
+                    return;
+                }
+            }
+            if constexpr (decltype(OVL)::value) {  // (epi_overlaps: the two forms of a ResBlock's layers — conv1: activated rows only; conv2: residual, both outputs)
+                if (has_res) pass(Y, N, Y, Y);
+                else pass(N, N, N, Y);
+                return;
+            }
+            if (has_res) {
+                if (has_y && has_ys) pass(Y, N, Y, Y);
+                else if (has_y) pass(Y, N, Y, N);
+                else pass(Y, N, N, Y);
+            } else {
+                if (has_y && has_ys) pass(N, N, Y, Y);
+                else if (has_y) pass(N, N, Y, N);
+                else pass(N, N, N, Y);
+            }
+        }
+    };
+    // the launches whose last tap carries the epilogue: the layers of the ResBlocks (everything else — the polyphase upsamplers, data gradients, single
+    // outputs — keeps the epilogue behind the K loop: fewer copies of the unrolled tap)
+    auto epi_overlaps = [&](const ConvParams& p, int b) {
+        const bool has_y = L_y(p, b) != nullptr, has_ys = L_ys(p, b) != nullptr, has_res = L_res(p, b) != nullptr;
+        return !p.mask_src && has_ys && has_y == has_res;
+    };
+
     int j = 0;
     int last = -1;  // position of the last tile computed
     int last_done = -1;  // (chained layers) position of the tile whose epilogue was issued last
@@ -963,6 +1136,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         const int roff0 = __builtin_amdgcn_readfirstlane(L_tap_off0(p, T.b, phase) - L_off_min(p, T.b));
         const int tap_step = L_tap_step(p, T.b);
         const int ntaps = L_ntaps(p, T.b);
+        const bool ovl = kEpiOverlap && epi_overlaps(p, T.b);
+        // (read here, not in the epilogue: a ragged batch's length is a memory load)
+        const int rows_valid_t = kRowMajorAcc ? __builtin_amdgcn_readfirstlane(min(TM, seq_rows(p, T.seq) - T.t0)) : 0;
         // after this tile's stream is exhausted the loads continue with the NEXT tile's first tap-groups, so its ring is
         // primed when it starts (the last tile re-reads its own head: harmless)
         const Tile Tn = decode(tile_of(itn < my_rounds ? itn : it));
@@ -984,7 +1160,11 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
                 // epilogue, so the wait finds them done; it also drains the weight ring's loads, issued a slab step ago)
                 if (c == 1 && last_done >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __syncthreads();  // item j is staged
+            // item j is staged.  Direct output: the barrier alone — __syncthreads() also waits for this wave's own global stores (vmcnt(0): the whole
+            // write latency of the tile just stored, with the matrix pipe idle); they only have to land by the end of the kernel, and what the barrier
+            // orders here is LDS (the loaders wait for their DMA in front of theirs).
+            if constexpr (kLightBarrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else __syncthreads();
             HIFICAR_STAMP(2 + 3 * j);
             if (!active) continue;  // partial channel group: this wave only keeps the barriers
             const int buf_off = (j & 1) * buf_bytes;
@@ -993,7 +1173,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
             if constexpr (NC16 % 2 == 0) {
                 frag_t x0h[MI], x0l[MI], x1h[MI], x1l[MI];
                 load_x(x0h, x0l, ad[0]);
-                for (int t = 0; t < ntaps; ++t) {
+                // (kEpiOverlap) the tile's last tap runs behind the loop, row block by row block, with the epilogue in between
+                const int ntaps_loop = ovl && c + 1 == nchunks ? ntaps - 1 : ntaps;
+                for (int t = 0; t < ntaps_loop; ++t) {
                     const bool last_tap = t + 1 == ntaps;
                     int adn[NC16][2];
                     addr_set(buf_off, roff0 + (last_tap ? t : t + 1) * tap_step, adn);
@@ -1017,6 +1199,17 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
                     for (int u = 0; u < NC16; ++u) {
                         ad[u][0] = adn[u][0];
                         ad[u][1] = adn[u][1];
+                    }
+                }
+                if constexpr (kEpiOverlap) {
+                    if (ntaps_loop < ntaps) {  // `ad` holds the last tap's addresses
+                        if (groups_left == 0) {
+                            wp = wp_next;
+                            groups_left = groups_next;
+                        }
+                        --groups_left;
+                        epilogue_rm(T, p, nb, rows_valid_t, std::true_type{}, ad);
+                        wp += NC16 * 128;
                     }
                 }
             } else {
@@ -1056,9 +1249,14 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         primed = active;  // an active tile ends with the ring holding the next tile's head
         if constexpr (kSplitPass) __syncthreads();  // X: the loader waves have finished the previous tile's output pass
         if constexpr (kRowMajorAcc) {
+            if (active && !ovl) {
+                const int no_ad[NC16][2] = {};
+                epilogue_rm(T, p, nb, rows_valid_t, std::false_type{}, no_ad);
+            }
+        } else if constexpr (DOUT) {
             if (active) {
-                // the wave's share of the tile as raw buffers over its VALID rows: accesses to rows past a sequence's end fall outside the range (loads
-                // return 0, stores are dropped) — no per-row branches.  Descriptors are built from wave-uniform scalars right here.
+                // (A/B form, HIFICAR_DOUT_ROWMAJOR=0) weights as the A operand: lane (li, g) owns row li and channels 8 q + 4 g + {0..3} of its block —
+                // 16-byte accesses, 32 rows x 32 bytes per wave-instruction; same straight-line passes over range-checked raw buffers as above
                 const int rows_valid = min(TM, seq_rows(p, T.seq) - T.t0);
                 const int rows_w = max(min(rows_valid - wave_row0, MI * 32), 0);
                 const unsigned pitch_b = (unsigned)p.cout_total * 4u;
@@ -1080,41 +1278,46 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
                 const __amdgpu_buffer_rsrc_t r_ys = rsrc_of(has_ys ? reinterpret_cast<float*>(ys_p) + (size_t)T.z * mp.zs_y + first : nullptr, has_ys);
                 const __amdgpu_buffer_rsrc_t r_res = rsrc_of(has_res ? res_p + first : nullptr, has_res);
                 const __amdgpu_buffer_rsrc_t r_mask = rsrc_of(has_mask ? p.mask_src + first : nullptr, has_mask);
-                constexpr int kAux = CHAIN ? 16 : 0;  // chained layers: write-through stores (sc1)
-                const int voff = (int)((4u * g * p.cout_total + nb * 32 + li) * 4u);  // (row 4 g, this lane's channel)
-                const float bias_l = bias_z[nb * 32 + li];
+                constexpr int kAux = CHAIN ? 16 : 0;
+                const int voff = (int)(((unsigned)li * p.cout_total + nb * 32 + 4 * g) * 4u);  // (row li, this lane's first channel)
+                f32x4 bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(bias_z + nb * 32 + 4 * g + 8 * q);
                 const float slope_out = p.slope_out, mask_slope = p.mask_slope;
-                // one straight-line pass per combination of operands (HR residual, HM mask, HY fp32 rows, HS activated rows): a pass compiled for all
-                // four with per-element uniform branches is slower than the 16-byte form it replaces.  An operand a pass was compiled with but the
-                // layer lacks has an empty range.
                 auto pass = [&](auto HR, auto HM, auto HY, auto HS) {
                     constexpr bool kRes = decltype(HR)::value, kMask = decltype(HM)::value, kY = decltype(HY)::value, kYs = decltype(HS)::value;
                     constexpr int G2 = MI >= 2 ? 2 : 1;
 #pragma unroll
                     for (int m0 = 0; m0 < MI; m0 += G2) {
-                        float rs[G2][16], mk[G2][16];
+                        f32x4 rs[G2][4], mk[G2][4];
                         if constexpr (kRes || kMask) {
 #pragma unroll
                             for (int mm = 0; mm < G2; ++mm)
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) {
-                                    const int off = voff + (int)(((m0 + mm) * 32 + 8 * (r >> 2) + (r & 3)) * pitch_b);
-                                    if constexpr (kRes) rs[mm][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_res, off, 0, 0));
-                                    if constexpr (kMask) mk[mm][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_mask, off, 0, 0));
+                                for (int q = 0; q < 4; ++q) {
+                                    const int off = voff + (int)((m0 + mm) * 32 * pitch_b) + 32 * q;
+                                    if constexpr (kRes) rs[mm][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off, 0, 0));
+                                    if constexpr (kMask) mk[mm][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_mask, off, 0, 0));
                                 }
                         }
 #pragma unroll
                         for (int mm = 0; mm < G2; ++mm) {
                             const int mi = m0 + mm;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int off = voff + (int)((mi * 32 + 8 * (r >> 2) + (r & 3)) * pitch_b);
-                                float o = acc[0][mi][r] + bias_l;
-                                if constexpr (kMask) o *= mk[mm][r] > 0.f ? 1.f : mask_slope;  // backward: act'(x) * dgrad + skip gradient
-                                if constexpr (kRes) o += rs[mm][r];
-                                else o += 0.f;  // (the 16-byte form adds the absent residual as 0: -0 becomes +0)
-                                if constexpr (kY) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), r_y, off, 0, kAux);
-                                if constexpr (kYs) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(o, o * slope_out)), r_ys, off, 0, kAux);
+                            for (int q = 0; q < 4; ++q) {
+                                const int off = voff + (int)(mi * 32 * pitch_b) + 32 * q;
+                                f32x4 o, a;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float v = acc[0][mi][4 * q + e] + bv[q][e];
+                                    if constexpr (kMask) v *= mk[mm][q][e] > 0.f ? 1.f : mask_slope;
+                                    if constexpr (kRes) v += rs[mm][q][e];
+                                    else v += 0.f;
+                                    o[e] = v;
+                                    a[e] = fmaxf(v, v * slope_out);
+                                }
+                                if constexpr (kY) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), r_y, off, 0, kAux);
+                                if constexpr (kYs) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, a), r_ys, off, 0, kAux);
                             }
                         }
                     }
@@ -1130,65 +1333,6 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
                     if (has_y && has_ys) pass(N, N, Y, Y);
                     else if (has_y) pass(N, N, Y, N);
                     else pass(N, N, N, Y);
-                }
-            }
-        } else if constexpr (DOUT) {
-            if (active) {
-                const int vc0 = nb * 32 + 4 * g;  // this lane's first virtual channel
-                const size_t seq_base = (size_t)T.seq * p.L;
-                const int rows_valid = min(TM, seq_rows(p, T.seq) - T.t0);
-                const float* const bias_z = L_bias(p, T.b) + (size_t)T.z * mp.zs_b;
-                float* const y_p = L_y(p, T.b);
-                char* const ys_p = L_ys(p, T.b);
-                const float* const res_p = L_res(p, T.b);
-                float* const y_z = y_p ? y_p + (size_t)T.z * mp.zs_y : nullptr;
-                float* const ys_z = ys_p ? reinterpret_cast<float*>(ys_p) + (size_t)T.z * mp.zs_y : nullptr;
-                f32x4 bv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(bias_z + vc0 + 8 * q);
-                const float slope_out = p.slope_out;
-                // residual / mask rows are requested two row blocks at a time before the first is used (the K loop's operand registers are dead
-                // here; all MI blocks at once would need 128 registers with a mask and spills)
-                constexpr int G2 = MI >= 2 ? 2 : 1;
-#pragma unroll
-                for (int m0 = 0; m0 < MI; m0 += G2) {
-                    f32x4 rs[G2][4], mk[G2][4];
-#pragma unroll
-                    for (int mm = 0; mm < G2; ++mm) {
-                        const int row_l = wave_row0 + (m0 + mm) * 32 + li;
-                        const size_t off = (seq_base + T.t0 + min(row_l, max(rows_valid - 1, 0))) * p.cout_total + vc0;  // (clamped: rows past the end are not stored)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            rs[mm][q] = res_p ? *reinterpret_cast<const f32x4*>(res_p + off + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-                            if (p.mask_src) mk[mm][q] = *reinterpret_cast<const f32x4*>(p.mask_src + off + 8 * q);
-                        }
-                    }
-#pragma unroll
-                    for (int mm = 0; mm < G2; ++mm) {
-                        const int mi = m0 + mm;
-                        const int row_l = wave_row0 + mi * 32 + li;
-                        if (row_l < rows_valid) {
-                            const size_t off = (seq_base + T.t0 + row_l) * p.cout_total + vc0;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                f32x4 o;
-                                if (p.mask_src) {  // backward: act'(x) * dgrad + skip gradient (as write_out)
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) o[e] = (acc[0][mi][4 * q + e] + bv[q][e]) * (mk[mm][q][e] > 0.f ? 1.f : p.mask_slope) + rs[mm][q][e];
-                                } else {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) o[e] = (acc[0][mi][4 * q + e] + bv[q][e]) + rs[mm][q][e];
-                                }
-                                if (y_z) store16<CHAIN>(y_z + off + 8 * q, o);
-                                if (ys_z) {
-                                    f32x4 a;
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) a[e] = fmaxf(o[e], o[e] * slope_out);
-                                    store16<CHAIN>(ys_z + off + 8 * q, a);
-                                }
-                            }
-                        }
-                    }
                 }
             }
         } else if (active) {
@@ -1209,7 +1353,8 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         }
     }
     if constexpr (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's stores, in front of the barrier behind which it is published
-    __syncthreads();  // matches the loader waves' final barrier
+    if constexpr (kLightBarrier && !CHAIN) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();  // matches the loader waves' final barrier
     HIFICAR_STAMP(62);
     if constexpr (!DOUT) {
         if (last >= 0) write_out(decode(tile_of(last)), tid, NTHR);
