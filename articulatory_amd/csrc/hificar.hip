@@ -145,6 +145,7 @@ struct hificar_handle {
         unsigned epoch = 0;
     };
     std::map<std::string, ChainState> chains;
+    bool act_read = true;          // HIFICAR_ACT_READ=0: every producer writes an activated copy for its consumer conv (the form before round 5; A/B runs)
     bool use_chain = false;        // HIFICAR_CHAIN=1: the layers of a chainable ResBlock stage as one launch (round 5: built, bit-identical, 1.8 % SLOWER —
                                    // the write-through stores / L2-bypassing loads the hand-off needs cost more than the launches it removes:
                                    // profiles/r05_chain_launch.txt)
@@ -318,6 +319,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
     if (const char* e = getenv("HIFICAR_XCD_ORDER")) h->xcd_order = atoi(e) != 0;    // (A/B runs)
     if (const char* e = getenv("HIFICAR_LPT")) h->use_lpt = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_CHAIN")) h->use_chain = atoi(e) != 0;
+    if (const char* e = getenv("HIFICAR_ACT_READ")) h->act_read = atoi(e) != 0;
     if (const char* e = getenv("HIFICAR_KSPLIT")) h->ksplit = atoi(e);
     if (const char* e = getenv("HIFICAR_AR_DUAL_MIN")) h->ar_dual_min = atoi(e);  // (A/B runs, tests)
     if (const char* e = getenv("HIFICAR_AR_DUAL_MAX")) h->ar_dual_max = atoi(e);
@@ -1099,6 +1101,7 @@ struct ConvIO {
     int x_row_bytes = 0;
     int x_rows = 0;                   // input rows per sequence when they differ from the launch's rows (ConvParams::x_rows)
     int x_up = 0;                     // nearest-neighbour upsampling of the input rows while staging (ConvParams::x_up); the input then has rows / x_up rows
+    float x_slope = -1.f;             // >= 0: xs holds PRE-activation fp32 rows, LeakyReLU(x_slope) is applied while staging (ConvParams::act_in; exact fp32 only)
 };
 
 // Replicas of every branch at regular strides (the groups of a grouped conv): see MultiConvParams::zrep
@@ -1281,6 +1284,11 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         fill_params(mp.p[b], Lb, rows, TM, io[b].res, io[b].y, rg);
         mp.p[b].xs = io[b].xs;
         mp.p[b].ys = io[b].ys;
+        if (io[b].x_slope >= 0.f) {
+            if (!f32 || cb) return fail(HIFICAR_E_INVALID, "internal: pre-activation input rows of %s outside the exact-fp32 layer-by-layer launches", Lb.name.c_str());
+            mp.p[b].act_in = 1;
+            mp.p[b].slope_in = io[b].x_slope;
+        }
         mp.p[b].mask_src = io[b].mask_src;
         mp.p[b].mask_slope = io[b].mask_slope;
         mp.p[b].x_seq_bytes = io[b].x_seq_bytes;
@@ -1839,9 +1847,19 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     const int ci = conv_index(h, i, j, d);
                     all_pairs = all_pairs && pair_eligible(h, h->convs1[ci], h->convs2[ci], B, rows * cfg.upsample_scales[i]);
                 }
+            // Layer-by-layer stages in inference, exact fp32 (round 5): the convs1 read the fp32 residual stream itself and apply LeakyReLU while staging
+            // (ConvParams::act_in), so neither the upsampler nor the convs2 store an activated copy — 64 KB less per output tile of a direct epilogue that
+            // the matrix pipe idles through.  Not with fused pairs in the stage or single-conv layers (those write the stream they read in place),
+            // not in training (the weight gradients read the activated copies).
+            bool stage_act = h->act_read && f32 && !tp && !h->use_chain && add_convs && !all_pairs;
+            for (int j = 0; j < nbk && stage_act; ++j)
+                for (int d = 0; d < cfg.n_dilations[j]; ++d) {
+                    const int ci = conv_index(h, i, j, d);
+                    if (pair_eligible(h, h->convs1[ci], h->convs2[ci], B, rows * cfg.upsample_scales[i])) stage_act = false;
+                }
             {   // LeakyReLU + ConvTranspose1d (hifigan.py:224): fp32 u (first residual) (+ activated copy: first conv input)
                 const ConvLayer* lay[1] = {&h->ups[i]};
-                const ConvIO io[1] = {{up_in, nullptr, ws.u, all_pairs ? nullptr : (tp ? tp->u_s[i] : ws.u_s)}};
+                const ConvIO io[1] = {{up_in, nullptr, ws.u, all_pairs || stage_act ? nullptr : (tp ? tp->u_s[i] : ws.u_s)}};
                 if ((rc = launch_conv(h, lay, 1, B, rows, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
             }
             rows *= cfg.upsample_scales[i];
@@ -1926,6 +1944,11 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     }
                     io1[n] = {cur_s[j], nullptr, tap_convs1 ? h->tap_scratch + (size_t)n * tap_se : nullptr, mid};
                     io2[n] = {mid, d == 0 ? ws.u : xres[j], xres[j], last ? nullptr : lbl_out[n]};
+                    if (stage_act) {  // conv1 stages the fp32 stream; conv2 (in place on it: it reads no halo of it) writes no activated copy
+                        io1[n].xs = reinterpret_cast<const char*>(d == 0 ? ws.u : xres[j]);
+                        io1[n].x_slope = cfg.lrelu_slope;
+                        io2[n].ys = nullptr;
+                    }
                     if (!add_convs) {  // one conv per layer: conv1 carries the residual epilogue; its activated output is the next layer's input
                         char* nxt = tp ? tp->x_s[i][j][d] : pair_out[n];
                         io1[n] = {cur_s[j], d == 0 ? ws.u : xres[j], xres[j], last ? nullptr : nxt};

@@ -47,6 +47,9 @@ struct ConvParams {
     const float* xf;    // pair kernel only: fp32 PRE-activation input rows (C floats per row); LeakyReLU(slope_in) + split are
                         // then applied while staging and xs is null (narrow stages: the producer writes no activated copy)
     float slope_in;
+    int act_in;         // exact-fp32 conv kernels (conv_ws_body): 1 = xs holds PRE-activation fp32 rows; the loader waves stage them through registers
+                        // and apply LeakyReLU(slope_in) on the way (global load, 8 VALU, ds_write per 16 bytes) instead of the LDS-DMA, so the
+                        // producer stores no activated copy.  0: xs is activated already (LDS-DMA)
     const char* xs;     // input rows, already activated (and split) by their producer
     char* ys;           // activated (and split) copy of the output for the consumer conv: LeakyReLU(out, slope_out), or null
     const char* zeros;  // >= 16 bytes of zeros (source of padding rows for the LDS DMA)
@@ -91,12 +94,21 @@ struct ConvParams {
     unsigned x_up_rcp;
 };
 
+// A wave-uniform int the HOST wrote before the launch (tile schedules, sequence lengths), read through the scalar cache.  A plain load of it compiles to
+// a VECTOR load followed by s_waitcnt vmcnt(0) — the kernels store to global memory, so hipcc will not use the scalar cache on its own — and that wait
+// also sits out every store the wave has in flight: between two tiles of the direct-output conv kernels, the whole epilogue (2.8 k cycles per tile).
+__device__ __forceinline__ int scalar_load_i32(const int* p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
 __device__ __forceinline__ bool is_ragged(const ConvParams& p) { return p.seq_len != nullptr || p.len_const >= 0; }
 
 // valid rows of sequence `seq` (wave-uniform: one scalar load)
 __device__ __forceinline__ int seq_rows(const ConvParams& p, int seq) {
     if (!is_ragged(p)) return p.L;
-    const int n = (p.seq_len ? p.seq_len[__builtin_amdgcn_readfirstlane(seq)] : p.len_const) - p.len_f0;
+    const int n = (p.seq_len ? scalar_load_i32(p.seq_len + __builtin_amdgcn_readfirstlane(seq)) : p.len_const) - p.len_f0;
     return min(max(n, 0), p.len_max) * p.len_mul;
 }
 
@@ -364,13 +376,13 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
     // LIGHT FIRST: the loader waves write a finished tile out while the MFMA waves compute the next one, and that only
     // hides completely behind a tile at least as heavy.  Odd workgroups swap their last two tiles so that
     // neighbouring CUs are not in the same phase all the time (synchronised DMA / output bursts cost ~15 % here).
-    const int sched_lo = mp.sched_start ? mp.sched_start[blockIdx.x] : 0;
-    const int my_rounds = mp.sched_start ? mp.sched_start[blockIdx.x + 1] - sched_lo
+    const int sched_lo = mp.sched_start ? scalar_load_i32(mp.sched_start + blockIdx.x) : 0;
+    const int my_rounds = mp.sched_start ? scalar_load_i32(mp.sched_start + blockIdx.x + 1) - sched_lo
                                          : (mp.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     auto tile_of = [&](int it) {
         int i = it;
         if ((blockIdx.x & 1) && my_rounds >= 3 && it >= my_rounds - 2) i = it == my_rounds - 1 ? my_rounds - 2 : my_rounds - 1;
-        if (mp.sched_start) return mp.sched_tiles[sched_lo + i];
+        if (mp.sched_start) return scalar_load_i32(mp.sched_tiles + sched_lo + i);
         if (mp.xcd_order) {
             // one tile per workgroup, weights outweigh activations (small batches, the discriminators' few-row GEMMs): workgroups are
             // dispatched to the 8 XCDs round-robin, so workgroup w = 8 l + x takes tile l of XCD x's CONTIGUOUS share of the tile list —
@@ -623,6 +635,57 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
             }
         };
+        // The same item from PRE-activation fp32 rows (ConvParams::act_in): 16 bytes per lane through registers, LeakyReLU(slope_in) applied, written
+        // to the slot the DMA would have filled (position i * 1024 + lane * 16 holds logical slot sl of row r).
+        auto stage_act_item = [&](const Tile& T, int c, int jj) {
+            if constexpr (F32) {
+                const ConvParams& p = mp.p[T.b];
+                const int R = TM + L_halo(p, T.b);
+                const int ninstr = (R * SPR + 63) >> 6;
+                const int Ls = p.x_rows ? p.x_rows : seq_rows(p, T.seq);
+                const int row_bytes = p.x_row_bytes ? p.x_row_bytes : p.cin * 4;
+                const char* const xs_z = L_xs(p, T.b) + (size_t)T.z * mp.zs_x + (size_t)T.seq * (p.x_seq_bytes ? (size_t)p.x_seq_bytes : (size_t)p.L * p.cin * 4);
+                char* dst = smem_b + (jj & 1) * buf_bytes;
+                const int c0b = c * CH * 2;
+                const float slope = p.slope_in;
+                constexpr int UB = 12;  // (an item is 36-48 wave-loads: all of a loader wave's share in flight at once, one memory latency per item like the DMA)
+                for (int i0 = lw; i0 < ninstr; i0 += 4 * UB) {
+                    f32x4 v[UB];
+#pragma unroll
+                    for (int q = 0; q < UB; ++q) {
+                        const int i = i0 + 4 * q;
+                        v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const int n = i * 64 + lane;
+                        const int r = n >> LOG_SPR;
+                        const int sl = (n & (SPR - 1)) ^ ((r >> LOG_RPB) & (SPR - 1));
+                        const int t = T.t0 + L_off_min(p, T.b) + r;
+                        if (i < ninstr && r < R && t >= 0 && t < Ls) {
+                            const int ts = p.x_up > 1 ? (int)__umulhi((unsigned)t, p.x_up_rcp) : t;
+                            v[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xs_z + (size_t)ts * row_bytes + 2 * c0b + sl * 16));
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < UB; ++q) {
+                        const int i = i0 + 4 * q;
+                        if (i < ninstr) {
+                            f32x4 a;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a[e] = fmaxf(v[q][e], v[q][e] * slope);
+                            *reinterpret_cast<f32x4*>(dst + i * 1024 + lane * 16) = a;
+                        }
+                    }
+                }
+            }
+        };
+        auto stage_item = [&](const Tile& T, int c, int jj) {
+            if constexpr (F32 && !CHAIN) {
+                if (mp.p[T.b].act_in) {
+                    stage_act_item(T, c, jj);
+                    return;
+                }
+            }
+            dma_item(T, c, jj);
+        };
         // items are numbered j = 0.. over (tile, chunk); the DMA of item j+1 runs while the MFMA waves compute item j
         int j = 0;
         HIFICAR_STAMP(0);
@@ -709,7 +772,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
             for (int it = nxt(0); it < my_rounds; it = nxt(it + 1)) {
                 const Tile T = decode(tile_of(it));
                 for (int c = 0; c < nchunks; ++c, ++j) {
-                    dma_item(T, c, j);
+                    stage_item(T, c, j);
                     // the tile that finished with item j-2 published its accumulators at barrier j-1 (nchunks >= 2, so the
                     // MFMA waves cannot overwrite the out-buffer before barrier j+1)
                     if constexpr (!DOUT) {
@@ -754,7 +817,6 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
     const frag_t* wp = nullptr;   // where the next tap-group of weight fragments is loaded from
     const frag_t* wp2 = nullptr;  // ... of the second channel block (NB = 2)
     int groups_left = 0;          // tap-groups of the current tile's stream not yet requested
-    bool primed = false;          // the ring holds the head of the tile about to be computed
     auto prime = [&](const Tile& T) {
         wp = wstream(T);
 #pragma unroll
@@ -862,7 +924,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
     //   OVL = true (kEpiOverlap): called in place of the tile's LAST tap (`ad`: its fragment addresses).  The tap's MFMAs run row block by row block — the ring holds the whole tap's weights, so the order inside a tap is free — and the epilogue of
     //   block mi (bias, residual, LeakyReLU, stores) is issued between the MFMAs of block mi + 1: only the last block's epilogue is left with the
     //   matrix pipe idle.  Same products in the same order per accumulator: results unchanged.
-    auto epilogue_rm = [&](const Tile& T, const ConvParams& p, int nb, int rows_valid, auto OVL, const int (&ad)[NC16][2]) {
+    auto epilogue_rm = [&](const Tile& T, const ConvParams& p, int nb, int rows_valid, float bias_l, auto OVL, const int (&ad)[NC16][2]) {
         if constexpr (kRowMajorAcc) {
             // a row block of the wave's share of the tile as raw buffers over its VALID rows: accesses to rows past a sequence's end fall outside the
             // range (loads return 0, stores are dropped) — no per-row branches.  Descriptors are built from wave-uniform scalars where they are used
@@ -870,7 +932,6 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
             const int rows_w = __builtin_amdgcn_readfirstlane(max(min(rows_valid - wave_row0, MI * 32), 0));
             const unsigned pitch_b = __builtin_amdgcn_readfirstlane((unsigned)p.cout_total * 4u);
             const size_t first = ((size_t)T.seq * p.L + T.t0 + wave_row0) * p.cout_total;
-            const float* const bias_z = L_bias(p, T.b) + (size_t)T.z * mp.zs_b;
             float* const y_p = L_y(p, T.b);
             char* const ys_p = L_ys(p, T.b);
             const float* const res_p = L_res(p, T.b);
@@ -893,7 +954,6 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
             int off16[16];  // byte offset of register r's element inside a row block: row 8 (r >> 2) + (r & 3) + 4 g
 #pragma unroll
             for (int r = 0; r < 16; ++r) off16[r] = voff + (int)((8 * (r >> 2) + (r & 3)) * pitch_b);
-            const float bias_l = bias_z[nb * 32 + li];
             const float slope_out = p.slope_out, mask_slope = p.mask_slope;
             // one straight-line pass per combination of operands (HR residual, HM mask, HY fp32 rows, HS activated rows): a pass compiled for all
             // four with per-element uniform branches is slower than the 16-byte form it replaces.  An operand a pass was compiled with but the
@@ -908,9 +968,14 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
                     float o = acc[0][mi][r] + bias_l;
                     if constexpr (kMask) o *= mk[r] > 0.f ? 1.f : mask_slope;  // backward: act'(x) * dgrad + skip gradient
                     if constexpr (kRes) o += rs[r];
-                    else o += 0.f;  // (an absent residual is added as 0: -0 becomes +0, as in the out-buffer form)
+#ifdef HIFICAR_EPI_NOSTORE  // (dev timing experiment: the epilogue without its stores — results are NOT valid)
+                    const float a_ns = fmaxf(o, o * slope_out);
+                    asm volatile("" : : "v"(o), "v"(a_ns));
+#else
                     if constexpr (kY) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsrc_of(b_y, has_y, mi), off16[r], 0, kAux);
-                    if constexpr (kYs) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(o, o * slope_out)), rsrc_of(b_ys, has_ys, mi), off16[r], 0, kAux);
+                    // LeakyReLU as v_mul + v_med3 (max(o, slope o) = the median of o, slope o and +inf; fmaxf() canonicalises o first: a third instruction)
+                    if constexpr (kYs) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_amdgcn_fmed3f(o, o * slope_out, __builtin_inff())), rsrc_of(b_ys, has_ys, mi), off16[r], 0, kAux);
+#endif
                 };
                 if constexpr (decltype(OVL)::value) {
                     constexpr int RPS = 16 / NC16;  // epilogue elements per slab step
@@ -1018,6 +1083,10 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         return !p.mask_src && has_ys && has_y == has_res;
     };
 
+    auto bias_of = [&](const Tile& T) {
+        const int nb = (T.ng * WN + wn) * NB;
+        return (L_bias(mp.p[T.b], T.b) + (size_t)T.z * mp.zs_b)[(nb < mp.p[T.b].n_blocks32 ? nb : 0) * 32 + li];
+    };
     int j = 0;
     int last = -1;  // position of the last tile computed
     int last_done = -1;  // (chained layers) position of the tile whose epilogue was issued last
@@ -1125,10 +1194,19 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         HIFICAR_STAMP(63);
         return;
     }
+    Tile T_carry = {};  // the tile about to be computed: decoded once, as the previous tile's `Tn`
+    // The weight ring is primed ONCE, for the first tile; every tile's last tap then loads the next tile's head.  A wave without a channel block of its
+    // own in a tile (partial channel group) runs the K loop all the same — on block 0's weights, results dropped — so that the ring never has to be
+    // primed inside the tile loop: a second definition of the ring registers there makes hipcc copy all 32 of them at every tile's start, behind a
+    // vmcnt(0) that also sits out the previous tile's stores.
+    if (nxt(0) < my_rounds) {
+        T_carry = decode(tile_of(nxt(0)));
+        prime(T_carry);
+    }
     for (int it = nxt(0), itn; it < my_rounds; it = itn) {
         itn = nxt(it + 1);
         last = it;
-        const Tile T = decode(tile_of(it));
+        const Tile T = T_carry;
         const ConvParams& p = mp.p[T.b];
         const int nb = (T.ng * WN + wn) * NB;
         const bool active = nb < p.n_blocks32;
@@ -1141,17 +1219,24 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         const int rows_valid_t = kRowMajorAcc ? __builtin_amdgcn_readfirstlane(min(TM, seq_rows(p, T.seq) - T.t0)) : 0;
         // after this tile's stream is exhausted the loads continue with the NEXT tile's first tap-groups, so its ring is
         // primed when it starts (the last tile re-reads its own head: harmless)
-        const Tile Tn = decode(tile_of(itn < my_rounds ? itn : it));
+        const Tile Tn = itn < my_rounds ? decode(tile_of(itn)) : T;
+        T_carry = Tn;
         const frag_t* wp_next = wstream(Tn);
         const long long wst_next = NB == 2 ? wstride(Tn) : 0LL;
         const int groups_next = nchunks * L_ntaps(mp.p[Tn.b], Tn.b);
-        if (active && !primed) prime(T);  // first tile, or this wave sat out the previous tile (partial channel group)
+        // Direct output with transposed accumulators: a lane owns ONE channel, so the accumulators start at its bias (one value per lane for all MI x 16
+        // registers) and the epilogue has no bias to add or wait for; the NEXT tile's value is requested now and arrives behind this tile's K loop.
 #pragma unroll
         for (int q = 0; q < NB; ++q)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][mi][r] = 0.f;
+        // (kRowMajorAcc) this lane's bias, requested here and first used in the epilogue: the load has the whole K loop to arrive.  (Requested a tile
+        // ahead and folded into the accumulators' start value it costs more than it saves: hipcc waits for the loop-carried load with a vmcnt that
+        // also sits out every store of the previous tile's epilogue.)  A wave without a channel block of its own reads block 0's and never uses it.
+        float bias_l = 0.f;
+        if constexpr (kRowMajorAcc) bias_l = bias_of(T);
 
         for (int c = 0; c < nchunks; ++c, ++j) {
             HIFICAR_STAMP(1 + 3 * j);
@@ -1166,7 +1251,6 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
             if constexpr (kLightBarrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else __syncthreads();
             HIFICAR_STAMP(2 + 3 * j);
-            if (!active) continue;  // partial channel group: this wave only keeps the barriers
             const int buf_off = (j & 1) * buf_bytes;
             int ad[NC16][2];
             addr_set(buf_off, roff0, ad);
@@ -1208,7 +1292,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
                             groups_left = groups_next;
                         }
                         --groups_left;
-                        epilogue_rm(T, p, nb, rows_valid_t, std::true_type{}, ad);
+                        epilogue_rm(T, p, nb, rows_valid_t, bias_l, std::true_type{}, ad);
                         wp += NC16 * 128;
                     }
                 }
@@ -1244,15 +1328,19 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
                 }
             }
         }
+#ifndef HIFICAR_STAMP_AFTER_EPI  // (dev: -DHIFICAR_STAMP_AFTER_EPI moves the "tile finished" stamp behind the epilogue)
         HIFICAR_STAMP(3 * j);
+#endif
         last_done = it;
-        primed = active;  // an active tile ends with the ring holding the next tile's head
         if constexpr (kSplitPass) __syncthreads();  // X: the loader waves have finished the previous tile's output pass
         if constexpr (kRowMajorAcc) {
             if (active && !ovl) {
                 const int no_ad[NC16][2] = {};
-                epilogue_rm(T, p, nb, rows_valid_t, std::false_type{}, no_ad);
+                epilogue_rm(T, p, nb, rows_valid_t, bias_l, std::false_type{}, no_ad);
             }
+#ifdef HIFICAR_STAMP_AFTER_EPI
+            HIFICAR_STAMP(3 * j);
+#endif
         } else if constexpr (DOUT) {
             if (active) {
                 // (A/B form, HIFICAR_DOUT_ROWMAJOR=0) weights as the A operand: lane (li, g) owns row li and channels 8 q + 4 g + {0..3} of its block —
@@ -1489,13 +1577,13 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
         return T;
     };
     // tile walk: host schedule or round-robin, light first (see conv_bf16x3_kernel)
-    const int sched_lo = mp.sched_start ? mp.sched_start[blockIdx.x] : 0;
-    const int my_rounds = mp.sched_start ? mp.sched_start[blockIdx.x + 1] - sched_lo
+    const int sched_lo = mp.sched_start ? scalar_load_i32(mp.sched_start + blockIdx.x) : 0;
+    const int my_rounds = mp.sched_start ? scalar_load_i32(mp.sched_start + blockIdx.x + 1) - sched_lo
                                          : (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     auto tile_of = [&](int it) {
         int i = it;
         if ((blockIdx.x & 1) && my_rounds >= 3 && it >= my_rounds - 2) i = it == my_rounds - 1 ? my_rounds - 2 : my_rounds - 1;
-        if (mp.sched_start) return mp.sched_tiles[sched_lo + i];
+        if (mp.sched_start) return scalar_load_i32(mp.sched_tiles + sched_lo + i);
         return (int)blockIdx.x + (my_rounds - 1 - i) * (int)gridDim.x;
     };
     auto nxt = [&](int i) {  // first non-empty position at or after i (ragged batches; see conv_ws_body)
