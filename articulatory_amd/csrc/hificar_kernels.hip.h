@@ -202,6 +202,9 @@ __device__ __forceinline__ void store16(float* p, f32x4 v) {
 #ifndef HIFICAR_PIN
 #define HIFICAR_PIN 2
 #endif
+#ifndef HIFICAR_LIGHT_BARRIER
+#define HIFICAR_LIGHT_BARRIER 1  // (A/B: 0 = __syncthreads() in the MFMA waves of the direct-output and pair kernels)
+#endif
 template <int I, int NDS, int NVMEM, int NMFMA>
 __device__ __forceinline__ void pin_slab_slot() {
     if constexpr (I < NMFMA) {
@@ -1770,6 +1773,15 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
     }
 
     // ---------------- MFMA role ----------------
+    // The MFMA waves' barriers order LDS only (the loaders wait for their DMA in front of theirs): `s_waitcnt lgkmcnt(0) ; s_barrier` instead of
+    // __syncthreads(), whose vmcnt(0) also waits for the weight-ring loads just requested for the next tap — four times per tile.
+    auto pair_barrier = [] {
+#if HIFICAR_LIGHT_BARRIER
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+        __syncthreads();
+#endif
+    };
     __builtin_amdgcn_s_setprio(1);  // the MFMA wave outranks the loader wave sharing its SIMD for issue slots
     f32x16 acc[MI];
     using frag_t = typename std::conditional<F32, f32x4, bf16x8>::type;  // 16 bytes per lane either way
@@ -1911,7 +1923,7 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
         const Tile Tn = decode(tile_of(itn < my_rounds ? itn : it));
         const int Ls = seq_rows(p1, T.seq);
         HIFICAR_STAMP(6 * it);
-        __syncthreads();  // A: input landed
+        pair_barrier();  // A: input landed
         HIFICAR_STAMP(6 * it + 1);
         // ---- conv1 over TMc rows (time t0 - pad2 + r1) ----
         if constexpr (F32) {
@@ -1921,7 +1933,7 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
         run_conv(0, wave_row0 + li + (p1.tap_off0[0] - p1.off_min), p1.tap_step, p1.ntaps, stream2(T), k2);
         if constexpr (F32) act_on = false;
         HIFICAR_STAMP(6 * it + 2);
-        __syncthreads();  // F: the loaders are done with the previous tile's out-buffer (same LDS region as TS)
+        pair_barrier();  // F: the loaders are done with the previous tile's out-buffer (same LDS region as TS)
         {   // bias + LeakyReLU + split -> TS (zero outside the sequence: conv2's padding)
             const float slope = mp.slope_mid;
             f32x4 bias4[4];
@@ -1962,12 +1974,12 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
             }
         }
         HIFICAR_STAMP(6 * it + 3);
-        __syncthreads();  // B: input buffer free, TS complete
+        pair_barrier();  // B: input buffer free, TS complete
         HIFICAR_STAMP(6 * it + 4);
         // ---- conv2 over TS: output row r2 reads TS rows r2 .. r2 + k2 - 1 ----
         run_conv(ts_off, wave_row0 + li, 1, k2, stream1(Tn), mp.p1[Tn.b].ntaps);
         HIFICAR_STAMP(6 * it + 5);
-        __syncthreads();  // C: every wave is done reading TS; its region becomes the out-buffer
+        pair_barrier();  // C: every wave is done reading TS; its region becomes the out-buffer
         {
             float* O = reinterpret_cast<float*>(smem_b + o_off);
 #pragma unroll
@@ -1981,7 +1993,7 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
                 }
         }
     }
-    __syncthreads();  // Z
+    pair_barrier();  // Z
     if (last >= 0) write_out(decode(tile_of(last)), tid, 512);
 }
 
