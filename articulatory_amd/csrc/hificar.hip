@@ -145,7 +145,8 @@ struct hificar_handle {
         unsigned epoch = 0;
     };
     std::map<std::string, ChainState> chains;
-    bool act_read = true;          // HIFICAR_ACT_READ=0: every producer writes an activated copy for its consumer conv (the form before round 5; A/B runs)
+    bool act_read = false;         // HIFICAR_ACT_READ=1 (round 5: built, parity-green, a fifth less HBM traffic per layer pair — and no faster at batch 64, 1.5 % slower at batch 1 / 8):
+                                   // the convs1 of a layer-by-layer stage stage the fp32 residual stream itself, no producer writes an activated copy
     bool use_chain = false;        // HIFICAR_CHAIN=1: the layers of a chainable ResBlock stage as one launch (round 5: built, bit-identical, 1.8 % SLOWER —
                                    // the write-through stores / L2-bypassing loads the hand-off needs cost more than the launches it removes:
                                    // profiles/r05_chain_launch.txt)

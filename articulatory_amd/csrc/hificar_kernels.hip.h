@@ -103,6 +103,14 @@ __device__ __forceinline__ int scalar_load_i32(const int* p) {
     return v;
 }
 
+// two consecutive ints (a workgroup's [start, end) of the tile schedule) in one request
+__device__ __forceinline__ void scalar_load_2i32(const int* p, int& a, int& b) {
+    long long v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    a = (int)v;
+    b = (int)(v >> 32);
+}
+
 __device__ __forceinline__ bool is_ragged(const ConvParams& p) { return p.seq_len != nullptr || p.len_const >= 0; }
 
 // valid rows of sequence `seq` (wave-uniform: one scalar load)
@@ -309,7 +317,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
 #ifndef HIFICAR_LIGHT_BARRIER
 #define HIFICAR_LIGHT_BARRIER 1  // (A/B: 0 = __syncthreads() in the MFMA waves of the direct-output kernels)
 #endif
-    constexpr bool kLightBarrier = DOUT && HIFICAR_LIGHT_BARRIER != 0;
+    // (every form: an MFMA wave's barriers order LDS — staged items in, out-buffer hand-over out — never its own global loads / stores)
+    constexpr bool kLightBarrier = HIFICAR_LIGHT_BARRIER != 0;
+    constexpr bool kPrimeOnce = DOUT;  // the weight ring primed once in front of the tile loop (see there)
     constexpr bool kRowMajorAcc = DOUT && HIFICAR_DOUT_ROWMAJOR != 0;
 #ifndef HIFICAR_EPI_OVERLAP
 #define HIFICAR_EPI_OVERLAP 0  // (A/B, measured slower — profiles/r05_epilogue_layouts.txt: 1 = the epilogue of row blocks 0 .. MI - 2 between the MFMAs of the tile's last tap)
@@ -379,8 +389,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
     // LIGHT FIRST: the loader waves write a finished tile out while the MFMA waves compute the next one, and that only
     // hides completely behind a tile at least as heavy.  Odd workgroups swap their last two tiles so that
     // neighbouring CUs are not in the same phase all the time (synchronised DMA / output bursts cost ~15 % here).
-    const int sched_lo = mp.sched_start ? scalar_load_i32(mp.sched_start + blockIdx.x) : 0;
-    const int my_rounds = mp.sched_start ? scalar_load_i32(mp.sched_start + blockIdx.x + 1) - sched_lo
+    int sched_lo = 0, sched_hi = 0;
+    if (mp.sched_start) scalar_load_2i32(mp.sched_start + blockIdx.x, sched_lo, sched_hi);
+    const int my_rounds = mp.sched_start ? sched_hi - sched_lo
                                          : (mp.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     auto tile_of = [&](int it) {
         int i = it;
@@ -1141,7 +1152,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
                     w1l = wc[512 + 64];
                 }
                 HIFICAR_STAMP(1 + 3 * j);
-                __syncthreads();  // item j is staged
+                // item j is staged (the weight fragments requested just above stay in flight across it: __syncthreads() would wait for them here)
+                if constexpr (kLightBarrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else __syncthreads();
                 HIFICAR_STAMP(2 + 3 * j);
                 const int buf_off = (j & 1) * buf_bytes;
                 frag_t x0h[MI], x0l[MI], x1h[MI], x1l[MI];
@@ -1202,9 +1215,13 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
     // own in a tile (partial channel group) runs the K loop all the same — on block 0's weights, results dropped — so that the ring never has to be
     // primed inside the tile loop: a second definition of the ring registers there makes hipcc copy all 32 of them at every tile's start, behind a
     // vmcnt(0) that also sits out the previous tile's stores.
+    // (direct-output kernels only — kPrimeOnce: in the other forms — out-buffer, register-blocked, bf16x3 — the MFMA waves store nothing, partial channel
+    // groups are common (C = 64 on a 128-channel tile) and an idle wave's duplicate LDS reads cost more than the copies: bf16x3 leg 100 -> 93 M samples/s)
+    bool primed = false;  // (!kPrimeOnce) the ring holds the head of the tile about to be computed
+    (void)primed;
     if (nxt(0) < my_rounds) {
         T_carry = decode(tile_of(nxt(0)));
-        prime(T_carry);
+        if constexpr (kPrimeOnce) prime(T_carry);
     }
     for (int it = nxt(0), itn; it < my_rounds; it = itn) {
         itn = nxt(it + 1);
@@ -1227,6 +1244,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         const frag_t* wp_next = wstream(Tn);
         const long long wst_next = NB == 2 ? wstride(Tn) : 0LL;
         const int groups_next = nchunks * L_ntaps(mp.p[Tn.b], Tn.b);
+        if constexpr (!kPrimeOnce) {
+            if (active && !primed) prime(T);  // first tile, or this wave sat out the previous tile (partial channel group)
+        }
         // Direct output with transposed accumulators: a lane owns ONE channel, so the accumulators start at its bias (one value per lane for all MI x 16
         // registers) and the epilogue has no bias to add or wait for; the NEXT tile's value is requested now and arrives behind this tile's K loop.
 #pragma unroll
@@ -1254,6 +1274,9 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
             if constexpr (kLightBarrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else __syncthreads();
             HIFICAR_STAMP(2 + 3 * j);
+            if constexpr (!kPrimeOnce) {
+                if (!active) continue;  // partial channel group: this wave only keeps the barriers
+            }
             const int buf_off = (j & 1) * buf_bytes;
             int ad[NC16][2];
             addr_set(buf_off, roff0, ad);
@@ -1335,6 +1358,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         HIFICAR_STAMP(3 * j);
 #endif
         last_done = it;
+        primed = active;  // (!kPrimeOnce) an active tile ends with the ring holding the next tile's head
         if constexpr (kSplitPass) __syncthreads();  // X: the loader waves have finished the previous tile's output pass
         if constexpr (kRowMajorAcc) {
             if (active && !ovl) {
@@ -1580,8 +1604,9 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
         return T;
     };
     // tile walk: host schedule or round-robin, light first (see conv_bf16x3_kernel)
-    const int sched_lo = mp.sched_start ? scalar_load_i32(mp.sched_start + blockIdx.x) : 0;
-    const int my_rounds = mp.sched_start ? scalar_load_i32(mp.sched_start + blockIdx.x + 1) - sched_lo
+    int sched_lo = 0, sched_hi = 0;
+    if (mp.sched_start) scalar_load_2i32(mp.sched_start + blockIdx.x, sched_lo, sched_hi);
+    const int my_rounds = mp.sched_start ? sched_hi - sched_lo
                                          : (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     auto tile_of = [&](int it) {
         int i = it;
