@@ -1785,11 +1785,22 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
             HIFICAR_STAMP(4 * it + 1);
             if (it != first) write_out(Tprev, ltid, 256);  // hidden behind conv1 of this tile
             HIFICAR_STAMP(4 * it + 2);
+#if HIFICAR_LIGHT_BARRIER
+            // F, B, C order LDS only (the out-buffer has been READ: lgkmcnt); the output pass's global stores need not have landed — __syncthreads()
+            // would hold the MFMA waves at F for their whole write latency.  The DMA issued behind B is waited for at A (vmcnt(0) there).
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // F: shared region free
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: TS complete, input buffer free
+#else
             __syncthreads();                 // F: shared region free
             __syncthreads();                 // B: TS complete, input buffer free
+#endif
             HIFICAR_STAMP(4 * it + 3);
             if (itn < my_rounds) stage_in(decode(tile_of(itn)));  // hidden behind conv2
+#if HIFICAR_LIGHT_BARRIER
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // C: conv2 done reading TS
+#else
             __syncthreads();                 // C: conv2 done reading TS
+#endif
             Tprev = T;
         }
         __syncthreads();                     // Z: the last tile's accumulators are in the out-buffer
