@@ -369,16 +369,20 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         int b, z, ng, seq, t0;
     };
     auto decode = [&](int tile) {
-        Tile T;
-        const int bz = tile / tiles_per_branch;
-        T.b = bz / mp.zrep;
-        T.z = bz - T.b * mp.zrep;
-        const int rem = tile - bz * tiles_per_branch;
-        T.ng = rem / mp.nseq_tiles;
-        const int m = rem - T.ng * mp.nseq_tiles;
-        const int tps = mp.p[0].tiles_per_seq;
-        T.seq = m / tps;
-        T.t0 = (m - T.seq * tps) * TM;
+        Tile T;  // (unsigned divisions: half the scalar instructions of signed ones, and this runs between two tiles of every workgroup)
+        const unsigned ut = (unsigned)tile, tpb = (unsigned)tiles_per_branch, zr = (unsigned)mp.zrep, nst = (unsigned)mp.nseq_tiles;
+        const unsigned bz = ut / tpb;
+        const unsigned b = bz / zr;
+        T.b = (int)b;
+        T.z = (int)(bz - b * zr);
+        const unsigned rem = ut - bz * tpb;
+        const unsigned ng = rem / nst;
+        T.ng = (int)ng;
+        const unsigned m = rem - ng * nst;
+        const unsigned tps = (unsigned)mp.p[0].tiles_per_seq;
+        const unsigned seq = m / tps;
+        T.seq = (int)seq;
+        T.t0 = (int)((m - seq * tps) * (unsigned)TM);
         return T;
     };
 
@@ -1115,7 +1119,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
             const Tile T = decode(tile_of(it));
             const ConvParams& p = mp.p[T.b];
             const int nb = T.ng;  // one 32-channel block per tile
-            const int phase = nb / p.nb32_per_phase;
+            const int phase = (int)((unsigned)nb / (unsigned)p.nb32_per_phase);
             const int roff0 = __builtin_amdgcn_readfirstlane(p.tap_off0[phase] - p.off_min);
             const int tap_step = p.tap_step;
             const int nsteps = p.ntaps * NC16;
@@ -1230,7 +1234,7 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const Ch
         const ConvParams& p = mp.p[T.b];
         const int nb = (T.ng * WN + wn) * NB;
         const bool active = nb < p.n_blocks32;
-        const int phase = active ? nb / p.nb32_per_phase : 0;
+        const int phase = active ? (int)((unsigned)nb / (unsigned)p.nb32_per_phase) : 0;
         const int roff0 = __builtin_amdgcn_readfirstlane(L_tap_off0(p, T.b, phase) - L_off_min(p, T.b));
         const int tap_step = L_tap_step(p, T.b);
         const int ntaps = L_ntaps(p, T.b);
@@ -1596,11 +1600,12 @@ __device__ __forceinline__ void conv_pair_body(const PairParams& mp) {
         T.b = 0;
         if (mp.n_branches > 1 && tile >= mp.tile_start[1]) T.b = 1;
         if (mp.n_branches > 2 && tile >= mp.tile_start[2]) T.b = 2;
-        const int m = tile - mp.tile_start[T.b];
-        const int tps = mp.tiles_per_seq[T.b];
+        const unsigned m = (unsigned)(tile - mp.tile_start[T.b]);
+        const unsigned tps = (unsigned)mp.tiles_per_seq[T.b];
         T.tmo = TMc - (mp.p2[T.b].ntaps - 1);
-        T.seq = m / tps;
-        T.t0 = (m - T.seq * tps) * T.tmo;
+        const unsigned seq = m / tps;  // (unsigned: half the scalar instructions of a signed division)
+        T.seq = (int)seq;
+        T.t0 = (int)(m - seq * tps) * T.tmo;
         return T;
     };
     // tile walk: host schedule or round-robin, light first (see conv_bf16x3_kernel)
