@@ -266,7 +266,8 @@ __device__ __forceinline__ void pin_slab_step() {
 //   MFMA: D^T = W * X^T — weights are the A operand (pre-packed in lane order, streamed from L2 one tap
 //   ahead through a register ring whose pointer jumps to the next tile's stream during a tile's last tap),
 //   activations the B operand (lane l -> time row l&31, channels 8*(l>>5)+j = 16 contiguous bytes), software-
-//   pipelined one K slab ahead.  So a lane ends with 4 adjacent channels per register quad: 16-byte stores.
+//   pipelined one K slab ahead.  So a lane ends with 4 adjacent channels per register quad: 16-byte stores (out-buffer forms; the
+//   direct-output form swaps the operands: see DOUT below).
 // ------------------------------------------------------------------------------------------------
 //
 // F32 = true is the exact-fp32 arithmetic on the same skeleton: rows are plain fp32 LeakyReLU(x) (same 4*C bytes), a
@@ -291,9 +292,10 @@ __device__ __forceinline__ void pin_slab_step() {
 // (tile = WM*MI*32 rows x WN*NB*32 channels).  Every 16-byte load next to fp32 MFMAs costs ~22 cycles of matrix-pipe time.
 //
 // DOUT = true (round 4; the default of the dense exact-fp32 launches, HIFICAR_DOUT=0 turns it off): the MFMA waves write a finished tile straight from their accumulators
-// (bias, residual, LeakyReLU, 16-byte stores: lane (li, g) owns row li and four adjacent channels per register quad) — no LDS out-buffer, no
-// output pass in the loader waves, which then only stage.  Trades the loaders' share of the SIMDs' issue slots during the K loop (and the waits
-// at the out-buffer hand-over barriers) for an epilogue the matrix pipe idles through: +1.5 % end to end (37.41 -> 37.96 M samples/s).
+// (bias, residual, LeakyReLU, stores) — no LDS out-buffer, no output pass in the loader waves, which then only stage.  Trades the loaders' share of the SIMDs' issue
+// slots during the K loop (and the waits at the out-buffer hand-over barriers) for an epilogue the matrix pipe idles through: +1.5 % end to end (37.41 -> 37.96 M).
+// Round 5: in this form the operands are SWAPPED — D = X * W^T, activations as the A operand, same products in the same order — so that a lane owns ONE channel and
+// 16 rows per 32 x 32 block and a 4-byte wave-store writes two whole 128-byte rows (kRowMajorAcc / epilogue_rm below; 38.4 -> 39.6 M with the waits around it removed).
 template <int MI, int WM, int WN, int NC16, bool F32, int KS = 1, int NB = 1, bool DOUT = false, bool CHAIN = false>
 __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp, const ChainCtx* cx = nullptr, int layer = 0) {
     static_assert(!DOUT || (F32 && KS == 1 && NB == 1), "direct output: exact fp32, dense form, one channel block per wave");
