@@ -193,6 +193,8 @@ def get_parser():
     parser.add_argument("--verbose", type=int, default=1, help="logging level. higher is more logging. (default=1)")
     parser.add_argument("--batch-size", type=int, default=1,
                         help="utterances synthesised per device call (any lengths; not in the reference, which is batch-1)")
+    parser.add_argument("--dry-run", default=False, action="store_true",
+                        help="print this rank's share of the utterance list as one JSON line and exit (no GPU needed; not in the reference)")
     return parser
 
 
@@ -279,15 +281,21 @@ def main(argv=None):
     pairs = list_features(args.feats_scp, args.dumpdir, config.get("format", "npy"))
     logging.info(f"The number of features to be decoded = {len(pairs)}.")
 
-    if not torch.cuda.is_available():
-        raise RuntimeError("decode: no GPU visible; this package has no CPU synthesis path")
     # under torchrun (one process per GPU) every rank decodes its own share of the list and writes its own files
     from articulatory_amd.bin.shard import shard_items
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     # shard the (utt_id, path) list first — lengths from the .npy headers — and load each rank's utterances lazily, one at a
     # time (every rank loading the whole dataset would cost N x the I/O and a full copy in host RAM per rank)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         pairs = shard_items(pairs, length_of=lambda kv: npy_frames(kv[1]))
+    if args.dry_run:  # what this rank would decode, without touching a GPU (tests/test_distributed_gloo.py runs it under an 8-rank torchrun)
+        import json
+        print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "world_size": int(os.environ.get("WORLD_SIZE", "1")),
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "utterances": [u for u, _ in pairs],
+                          "frames": int(sum(npy_frames(pth) for _, pth in pairs))}), flush=True)
+        return
+    if not torch.cuda.is_available():
+        raise RuntimeError("decode: no GPU visible; this package has no CPU synthesis path")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     items = load_features(pairs)
     device = torch.device("cuda")
     model = load_model(args.checkpoint, config)

@@ -3,6 +3,7 @@
 // from a hificar_config, repacks folded weights into the kernels' layouts, plans the workspace and
 // enqueues the forward pass / the batched autoregressive loop on the caller's HIP stream.
 #include "hificar_kernels.hip.h"
+#include "hificar_launch.h"
 #include "hificar_backward.hip.h"
 #include "hificar_disc_kernels.hip.h"
 
@@ -69,7 +70,6 @@ struct ConvLayer {
     uint16_t* d_w16c = nullptr;  // same fragments packed with one K chunk = all channels (fused pair kernel, C <= 64)
     float* d_w32 = nullptr;      // exact-fp32 arithmetic: fp32 fragments in the same order
     float* d_w32c = nullptr;     // fp32 fragments with one K chunk = all channels (fused pair kernel, C <= 64)
-    float* d_w32n = nullptr;     // fp32 fragments packed with 16-channel K chunks (the 128-accumulator wave tile conv_f32nb_kernel<4,1,4,1>, C >= 256)
 };
 
 // One GBlock of a GBlockGenerator (articulatory/layers/pytorch_layers.py:32-91): conv1 = [ReLU, Upsample, c1a, ReLU, c1b (dilation 3)],
@@ -89,13 +89,13 @@ struct hificar_handle {
     int precision = HIFICAR_PREC_F32;
     bool profile_detail = false;   // HIFICAR_PROFILE_DETAIL=1: profile rows carry the layer name
     bool use_pair = true;          // HIFICAR_PAIR=0: run narrow stages layer by layer (A/B runs)
-    bool use_lpt = true;           // HIFICAR_LPT=0: round-robin tile walk instead of the host LPT schedule (A/B runs)
+    bool use_lpt = true;           // false: round-robin tile walk instead of the host LPT schedule
     double mi1_penalty = 1.05;     // cost factor of 32-row tiles in the exact-fp32 tile choice (they re-stream the weights most often: L2-bound when
                                    // K is long).  The discriminator engine raises it: its launches overlap on several streams, so a nearly
                                    // empty last round of taller tiles costs little there, while the L2 traffic of short tiles is shared by all
     int pick_throughput = 0;       // > 0: launches of at least this many tiles choose their tile shape by workgroup-time instead of makespan (set by
                                    // the discriminator engine, whose sub-networks run on eight streams; HIFICAR_DISC_PICK overrides, 0 = off)
-    bool xcd_order = true;         // HIFICAR_XCD_ORDER: XCD-contiguous tile order for one-round launches that stream more weights than activations
+    bool xcd_order = true;         // XCD-contiguous tile order for one-round launches that stream more weights than activations
     bool pair_small = true;        // HIFICAR_PAIR_SMALL: 128-row fused pair tiles at C = 32 for mid-size launches (pair_small_tiles)
     int ksplit = 1;                // HIFICAR_KSPLIT: 0 = never use the split-K conv form, 1 = when it is estimated faster (default), 2 = always
     int cf = 0;       // feature channels = in_channels - ar_output*use_ar
@@ -138,20 +138,6 @@ struct hificar_handle {
         int* d_tiles = nullptr;
     };
     std::map<std::string, Sched> scheds;
-    // chained launches (conv_f32chain_kernel: the layers of a ResBlock stage in one launch): per launch shape the per-tile counters (arena memory,
-    // zeroed once) and how many launches have counted on them
-    struct ChainState {
-        unsigned* d_flags = nullptr;
-        unsigned epoch = 0;
-    };
-    std::map<std::string, ChainState> chains;
-    bool act_read = false;         // HIFICAR_ACT_READ=1 (round 5: built, parity-green, a fifth less HBM traffic per layer pair — and no faster at batch 64, 1.5 % slower at batch 1 / 8):
-                                   // the convs1 of a layer-by-layer stage stage the fp32 residual stream itself, no producer writes an activated copy
-    bool use_chain = false;        // HIFICAR_CHAIN=1: the layers of a chainable ResBlock stage as one launch (round 5: built, bit-identical, 1.8 % SLOWER —
-                                   // the write-through stores / L2-bypassing loads the hand-off needs cost more than the launches it removes:
-                                   // profiles/r05_chain_launch.txt)
-    int* chain_err = nullptr;      // pinned host memory the device writes when a chained launch gave up waiting (never in a correct run)
-    int* d_chain_err = nullptr;
     std::map<std::string, int> tile_picks;  // launch shape -> index into kTileCfgs (launch_conv's choice, cached: it simulates the LPT assignment)
     struct Arena {
         char* d = nullptr;
@@ -205,7 +191,30 @@ struct hificar_handle {
     hipStream_t prof_stream = nullptr;
 };
 
-// RAII bracket: records an event before and after one kernel launch while profiling is on.
+// The library's environment switches — all of them, read once per handle (generator, GBlock generator, the discriminators' engine):
+//   HIFICAR_PROFILE_DETAIL=1   rows of hificar_profile_end carry the layer name ("kernel|layer xN")
+//   HIFICAR_LAUNCH_LOG=<path>  every kernel launch of the library is appended to <path> in enqueue order as "kernel|layer<TAB>flops<TAB>algorithmic bytes":
+//                              joined with rocprofv3's per-dispatch rows by tools/pmc_by_layer.py (implies PROFILE_DETAIL)
+//   HIFICAR_KSPLIT=0|1|2       split-K conv form: never / when estimated faster (default) / always.  0 makes every launch shape use one accumulation
+//                              order, so results are bit-identical across batch compositions (tests/test_gpu_parity.py)
+//   HIFICAR_PAIR=0             narrow stages layer by layer instead of the fused pair kernels;  HIFICAR_PAIR_SMALL=0: no 128-row pair tiles at C = 32
+//   HIFICAR_AR_DUAL_MIN / _MAX the batch sizes hificar_ar_loop runs as two halves on two streams (default 17..62; MAX=0: never)
+// hificar_disc.hip.inc adds HIFICAR_DISC_STREAMS=0 (sub-discriminators on the caller's stream: per-launch counters) and HIFICAR_COL2IM_VEC4=0.
+static FILE* g_launch_log = nullptr;
+static void read_env_switches(hificar_handle* h) {
+    if (const char* e = getenv("HIFICAR_PROFILE_DETAIL")) h->profile_detail = atoi(e) != 0;
+    if (const char* e = getenv("HIFICAR_LAUNCH_LOG")) {
+        if (!g_launch_log && *e) g_launch_log = fopen(e, "a");
+        if (g_launch_log) h->profile_detail = true;
+    }
+    if (const char* e = getenv("HIFICAR_KSPLIT")) h->ksplit = atoi(e);
+    if (const char* e = getenv("HIFICAR_PAIR")) h->use_pair = atoi(e) != 0;
+    if (const char* e = getenv("HIFICAR_PAIR_SMALL")) h->pair_small = atoi(e) != 0;
+    if (const char* e = getenv("HIFICAR_AR_DUAL_MIN")) h->ar_dual_min = atoi(e);
+    if (const char* e = getenv("HIFICAR_AR_DUAL_MAX")) h->ar_dual_max = atoi(e);
+}
+
+// RAII bracket around one kernel launch: the launch log, and an event before and after while profiling is on.
 struct ProfScope {
     hificar_handle* h;
     hipStream_t s;
@@ -213,6 +222,10 @@ struct ProfScope {
     std::string name;
     double flops, bytes;
     ProfScope(hificar_handle* h_, hipStream_t s_, const std::string& n, double f, double b) : h(h_), s(s_), name(n), flops(f), bytes(b) {
+        if (g_launch_log) {
+            fprintf(g_launch_log, "%s\t%.0f\t%.0f\n", n.c_str(), f, b);
+            fflush(g_launch_log);
+        }
         if (!h->profiling) return;
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
@@ -314,16 +327,7 @@ extern "C" int hificar_create(const hificar_config* cfg, hificar_handle** out) {
 
     hificar_handle* h = new hificar_handle();
     h->cfg = c;
-    if (const char* e = getenv("HIFICAR_PROFILE_DETAIL")) h->profile_detail = atoi(e) != 0;
-    if (const char* e = getenv("HIFICAR_PAIR")) h->use_pair = atoi(e) != 0;
-    if (const char* e = getenv("HIFICAR_PAIR_SMALL")) h->pair_small = atoi(e) != 0;  // (A/B runs)
-    if (const char* e = getenv("HIFICAR_XCD_ORDER")) h->xcd_order = atoi(e) != 0;    // (A/B runs)
-    if (const char* e = getenv("HIFICAR_LPT")) h->use_lpt = atoi(e) != 0;
-    if (const char* e = getenv("HIFICAR_CHAIN")) h->use_chain = atoi(e) != 0;
-    if (const char* e = getenv("HIFICAR_ACT_READ")) h->act_read = atoi(e) != 0;
-    if (const char* e = getenv("HIFICAR_KSPLIT")) h->ksplit = atoi(e);
-    if (const char* e = getenv("HIFICAR_AR_DUAL_MIN")) h->ar_dual_min = atoi(e);  // (A/B runs, tests)
-    if (const char* e = getenv("HIFICAR_AR_DUAL_MAX")) h->ar_dual_max = atoi(e);
+    read_env_switches(h);
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -615,10 +619,6 @@ static int pack_conv(hificar_handle* h, ConvLayer& L) {
 
     if ((rc = pack_w16(h, L, W, L.chunk16, &L.d_w16)) != HIFICAR_OK) return rc;
     if ((rc = pack_w32(h, L, W, L.chunk16, &L.d_w32)) != HIFICAR_OK) return rc;
-    // wide layers: a second fp32 pack with 16-channel K chunks for the 128-accumulator wave tile (its 128 x 256 out-buffer leaves room for
-    // 16-channel staging items only); HIFICAR_NB=0 (the default) never launches it
-    static const bool want_nb4 = getenv("HIFICAR_NB") && atoi(getenv("HIFICAR_NB")) != 0;
-    if (want_nb4 && L.n_blocks32 >= 8 && L.chunk16 != 16 && (rc = pack_w32(h, L, W, 16, &L.d_w32n)) != HIFICAR_OK) return rc;
     if (!L.transposed && L.cin_pad == L.cin && (L.cin == 32 || L.cin == 64) && L.cout == L.cin) {
         if ((rc = pack_w16(h, L, W, L.cin_pad, &L.d_w16c)) != HIFICAR_OK) return rc;
         if ((rc = pack_w32(h, L, W, L.cin_pad, &L.d_w32c)) != HIFICAR_OK) return rc;
@@ -626,34 +626,28 @@ static int pack_conv(hificar_handle* h, ConvLayer& L) {
     return HIFICAR_OK;
 }
 
-template <int MI, int WM, int WN, int NC16>
-static hipError_t set_lds_attr_b() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MI, WM, WN, NC16>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+// the conv kernels' instantiation sets (hificar_conv_inst.hip): the one place the host code meets them
+hipError_t hificar::conv_launch(const ConvShape& s, const void* params, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    bool handled = false;
+    hipError_t e = hipSuccess;
+#define HIFICAR_TRY_SET(n)                                                      \
+    if (!handled) e = conv_inst_launch_##n(s, params, grid, lds_bytes, stream, &handled); \
+    if (handled) return e;
+    HIFICAR_TRY_SET(0) HIFICAR_TRY_SET(1) HIFICAR_TRY_SET(2) HIFICAR_TRY_SET(3) HIFICAR_TRY_SET(4)
+    HIFICAR_TRY_SET(5) HIFICAR_TRY_SET(6) HIFICAR_TRY_SET(7) HIFICAR_TRY_SET(8) HIFICAR_TRY_SET(9)
+#undef HIFICAR_TRY_SET
+    return hipErrorInvalidValue;  // a shape that is not built
 }
 
-template <int MI, int WM, int WN, int NC16>
-static hipError_t set_lds_attr_f() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_kernel<MI, WM, WN, NC16>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+hipError_t hificar::conv_set_lds_attributes() {
+    hipError_t e = hipSuccess;
+#define HIFICAR_ATTR_SET(n) \
+    if (e == hipSuccess) e = conv_inst_attrs_##n();
+    HIFICAR_ATTR_SET(0) HIFICAR_ATTR_SET(1) HIFICAR_ATTR_SET(2) HIFICAR_ATTR_SET(3) HIFICAR_ATTR_SET(4)
+    HIFICAR_ATTR_SET(5) HIFICAR_ATTR_SET(6) HIFICAR_ATTR_SET(7) HIFICAR_ATTR_SET(8) HIFICAR_ATTR_SET(9)
+#undef HIFICAR_ATTR_SET
+    return e;
 }
-
-// every (MI, WM, WN) x NC16 instantiation of the conv kernels (both arithmetics)
-// (The kernel body also supports 8 MFMA waves per workgroup — two per SIMD, e.g. X(2, 2, 4, nc) — measured 3-5 % SLOWER than the
-// 4-wave shapes of the same tile in both arithmetics: the matrix pipe's idle share is not an issue-gap problem, see DESIGN.md.)
-#define HIFICAR_FOR_TILES(X, nc) \
-    X(4, 1, 4, nc) X(4, 2, 2, nc) X(4, 4, 1, nc) X(2, 1, 4, nc) X(2, 2, 2, nc) X(2, 4, 1, nc) X(1, 1, 4, nc) X(1, 2, 2, nc) X(1, 4, 1, nc)
-#define HIFICAR_FOR_ALL_TILES(X) HIFICAR_FOR_TILES(X, 1) HIFICAR_FOR_TILES(X, 2) HIFICAR_FOR_TILES(X, 4)
-// the register-blocked (NB = 2) shapes: (MI, WM, WN)
-#define HIFICAR_FOR_NB_TILES(X, nc) X(2, 2, 2, nc) X(2, 4, 1, nc) X(2, 1, 4, nc)
-#define HIFICAR_FOR_ALL_NB_TILES(X) HIFICAR_FOR_NB_TILES(X, 2) HIFICAR_FOR_NB_TILES(X, 4) X(4, 1, 4, 1)
-// chained ResBlock-stage launches (conv_f32chain_kernel): the shapes whose tiles are at least as tall as the widest halo of the shipped stages
-#define HIFICAR_FOR_CHAIN_TILES(X) \
-    X(4, 1, 4, 1) X(4, 2, 2, 1) X(4, 4, 1, 1) X(2, 1, 4, 1) X(2, 2, 2, 1) X(2, 4, 1, 1) \
-    X(4, 1, 4, 2) X(4, 2, 2, 2) X(4, 4, 1, 2) X(2, 1, 4, 2) X(2, 2, 2, 2) X(2, 4, 1, 2) \
-    X(4, 1, 4, 4) X(4, 2, 2, 4) X(4, 4, 1, 4) X(2, 1, 4, 4) X(2, 2, 2, 4) X(2, 4, 1, 4)
-// split-K forms: (MI, NC16)
-#define HIFICAR_FOR_SK_TILES(X) X(1, 1) X(2, 1) X(4, 1) X(1, 2) X(2, 2) X(4, 2) X(1, 4) X(2, 4) X(4, 4)
 
 // Device-side state every launch needs, whatever network the handle holds (the generator, or the discriminators' engine handle):
 // the zero page of the LDS DMA, the kernels' dynamic-LDS attributes, the first schedule arena.
@@ -665,48 +659,7 @@ static int engine_setup(hificar_handle* h) {
         HIP_TRY(hipMemset(z, 0, 256));
         h->d_zeros = static_cast<char*>(z);
     }
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 2, 2, 4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_bf16x3_kernel<4, 4, 1, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<4, 2, 2, 4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<4, 4, 1, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_f32_kernel<1, 4, 1, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-
-#define HIFICAR_SET_ATTR(mi, wm, wn, nc)         \
-    HIP_TRY((set_lds_attr_b<mi, wm, wn, nc>())); \
-    HIP_TRY((set_lds_attr_f<mi, wm, wn, nc>())); \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32do_kernel<mi, wm, wn, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIFICAR_FOR_ALL_TILES(HIFICAR_SET_ATTR)
-#undef HIFICAR_SET_ATTR
-#define HIFICAR_SET_ATTR_NB(mi, wm, wn, nc)                                                                                                \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32nb_kernel<mi, wm, wn, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                160 * 1024));                                                                                              \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3nb_kernel<mi, wm, wn, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIFICAR_FOR_ALL_NB_TILES(HIFICAR_SET_ATTR_NB)
-#undef HIFICAR_SET_ATTR_NB
-#define HIFICAR_SET_ATTR_SK(mi, nc)                                                                                              \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_bf16x3_kernel<mi, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                160 * 1024));                                                                                  \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_f32_kernel<mi, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIFICAR_FOR_SK_TILES(HIFICAR_SET_ATTR_SK)
-#undef HIFICAR_SET_ATTR_SK
-#define HIFICAR_SET_ATTR_CH(mi, wm, wn, nc) \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32chain_kernel<mi, wm, wn, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIFICAR_FOR_CHAIN_TILES(HIFICAR_SET_ATTR_CH)
-#undef HIFICAR_SET_ATTR_CH
-    if (!h->chain_err) {
-        void* p = nullptr;
-        HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocMapped));
-        h->chain_err = static_cast<int*>(p);
-        *h->chain_err = 0;
-        void* dp = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&dp, p, 0));
-        h->d_chain_err = static_cast<int*>(dp);
-    }
+    HIP_TRY(conv_set_lds_attributes());
     if (h->arenas.empty()) {
         int rca = arena_add(h, 0);
         if (rca != HIFICAR_OK) return rca;
@@ -965,7 +918,6 @@ static int arena_take(hificar_handle* h, size_t bytes, char** d, char** hm) {
             // the device first (rare, off the hot path; hificar_forward buckets non-AR lengths so that keys repeat)
             HIP_TRY(hipDeviceSynchronize());
             h->scheds.clear();
-            h->chains.clear();
             for (auto& a : h->arenas) a.used = 0;
             std::sort(h->arenas.begin(), h->arenas.end(), [](const hificar_handle::Arena& x, const hificar_handle::Arena& y) { return x.cap < y.cap; });
             if (bytes > h->arenas.back().cap) return fail(HIFICAR_E_INVALID, "tile schedule of %zu bytes exceeds the arena", bytes);
@@ -1053,41 +1005,14 @@ static int enter_stream(hificar_handle* h, hipStream_t stream) {
 struct TileCfg {
     int MI, WM, WN;
     int KS;  // 1: each MFMA wave owns a 32-channel block of the tile; 4: the four MFMA waves split the K loop of ONE block (WM = WN = 1)
-    int NB;  // channel blocks per MFMA wave (conv_ws_body's register blocking): tile = WM*MI*32 rows x WN*NB*32 channels
-    int CH;  // K chunk (channels per LDS item) the shape is built for; 0: the layer's own chunk16
+    int NB;  // channel blocks per MFMA wave (conv_ws_body's register blocking, bf16x3 only): tile = WM*MI*32 rows x WN*NB*32 channels
 };
 static size_t out_buf_bytes(const TileCfg& t) { return (size_t)t.KS * (t.WM * t.MI * 32) * (t.WN * t.NB * 32 + 4) * sizeof(float); }
 // preference order: ties keep the earlier entry (taller wave tiles re-read fewer weights per MFMA)
-static const TileCfg kTileCfgs[16] = {{4, 1, 4, 1, 2, 16}, {4, 1, 4, 1, 1, 0}, {4, 2, 2, 1, 1, 0}, {4, 4, 1, 1, 1, 0}, {2, 2, 2, 1, 2, 0}, {2, 4, 1, 1, 2, 0},
-                                      {2, 1, 4, 1, 2, 0}, {2, 1, 4, 1, 1, 0}, {2, 2, 2, 1, 1, 0}, {2, 4, 1, 1, 1, 0},
-                                      {1, 1, 4, 1, 1, 0}, {1, 2, 2, 1, 1, 0}, {1, 4, 1, 1, 1, 0}, {4, 1, 1, 4, 1, 0}, {2, 1, 1, 4, 1, 0}, {1, 1, 1, 4, 1, 0}};
-
-template <int MI, int WM, int WN, int NC16>
-static hipError_t launch_conv_do_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((conv_f32do_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
-    return hipGetLastError();
-}
-
-template <int MI, int WM, int WN, int NC16>
-static hipError_t launch_conv_nb_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
-    if (f32) hipLaunchKernelGGL((conv_f32nb_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
-    else hipLaunchKernelGGL((conv_bf16x3nb_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
-    return hipGetLastError();
-}
-
-template <int MI, int NC16>
-static hipError_t launch_conv_sk_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
-    if (f32) hipLaunchKernelGGL((conv_sk_f32_kernel<MI, NC16>), grid, dim3(512), lds, stream, mp);
-    else hipLaunchKernelGGL((conv_sk_bf16x3_kernel<MI, NC16>), grid, dim3(512), lds, stream, mp);
-    return hipGetLastError();
-}
-
-template <int MI, int WM, int WN, int NC16>
-static hipError_t launch_conv_t(const MultiConvParams& mp, dim3 grid, size_t lds, hipStream_t stream, bool f32) {
-    if (f32) hipLaunchKernelGGL((conv_f32_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
-    else hipLaunchKernelGGL((conv_bf16x3_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp);
-    return hipGetLastError();
-}
+constexpr int kNumTileCfgs = 15;
+static const TileCfg kTileCfgs[kNumTileCfgs] = {{4, 1, 4, 1, 1}, {4, 2, 2, 1, 1}, {4, 4, 1, 1, 1}, {2, 2, 2, 1, 2}, {2, 4, 1, 1, 2},
+                                                {2, 1, 4, 1, 2}, {2, 1, 4, 1, 1}, {2, 2, 2, 1, 1}, {2, 4, 1, 1, 1},
+                                                {1, 1, 4, 1, 1}, {1, 2, 2, 1, 1}, {1, 4, 1, 1, 1}, {4, 1, 1, 4, 1}, {2, 1, 1, 4, 1}, {1, 1, 1, 4, 1}};
 
 // One conv launch on activated rows (either arithmetic).  Per branch: xs (activated input) -> y (fp32, nullable) and/or ys (split copy of
 // LeakyReLU(out, slope_out), nullable), + optional fp32 residual.
@@ -1111,62 +1036,26 @@ struct ConvRep {
     long long zs_x = 0, zs_w = 0, zs_y = 0, zs_b = 0;
 };
 
-// A chained launch under construction (launch_chain): launch_conv is called once in PICK mode (the tile shape for the chain's widest halo) and
-// once per layer in FILL mode (parameters instead of a launch).
-struct ChainBuild {
-    enum { PICK, FILL } phase = PICK;
-    int halo_all = 0;     // widest halo over every layer of the chain
-    TileCfg tc = {0, 0, 0, 0, 0, 0};
-    int nc16 = 0;
-    int layer = 0;        // FILL: which layer this call describes
-    MultiConvParams mp;   // FILL, layer 0: the chain's common parameters (shapes, lengths, tile list)
-    ChainCtx cx;
-    dim3 grid;
-    size_t lds = 0;
-    double flops = 0.0, bytes = 0.0;
-    std::string key;
-};
-
-static bool dout_enabled() {
-    static const bool on = !getenv("HIFICAR_DOUT") || atoi(getenv("HIFICAR_DOUT")) != 0;
-    return on;
-}
-
 static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nbr, int nseq, int rows, const ConvIO* io,
-                              float slope_out, const Ragged& rg, hipStream_t stream, const ConvRep& zr = ConvRep(), ChainBuild* cb = nullptr) {
+                              float slope_out, const Ragged& rg, hipStream_t stream, const ConvRep& zr = ConvRep()) {
     const ConvLayer& L0 = *layers[0];
     const bool f32 = h->precision == HIFICAR_PREC_F32;  // rows are plain fp32 LeakyReLU(x) instead of split rows
     int halo_all = 0;
     for (int b = 0; b < nbr; ++b) halo_all = std::max(halo_all, layers[b]->off_max - layers[b]->off_min);
-    if (cb) halo_all = std::max(halo_all, cb->halo_all);  // (one staging-buffer size and one tile shape for every layer of a chain)
     // Tile shape: simulate the kernel's static tile walk (workgroup w takes tiles w, w+G, ...; branch-major order) and
     // take the shape with the smallest makespan.  A tile costs its MFMA issue cycles (all four MFMA waves run in
     // lock step: 3*MI MFMAs of 32 cycles per 16-channel K slab) plus a fixed per-tile and per-item overhead.
-    TileCfg tc = {1, 4, 1, 1, 1, 0};
+    TileCfg tc = {1, 4, 1, 1, 1};
     double best = 1e300;
-    int best_ti = 12;  // {1, 4, 1, 1, 1, 0}
-    // Direct output (round 4, conv_f32do_kernel): the dense exact-fp32 launches store their tiles straight from the MFMA waves' accumulators — no LDS
-    // out-buffer (its bytes are free for taller tiles / wider halos below), no output pass in the loader waves.  +1.5 % end to end; HIFICAR_DOUT=0
-    // restores the out-buffer form (A/B runs).
-    const bool dout_on = dout_enabled();
-    // HIFICAR_NB: 0 = never use the register-blocked (NB = 2) wave tiles, 1 = when the cost model prefers them, 2 = whenever one fits, 3 = only the
-    // 128-accumulator shape forced (A/B runs: tools/nb_ab.sh; measured in profiles/r04_nb_register_blocking.txt)
-    static const int nb_env = getenv("HIFICAR_NB") ? atoi(getenv("HIFICAR_NB")) : -1;
-    const int nb_mode = nb_env >= 0 ? nb_env : (f32 ? 0 : 1);  // default: off in exact fp32 (-1.0 %), cost model in bf16x3 (+1.3 %)
+    int best_ti = 11;  // {1, 4, 1, 1, 1}
+    // The dense exact-fp32 launches are direct-output (conv_f32do_kernel): tiles stored straight from the MFMA waves' accumulators, no LDS out-buffer
+    // (its bytes are free for taller tiles / wider halos below).  The register-blocked (NB = 2) wave tiles exist in bf16x3 only, where the cost model
+    // may prefer them (+1.3 %; in exact fp32 they measured -1.0 %: profiles/r04_nb_register_blocking.txt).
     const int nsteps_min = [&] {
         int m = 1 << 30;
         for (int b = 0; b < nbr; ++b) m = std::min(m, layers[b]->ntaps * (L0.chunk16 / 16));
         return m;
     }();
-    // dev override: HIFICAR_TILE="cin,MI,WM,WN" forces the shape for layers with that many input channels
-    static const char* force = getenv("HIFICAR_TILE");
-    int fc = 0, fmi = 0, fwm = 0, fwn = 0;
-    if (force) sscanf(force, "%d,%d,%d,%d", &fc, &fmi, &fwm, &fwn);
-    // HIFICAR_TILE1: the same for single-layer launches (input conv, upsamplers)
-    static const char* force1 = getenv("HIFICAR_TILE1");
-    int fc1 = 0, fmi1 = 0, fwm1 = 0, fwn1 = 0;
-    if (force1) sscanf(force1, "%d,%d,%d,%d", &fc1, &fmi1, &fwm1, &fwn1);
-    static const bool lpt_sim = !getenv("HIFICAR_LPT_SIM") || atoi(getenv("HIFICAR_LPT_SIM")) != 0;  // (A/B runs: 0 = the closed-form estimate)
     std::string pick_key;
     pick_key.reserve(160);
     pick_key += f32 ? 'f' : 'c';
@@ -1177,34 +1066,23 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         pick_key += layers[b]->name;
     }
     pick_key += '|' + std::to_string(nseq) + 'x' + std::to_string(rows) + 'z' + std::to_string(zr.n);
-    if (cb) pick_key += "|chain" + std::to_string(halo_all);
     const auto cached_pick = h->tile_picks.find(pick_key);
-    if (cb && cb->phase == ChainBuild::FILL) tc = cb->tc;
-    else if (cached_pick != h->tile_picks.end()) tc = kTileCfgs[cached_pick->second];
+    if (cached_pick != h->tile_picks.end()) tc = kTileCfgs[cached_pick->second];
     else
-    for (int ti = 0; ti < 16; ++ti) {
+    for (int ti = 0; ti < kNumTileCfgs; ++ti) {
         const TileCfg& t = kTileCfgs[ti];
         const int TM = t.WM * t.MI * 32;
-        const int chunk = t.CH ? t.CH : L0.chunk16, RB = chunk * 4;
-        if (t.CH) {  // a shape with its own K chunk: exact fp32, inference packs only (device-resident training weights refresh d_w32 alone)
-            bool ok = f32 && !h->train && t.CH != L0.chunk16;
-            for (int b = 0; b < nbr; ++b) ok = ok && layers[b]->d_w32n != nullptr;
-            if (!ok) continue;
-        } else if (t.NB == 2 && L0.chunk16 == 16) {
-            continue;  // (not instantiated)
-        }
-        const size_t obuf = (dout_on && f32 && t.KS == 1 && t.NB == 1) ? 0 : out_buf_bytes(t);
+        const int chunk = L0.chunk16, RB = chunk * 4;
+        if (t.NB == 2 && (f32 || L0.chunk16 == 16)) continue;  // (not instantiated)
+        const size_t obuf = (f32 && t.KS == 1) ? 0 : out_buf_bytes(t);
         if (2 * round_up_sz((size_t)(TM + halo_all) * RB, 1024) + obuf > 160 * 1024) continue;
         if (t.NB == 2) {  // a wave's two channel blocks share the activation fragments: same phase of a polyphase (transposed) conv
-            bool ok = nb_mode != 0 && L0.n_blocks32 >= 2;
+            bool ok = L0.n_blocks32 >= 2;
             for (int b = 0; b < nbr; ++b) ok = ok && (layers[b]->n_phase == 1 || layers[b]->nb32_per_phase % 2 == 0);
             if (!ok) continue;
         }
-        if (fc == L0.cin_pad && nbr == 3 && !(t.MI == fmi && t.WM == fwm && t.WN == fwn)) continue;
-        if (fc1 == L0.cin_pad && nbr == 1 && zr.n == 1 && !(t.KS == 1 && t.MI == fmi1 && t.WM == fwm1 && t.WN == fwn1)) continue;
         if (t.KS == 4 && (h->ksplit == 0 || nsteps_min < 2)) continue;
         if (t.KS == 1 && h->ksplit == 2 && nsteps_min >= 2) continue;
-        if (cb && (t.KS != 1 || t.NB != 1 || t.MI < 2 || t.CH)) continue;  // (the shapes conv_f32chain_kernel is built for)
         const long long tiles_per_branch = (long long)nseq * ((rows + TM - 1) / TM) * ((L0.n_blocks32 + t.WN * t.NB - 1) / (t.WN * t.NB));
         const long long total = tiles_per_branch * nbr * zr.n;
         const int G = (int)std::min<long long>(total, h->num_cus);
@@ -1227,7 +1105,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
             cb[b] = c;
         }
         double worst = std::max(heaviest, total_cost / G);
-        if (h->use_lpt && lpt_sim && !h->shared_chip && total > G && total <= 4096) {
+        if (h->use_lpt && !h->shared_chip && total > G && total <= 4096) {
             // the makespan of the assignment the kernel will actually walk (get_schedule: longest tile first onto the least loaded workgroup).
             // Round 4: the closed form below charged "+ half a light tile" whenever the tile count is not a multiple of the workgroups — 384
             // tiles of weight 12 : 8 : 4 on 256 workgroups balance exactly (12 | 8 + 4), and the 128-row tile it ruled out at C = 256 is 1.1 %
@@ -1255,7 +1133,6 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         // operand loads per MFMA: 2 (MI + NB) 16-byte loads per slab step against (8 | 3) MI NB MFMAs
         if (t.NB == 2) worst *= f32 ? (t.MI == 4 ? 0.95 : t.MI == 2 ? 0.975 : 1.02) : (t.MI == 2 ? 0.93 : 1.10);
         else if (t.MI < 4) worst *= f32 ? (t.MI == 2 ? 1.02 : h->mi1_penalty) : (t.MI == 2 ? 1.10 : 1.25);
-        if (t.NB == 2 && (nb_mode == 2 || (nb_mode == 3 && t.CH))) worst *= 0.5;  // (3: only the 128-accumulator shape is forced)
         if (t.KS == 4) worst *= 1.05;  // near-ties go to the dense form
         if (worst < best * 0.98) {  // near-ties keep the earlier (taller) shape
             best = worst;
@@ -1263,17 +1140,12 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
             best_ti = ti;
         }
     }
-    if (cached_pick == h->tile_picks.end() && !(cb && cb->phase == ChainBuild::FILL)) {
+    if (cached_pick == h->tile_picks.end()) {
         if (h->tile_picks.size() > 20000) h->tile_picks.clear();  // (a very large number of distinct launch shapes: start over)
         h->tile_picks.emplace(pick_key, best_ti);
     }
-    if (cb && cb->phase == ChainBuild::PICK) {
-        cb->tc = tc;
-        cb->nc16 = (tc.CH ? tc.CH : L0.chunk16) / 16;
-        return HIFICAR_OK;
-    }
     const int TM = tc.WM * tc.MI * 32;
-    const int chunk_sel = tc.CH ? tc.CH : L0.chunk16, RB = chunk_sel * 4;
+    const int chunk_sel = L0.chunk16, RB = chunk_sel * 4;
     const int nc16 = chunk_sel / 16;
     MultiConvParams mp;
     memset(&mp, 0, sizeof(mp));
@@ -1286,7 +1158,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         mp.p[b].xs = io[b].xs;
         mp.p[b].ys = io[b].ys;
         if (io[b].x_slope >= 0.f) {
-            if (!f32 || cb) return fail(HIFICAR_E_INVALID, "internal: pre-activation input rows of %s outside the exact-fp32 layer-by-layer launches", Lb.name.c_str());
+            if (!f32) return fail(HIFICAR_E_INVALID, "internal: pre-activation input rows of %s outside the exact-fp32 layer-by-layer launches", Lb.name.c_str());
             mp.p[b].act_in = 1;
             mp.p[b].slope_in = io[b].x_slope;
         }
@@ -1305,14 +1177,14 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         mp.p[b].zeros = h->d_zeros;
         mp.p[b].slope_out = slope_out;
         mp.p[b].cout_real = Lb.cout_pad;
-        if (f32) mp.p[b].w16 = reinterpret_cast<const bf16x8*>(tc.CH ? Lb.d_w32n : Lb.d_w32);
+        if (f32) mp.p[b].w16 = reinterpret_cast<const bf16x8*>(Lb.d_w32);
         const double pos = (double)nseq * rows;
         flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K * zr.n;
         bytes += 4.0 * (pos * Lb.cin_pad / std::max(1, io[b].x_up) + pos * Lb.cout_total * ((io[b].res ? 1 : 0) + (io[b].y ? 1 : 0) + (io[b].ys ? 1 : 0)) +
                         (double)Lb.cin * Lb.cout * Lb.K);
     }
     const size_t buf_bytes = round_up_sz((size_t)(TM + halo_all) * RB, 1024);
-    const bool dout = dout_on && f32 && tc.KS == 1 && tc.NB == 1;
+    const bool dout = f32 && tc.KS == 1;
     const size_t lds = 2 * buf_bytes + (dout ? 0 : out_buf_bytes(tc));
     mp.n_branches = nbr;
     mp.nseq_tiles = nseq * ((rows + TM - 1) / TM);
@@ -1342,141 +1214,24 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         }
         if (zr.n > 1) key += "z" + std::to_string(zr.n);
         key += "|" + std::to_string(nseq) + "x" + std::to_string((rows + TM - 1) / TM) + "t" + std::to_string(TM) + "w" + std::to_string(tc.WN) +
-               "k" + std::to_string(tc.KS) + (tc.NB == 2 ? "b" : "") + (tc.CH ? "c" + std::to_string(tc.CH) : "");
+               "k" + std::to_string(tc.KS) + (tc.NB == 2 ? "b" : "");
         int rc2 = get_schedule(h, key, costs, (int)grid.x, stream, &mp.sched_start, &mp.sched_tiles);
         if (rc2 != HIFICAR_OK) return rc2;
-    }
-    if (cb) {  // FILL: this layer's per-branch fields go into the chain's table; layer 0 also provides the common parameters
-        if (!dout) return fail(HIFICAR_E_INVALID, "internal: chained layers need the direct-output form");
-        if (cb->layer == 0) {
-            cb->mp = mp;
-            cb->grid = grid;
-            cb->lds = lds;
-            cb->key = pick_key;
-        }
-        for (int b = 0; b < 3; ++b) {
-            ChainLayerBranch& q = cb->cx.lb[cb->layer][b];
-            memset(&q, 0, sizeof(q));
-            if (b >= nbr) continue;
-            const ConvParams& pb = mp.p[b];
-            q.w16 = pb.w16;
-            q.bias = pb.bias;
-            q.res = pb.res;
-            q.y = pb.y;
-            q.xs = pb.xs;
-            q.ys = pb.ys;
-            q.ntaps = pb.ntaps;
-            q.off_min = pb.off_min;
-            q.halo = pb.halo;
-            q.tap_step = pb.tap_step;
-            q.tap_off0 = pb.tap_off0[0];
-        }
-        cb->flops += flops;
-        cb->bytes += bytes;
-        return HIFICAR_OK;
     }
     char kname[96];
     if (dout) snprintf(kname, sizeof(kname), "conv_f32do_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, nc16);
     else if (tc.KS == 4) snprintf(kname, sizeof(kname), "%s<%d,%d>", f32 ? "conv_sk_f32_kernel" : "conv_sk_bf16x3_kernel", tc.MI, nc16);
-    else if (tc.NB == 2) snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_f32nb_kernel" : "conv_bf16x3nb_kernel", tc.MI, tc.WM, tc.WN, nc16);
-    else snprintf(kname, sizeof(kname), "%s<%d,%d,%d,%d>", f32 ? "conv_f32_kernel" : "conv_bf16x3_kernel", tc.MI, tc.WM, tc.WN, nc16);
+    else if (tc.NB == 2) snprintf(kname, sizeof(kname), "conv_bf16x3nb_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, nc16);
+    else snprintf(kname, sizeof(kname), "conv_bf16x3_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, nc16);
     if (h->profile_detail) {  // per-layer rows in the profile (tools/layer_profile.py)
         const size_t n = strlen(kname);
         snprintf(kname + n, sizeof(kname) - n, "|%s x%d", L0.name.c_str(), nbr);
     }
     ProfScope prof(h, stream, kname, flops, bytes);
-    hipError_t e = hipErrorInvalidValue;
-#define HIFICAR_DISPATCH(mi, wm, wn, nc)                                                                                        \
-    if (tc.KS == 1 && tc.NB == 1 && tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc)                                   \
-        e = dout ? launch_conv_do_t<mi, wm, wn, nc>(mp, grid, lds, stream) : launch_conv_t<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
-    HIFICAR_FOR_ALL_TILES(HIFICAR_DISPATCH)
-#undef HIFICAR_DISPATCH
-#define HIFICAR_DISPATCH_NB(mi, wm, wn, nc) \
-    if (tc.KS == 1 && tc.NB == 2 && tc.MI == mi && tc.WM == wm && tc.WN == wn && nc16 == nc) e = launch_conv_nb_t<mi, wm, wn, nc>(mp, grid, lds, stream, f32);
-    HIFICAR_FOR_ALL_NB_TILES(HIFICAR_DISPATCH_NB)
-#undef HIFICAR_DISPATCH_NB
-#define HIFICAR_DISPATCH_SK(mi, nc) \
-    if (tc.KS == 4 && tc.MI == mi && nc16 == nc) e = launch_conv_sk_t<mi, nc>(mp, grid, lds, stream, f32);
-    HIFICAR_FOR_SK_TILES(HIFICAR_DISPATCH_SK)
-#undef HIFICAR_DISPATCH_SK
+    const ConvShape shape = {dout ? kConvF32do : tc.KS == 4 ? (f32 ? kConvSkF32 : kConvSkBf16x3) : tc.NB == 2 ? kConvBf16x3nb : kConvBf16x3,
+                             tc.MI, tc.WM, tc.WN, nc16};
+    const hipError_t e = conv_launch(shape, &mp, grid, lds, stream);
     if (e != hipSuccess) return fail(HIFICAR_E_HIP, "conv launch (%s, %s) failed: %s", L0.name.c_str(), kname, hipGetErrorString(e));
-    return HIFICAR_OK;
-}
-
-template <int MI, int WM, int WN, int NC16>
-static hipError_t launch_chain_t(const MultiConvParams& mp, const ChainCtx& cx, dim3 grid, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((conv_f32chain_kernel<MI, WM, WN, NC16>), grid, dim3((WM * WN + 4) * 64), lds, stream, mp, cx);
-    return hipGetLastError();
-}
-
-// The layers of a ResBlock stage as ONE launch (conv_f32chain_kernel, ChainCtx in hificar_kernels.hip.h): lay[l] / io[l] are layer l's branches —
-// the same blocks in the same order in every layer, every layer C -> C on the same rows.  Returns HIFICAR_OK with *done = false when the stage is
-// not chainable (the caller then launches layer by layer).
-static int launch_chain(hificar_handle* h, const ConvLayer* const (*lay)[3], const ConvIO (*io)[3], int nlayers, int nbr, int nseq, int rows,
-                        float slope_out, const Ragged& rg, hipStream_t stream, bool* done) {
-    *done = false;
-    if (!h->use_chain || h->precision != HIFICAR_PREC_F32 || !dout_enabled() || h->shared_chip || h->train || nlayers < 2 || nlayers > kMaxChain || nbr > 3)
-        return HIFICAR_OK;
-    ChainBuild cb;
-    memset(&cb.cx, 0, sizeof(cb.cx));
-    for (int l = 0; l < nlayers; ++l)
-        for (int b = 0; b < nbr; ++b) {
-            const ConvLayer& L = *lay[l][b];
-            if (L.n_phase != 1 || L.cin_pad != lay[0][0]->cin_pad || L.cout_total != lay[0][0]->cout_total || L.chunk16 != lay[0][0]->chunk16 || L.cin_pad / L.chunk16 < 2 ||
-                io[l][b].x_up > 1 || io[l][b].x_rows || io[l][b].x_row_bytes || io[l][b].x_seq_bytes || io[l][b].mask_src)
-                return HIFICAR_OK;
-            cb.halo_all = std::max(cb.halo_all, L.off_max - L.off_min);
-        }
-    int rc;
-    cb.phase = ChainBuild::PICK;
-    if ((rc = launch_conv(h, lay[0], nbr, nseq, rows, io[0], slope_out, rg, stream, ConvRep(), &cb)) != HIFICAR_OK) return rc;
-    const TileCfg tc = cb.tc;
-    const int TM = tc.WM * tc.MI * 32;
-    // a tile's writes land in a buffer the PREVIOUS layer's neighbouring tiles read as halo; the counters it waits for cover exactly the row tiles
-    // next to it, so every halo has to stay inside one neighbouring tile
-    if (tc.KS != 1 || tc.NB != 1 || tc.MI < 2 || TM < cb.halo_all) return HIFICAR_OK;
-    cb.phase = ChainBuild::FILL;
-    for (int l = 0; l < nlayers; ++l) {
-        cb.layer = l;
-        if ((rc = launch_conv(h, lay[l], nbr, nseq, rows, io[l], slope_out, rg, stream, ConvRep(), &cb)) != HIFICAR_OK) return rc;
-    }
-    const MultiConvParams& mp = cb.mp;
-    // per-tile counters of this launch shape: [layer][branch][sequence x row tile], cumulative over launches
-    const size_t nflags = (size_t)nlayers * mp.n_branches * mp.nseq_tiles;
-    const std::string key = cb.key + "|L" + std::to_string(nlayers);
-    auto it = h->chains.find(key);
-    if (it == h->chains.end()) {
-        char *dp = nullptr, *hp = nullptr;
-        if ((rc = arena_take(h, nflags * sizeof(unsigned), &dp, &hp)) != HIFICAR_OK) return rc;
-        HIP_TRY(hipMemsetAsync(dp, 0, nflags * sizeof(unsigned), stream));
-        hificar_handle::ChainState st;
-        st.d_flags = reinterpret_cast<unsigned*>(dp);
-        it = h->chains.emplace(key, st).first;
-    }
-    hificar_handle::ChainState& st = it->second;
-    if ((unsigned long long)(st.epoch + 2) * (unsigned)mp.ngroups >= 0xF0000000ull) {  // (after ~10^9 launches: start the counters over, in stream order)
-        HIP_TRY(hipMemsetAsync(st.d_flags, 0, nflags * sizeof(unsigned), stream));
-        st.epoch = 0;
-    }
-    cb.cx.nlayers = nlayers;
-    cb.cx.flags = st.d_flags;
-    cb.cx.want = (st.epoch + 1) * (unsigned)mp.ngroups;
-    cb.cx.err = h->d_chain_err;
-    ++st.epoch;
-    char kname[96];
-    snprintf(kname, sizeof(kname), "conv_f32chain_kernel<%d,%d,%d,%d>", tc.MI, tc.WM, tc.WN, cb.nc16);
-    if (h->profile_detail) {
-        const size_t n = strlen(kname);
-        snprintf(kname + n, sizeof(kname) - n, "|%s x%d L%d", lay[0][0]->name.c_str(), nbr, nlayers);
-    }
-    ProfScope prof(h, stream, kname, cb.flops, cb.bytes);
-    hipError_t e = hipErrorInvalidValue;
-#define HIFICAR_DISPATCH_CH(mi, wm, wn, nc) \
-    if (tc.MI == mi && tc.WM == wm && tc.WN == wn && cb.nc16 == nc) e = launch_chain_t<mi, wm, wn, nc>(mp, cb.cx, cb.grid, cb.lds, stream);
-    HIFICAR_FOR_CHAIN_TILES(HIFICAR_DISPATCH_CH)
-#undef HIFICAR_DISPATCH_CH
-    if (e != hipSuccess) return fail(HIFICAR_E_HIP, "chained conv launch (%s) failed: %s", kname, hipGetErrorString(e));
-    *done = true;
     return HIFICAR_OK;
 }
 
@@ -1510,8 +1265,6 @@ static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const Con
     const size_t in_bytes = round_up_sz((size_t)(TMc + a.off_max - a.off_min) * C * 4, 1024);
     const size_t ts_bytes = std::max<size_t>((size_t)(TMc + 16) * C * 4, (size_t)TMc * (C + 4) * sizeof(float));
     if (in_bytes + ts_bytes > 160 * 1024) return false;
-    static const bool c64_f32 = !getenv("HIFICAR_PAIR_C64_F32") || atoi(getenv("HIFICAR_PAIR_C64_F32")) != 0;  // (A/B runs)
-    if (C == 64 && h->precision == HIFICAR_PREC_F32 && !c64_f32) return false;
     if (nseq > 0) {
         // The fused kernel's tiles are tall (TMc conv1 rows for TMc - (k-1) output rows).  (i) A launch with few tiles leaves most
         // CUs idle behind long serial tiles: small batches run layer by layer.  (ii) Tile quantisation: 1000 rows at k = 11 need 5
@@ -1522,8 +1275,7 @@ static bool pair_eligible(const hificar_handle* h, const ConvLayer& a, const Con
         const long long tiles = (long long)nseq * ((rows + tmo - 1) / tmo);
         if (3 * tiles < h->num_cus) return false;
         const double waste = (double)((rows + tmo - 1) / tmo) * TMc / rows;
-        static const double waste_f32 = getenv("HIFICAR_PAIR_WASTE") ? atof(getenv("HIFICAR_PAIR_WASTE")) : 1.12;  // (A/B runs)
-        if (waste > (h->precision == HIFICAR_PREC_F32 ? waste_f32 : 1.35)) return false;
+        if (waste > (h->precision == HIFICAR_PREC_F32 ? 1.12 : 1.35)) return false;
     }
     return true;
 }
@@ -1593,15 +1345,8 @@ static int launch_pair(hificar_handle* h, const ConvLayer* const* l1, const Conv
         snprintf(kname + n, sizeof(kname) - n, "|%s x%d", l1[0]->name.c_str(), nbr);
     }
     ProfScope prof(h, stream, kname, flops, bytes);
-    if (f32) {
-        if (C == 64) hipLaunchKernelGGL((conv_pair_f32_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
-        else if (small) hipLaunchKernelGGL((conv_pair_f32_kernel<1, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
-        else hipLaunchKernelGGL((conv_pair_f32_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
-    } else {
-        if (C == 64) hipLaunchKernelGGL((conv_pair_bf16x3_kernel<4, 2, 2, 4>), grid, dim3(512), lds, stream, pp);
-        else hipLaunchKernelGGL((conv_pair_bf16x3_kernel<4, 4, 1, 2>), grid, dim3(512), lds, stream, pp);
-    }
-    hipError_t e = hipGetLastError();
+    const ConvShape shape = {f32 ? kPairF32 : kPairBf16x3, MI, WM, 4 / WM, C / 16};
+    const hipError_t e = conv_launch(shape, &pp, grid, lds, stream);
     if (e != hipSuccess) return fail(HIFICAR_E_HIP, "pair launch (%s) failed: %s", l1[0]->name.c_str(), hipGetErrorString(e));
     return HIFICAR_OK;
 }
@@ -1783,7 +1528,8 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
     const size_t tap_se = tapping ? stage_elems(h, B, T) : 0;
     const int nbk = cfg.n_blocks;
     // residual blocks of a stage run side by side, heaviest kernel size first
-    int order[kMaxBlk] = {0, 1, 2, 3};
+    int order[kMaxBlk];
+    for (int j = 0; j < kMaxBlk; ++j) order[j] = j;
     std::sort(order, order + nbk, [&](int a, int b) { return cfg.resblock_kernel_sizes[a] > cfg.resblock_kernel_sizes[b]; });
     int max_d = 0;
     for (int j = 0; j < nbk; ++j) max_d = std::max(max_d, cfg.n_dilations[j]);
@@ -1841,26 +1587,15 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             // Narrow stage whose every layer pair runs in the fused kernel: the residual stream stays fp32-only (the pair
             // kernel activates + splits its input while staging), ping-ponging between x[j] and xt[j]; no activated copies
             // are written at all.  Otherwise: activated copies ("_s") travel next to the fp32 stream.
-            static const bool f32in = !getenv("HIFICAR_PAIR_F32IN") || atoi(getenv("HIFICAR_PAIR_F32IN")) != 0;  // A/B runs
-            bool all_pairs = f32in && !tap_convs1 && !tp && add_convs;
+            bool all_pairs = !tap_convs1 && !tp && add_convs;
             for (int j = 0; j < nbk && all_pairs; ++j)
                 for (int d = 0; d < cfg.n_dilations[j]; ++d) {
                     const int ci = conv_index(h, i, j, d);
                     all_pairs = all_pairs && pair_eligible(h, h->convs1[ci], h->convs2[ci], B, rows * cfg.upsample_scales[i]);
                 }
-            // Layer-by-layer stages in inference, exact fp32 (round 5): the convs1 read the fp32 residual stream itself and apply LeakyReLU while staging
-            // (ConvParams::act_in), so neither the upsampler nor the convs2 store an activated copy — 64 KB less per output tile of a direct epilogue that
-            // the matrix pipe idles through.  Not with fused pairs in the stage or single-conv layers (those write the stream they read in place),
-            // not in training (the weight gradients read the activated copies).
-            bool stage_act = h->act_read && f32 && !tp && !h->use_chain && add_convs && !all_pairs;
-            for (int j = 0; j < nbk && stage_act; ++j)
-                for (int d = 0; d < cfg.n_dilations[j]; ++d) {
-                    const int ci = conv_index(h, i, j, d);
-                    if (pair_eligible(h, h->convs1[ci], h->convs2[ci], B, rows * cfg.upsample_scales[i])) stage_act = false;
-                }
             {   // LeakyReLU + ConvTranspose1d (hifigan.py:224): fp32 u (first residual) (+ activated copy: first conv input)
                 const ConvLayer* lay[1] = {&h->ups[i]};
-                const ConvIO io[1] = {{up_in, nullptr, ws.u, all_pairs || stage_act ? nullptr : (tp ? tp->u_s[i] : ws.u_s)}};
+                const ConvIO io[1] = {{up_in, nullptr, ws.u, all_pairs ? nullptr : (tp ? tp->u_s[i] : ws.u_s)}};
                 if ((rc = launch_conv(h, lay, 1, B, rows, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
             }
             rows *= cfg.upsample_scales[i];
@@ -1908,14 +1643,6 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
             // activated stream of each branch: where the next conv1 reads its input.  It alternates between x_s[j] and
             // xt_s[j]: a launch never writes the buffer it (or a neighbouring tile, through the halo) reads.
             const char* u_act = tp ? tp->u_s[i] : ws.u_s;
-            // The stage's layers, conv1(d0), conv2(d0), conv1(d1), ...: first collected (`collect`), so that a chainable stage — inference, exact fp32,
-            // every block with the same number of dilations, no fused pairs, no taps — runs as ONE launch (launch_chain); otherwise launched one by one.
-            const ConvLayer* ch_lay[kMaxChain][3];
-            ConvIO ch_io[kMaxChain][3];
-            int ch_n = 0, ch_nbr = -1;
-            bool ch_ok = !tp && !tapping && add_convs && nbk <= 3 && 2 * max_d <= kMaxChain;
-            for (int j = 0; j < nbk; ++j) ch_ok = ch_ok && cfg.n_dilations[j] == max_d;
-            auto run_layers = [&](bool collect) -> int {
             const char* cur_s[kMaxBlk] = {u_act, u_act, u_act, u_act};
             for (int d = 0; d < max_d; ++d) {  // residual_block.py:217-221
                 const ConvLayer* l1[kMaxBlk];
@@ -1945,11 +1672,6 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     }
                     io1[n] = {cur_s[j], nullptr, tap_convs1 ? h->tap_scratch + (size_t)n * tap_se : nullptr, mid};
                     io2[n] = {mid, d == 0 ? ws.u : xres[j], xres[j], last ? nullptr : lbl_out[n]};
-                    if (stage_act) {  // conv1 stages the fp32 stream; conv2 (in place on it: it reads no halo of it) writes no activated copy
-                        io1[n].xs = reinterpret_cast<const char*>(d == 0 ? ws.u : xres[j]);
-                        io1[n].x_slope = cfg.lrelu_slope;
-                        io2[n].ys = nullptr;
-                    }
                     if (!add_convs) {  // one conv per layer: conv1 carries the residual epilogue; its activated output is the next layer's input
                         char* nxt = tp ? tp->x_s[i][j][d] : pair_out[n];
                         io1[n] = {cur_s[j], d == 0 ? ws.u : xres[j], xres[j], last ? nullptr : nxt};
@@ -1958,22 +1680,6 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     iop[n] = {nullptr, cur_s[j], d == 0 ? ws.u : xres[j], xres[j], last ? nullptr : pair_out[n]};
                     jn[n] = j;
                     ++n;
-                }
-                if (collect) {
-                    if (fuse || n < 1 || n > 3 || (ch_nbr >= 0 && n != ch_nbr)) {
-                        ch_ok = false;
-                        return HIFICAR_OK;
-                    }
-                    ch_nbr = n;
-                    for (int q = 0; q < n; ++q) {
-                        ch_lay[ch_n][q] = l1[q];
-                        ch_io[ch_n][q] = io1[q];
-                        ch_lay[ch_n + 1][q] = l2[q];
-                        ch_io[ch_n + 1][q] = io2[q];
-                    }
-                    ch_n += 2;
-                    for (int q = 0; q < n; ++q) cur_s[jn[q]] = lbl_out[q];
-                    continue;
                 }
                 if (fuse) {
                     for (int q0 = 0; q0 < n; q0 += 3)
@@ -1995,14 +1701,6 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                     if ((rc = tap_block(jn[q], d, xres[jn[q]])) != HIFICAR_OK) return rc;
                 for (int q = 0; q < n; ++q) cur_s[jn[q]] = fuse ? pair_out[q] : lbl_out[q];
             }
-            return HIFICAR_OK;
-            };
-            bool chained = false;
-            if (ch_ok && h->use_chain) {
-                if ((rc = run_layers(true)) != HIFICAR_OK) return rc;
-                if (ch_ok && ch_n >= 2 && (rc = launch_chain(h, ch_lay, ch_io, ch_n, ch_nbr, B, rows, cfg.lrelu_slope, rg, stream, &chained)) != HIFICAR_OK) return rc;
-            }
-            if (!chained && (rc = run_layers(false)) != HIFICAR_OK) return rc;
         }
     }
     if (cfg.use_ph_loss && cond.ph_out) {  // phoneme-loss head on the last stage's MRF mean (hifigan.py:232-237)
@@ -2036,11 +1734,6 @@ static int check_ready(hificar_handle* h, int B, int T, void* ws, size_t ws_byte
     if (!h) return fail(HIFICAR_E_INVALID, "null handle");
     if (!h->finalized) return fail(HIFICAR_E_STATE, "hificar_finalize has not been called");
     if (B < 1 || T < 1) return fail(HIFICAR_E_INVALID, "B=%d, T=%d must be positive", B, T);
-    if (h->chain_err && *h->chain_err) {  // (written by the device: a chained launch of an earlier call gave up waiting for a producer tile)
-        *h->chain_err = 0;
-        return fail(HIFICAR_E_HIP, "an earlier chained conv launch timed out waiting for another workgroup's tile (two chained launches competing for the "
-                    "CUs?); its output is invalid.  HIFICAR_CHAIN=0 runs one launch per layer");
-    }
     const size_t need = hificar_workspace_bytes(h, B, T);
     if (!ws || ws_bytes < need) return fail(HIFICAR_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
     if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) return fail(HIFICAR_E_INVALID, "workspace must be 256-byte aligned");

@@ -996,7 +996,6 @@ __global__ __launch_bounds__(256) void ph_head_bwd_kernel(const PhHeadBwdParams 
                 if (p.nin == 2) v = (v + p.x1[off]) / 2.0f;
                 else if (p.nin == 3) v = ((v + p.x1[off]) + p.x2[off]) / 3.0f;
                 else if (p.nin == 4) v = (((v + p.x1[off]) + p.x2[off]) + p.x3[off]) / 4.0f;
-    else if (p.nin == 4) v = (((v + p.x1[off]) + p.x2[off]) + p.x3[off]) / 4.0f;
                 s += v;
             }
         part[rs][c0 + ch] = s;

@@ -467,7 +467,10 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
 
     # copy.deepcopy / pickle build a module without running __init__ (see _NativeGenerator): the engine handle, the cached tapes / parameter
     # lists / side stream and the gradient-sync wiring stay behind; the copy registers with the optimizer post-step hook itself
-    _EPHEMERAL = ("_handle", "_lib", "_grad_sync", "_info_cache", "_sent_sig", "_real_cache", "_early_real", "_gside_done", "_raw_cache", "_early_stream")
+    # per-process state a copy must not carry: native handles, ctypes arrays (``_raw_cnames``: c_char_p arrays cannot be pickled), the held copy of the
+    # parameters last sent to the device (``_sent_held``: a second 70 M floats), cached passes / streams / events
+    _EPHEMERAL = ("_handle", "_lib", "_grad_sync", "_info_cache", "_sent_sig", "_sent_held", "_raw_cnames", "_real_cache", "_early_real", "_gside_done",
+                  "_raw_cache", "_early_stream")
 
     def __getstate__(self):
         state = self.__dict__.copy()

@@ -769,6 +769,12 @@ class HiFiGANGenerator(_NativeGenerator):
         # the reference builds getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params) (hifigan.py:121-123, 142-143).  The kernels'
         # activation is max(x, slope * x) with 0 <= slope <= 1: LeakyReLU, and with it ReLU (slope 0) and Identity (slope 1); other modules are not built
         nonlinear_activation_params = dict(nonlinear_activation_params or {})
+        if nonlinear_activation_params.get("inplace"):
+            # in the reference an in-place activation CHANGES the result: convs1[idx](x) activates x itself, so the residual `xt + x` adds the
+            # activated x and the first block's activation overwrites the `c` every block of a stage shares (residual_block.py:217-221,
+            # hifigan.py:226-230).  That arithmetic is not built: refuse instead of silently computing the out-of-place network.
+            raise NotImplementedError("nonlinear_activation_params['inplace']=True changes the reference's result (the residual adds the activated "
+                                      "input); only inplace=False (or no such key) is built")
         if nonlinear_activation == "ReLU":
             if set(nonlinear_activation_params) - {"inplace"}:
                 raise ValueError(f"ReLU takes no parameters besides inplace: {nonlinear_activation_params}")

@@ -55,45 +55,55 @@ DTYPE_NAME = {"f32": "fp32", "bf16x3": "bf16x3"}
 MFMA_PER_MAC = {"f32": 1, "bf16x3": 3}             # bf16x3 issues 3 bf16 MFMAs per algorithmic MAC
 
 
-def cpu_baseline(params, sd, chunk_frames, seed):
-    """CPU oracle (torch fp32 restatement, pinned to the reference's golden vectors) on a bounded sample.
-
-    The reference recipe runs single-threaded (egs/ema/voc1/path.sh:13, OMP_NUM_THREADS=1); torch's intra-op
-    parallelism helps these small convolutions only up to a point (using every core of a big host is ~10x SLOWER
-    than 16 threads), so a few thread counts are timed on a small sample and the best one is re-timed on a larger one.
-    """
+def cpu_baseline(params, sd, chunk_frames, feats8):
+    """CPU oracle (torch fp32 restatement, pinned to the reference's golden vectors) next to `value`, as SURVEY.md §8(d) specifies it:
+    on the FIRST 8 UTTERANCES of the very batch `value` was measured on (8 x 2000 frames = 10-s clips, the same features), timed
+      threads_1      torch.set_num_threads(1) — the recipe default (egs/ema/voc1/path.sh:13, OMP_NUM_THREADS=1), batched (B = 8)
+      threads_best   the best of a few thread counts (chosen on a small probe: every core of a big host is ~10x SLOWER than 16), batched
+      per_utterance  the B = 1 loop of egs/ema/voc1/local/predict_wav.py:124-137 — one utterance after the other — with 1 thread (first two
+                     utterances) and with the best thread count (all eight)
+    `value` / `cores` are the threads_best figure.  About 30 s of CPU work on the GPU box's host."""
     import torch
 
-    from articulatory_amd.utils.synth import synth_features
     from oracle import hificar_oracle as O
 
     all_cores = torch.get_num_threads()
     w = O.fold_weight_norm(sd)
+    x8 = feats8.permute(0, 2, 1).contiguous()  # (8, T, 13): the oracle's (B, T, C) layout
+    T = x8.shape[1]
 
-    def run(B, T, threads):
+    def run(x, threads, per_utterance=False):
         torch.set_num_threads(threads)
-        x = torch.from_numpy(synth_features(B, T, 13, seed=seed))
         with torch.no_grad():
-            O.ar_loop_batched(w, params, x[:, :chunk_frames], chunk_frames * HOP, HOP)  # warm-up: one chunk
+            O.ar_loop_batched(w, params, x[:1, :chunk_frames], chunk_frames * HOP, HOP)  # warm-up: one chunk
             t0 = time.perf_counter()
-            y = O.ar_loop_batched(w, params, x, chunk_frames * HOP, HOP)
+            n = 0
+            if per_utterance:
+                for i in range(x.shape[0]):
+                    n += O.ar_loop_batched(w, params, x[i:i + 1], chunk_frames * HOP, HOP).numel()
+            else:
+                n = O.ar_loop_batched(w, params, x, chunk_frames * HOP, HOP).numel()
             dt = time.perf_counter() - t0
-        return y.numel() / dt, dt
+        return {"samples_per_s": round(n / dt, 1), "seconds": round(dt, 2), "utterances": int(x.shape[0]), "threads": threads}
 
-    by_threads = {}
+    probe = {}
     for nt in sorted({1, 8, 16, 32, all_cores}):
         if nt <= all_cores:
-            by_threads[nt] = run(8, 5 * chunk_frames, nt)[0]
-    best = max(by_threads, key=by_threads.get)
-    B, T = 64, 60 * chunk_frames  # 64 utterances x 7.5 s = 60 chunks of 25 frames each (~15 s of CPU work)
-    value, dt = run(B, T, best)
+            probe[nt] = run(x8[:, :5 * chunk_frames], nt)["samples_per_s"]
+    best = max(probe, key=probe.get)
+    t_best = run(x8, best)
+    t_one = run(x8, 1)
+    pu_one = run(x8[:2], 1, per_utterance=True)
+    pu_best = run(x8, best, per_utterance=True)
     torch.set_num_threads(all_cores)
     return {
-        "value": round(value, 1), "unit": "samples/s", "cores": best, "kind": "port",
-        "sample": f"oracle.ar_loop_batched, batch {B} x {T} frames ({T // chunk_frames} chunks of {chunk_frames}), "
-                  f"torch {torch.__version__} CPU fp32, best of the thread counts tried = {best} of {all_cores} host threads, {dt:.1f} s",
-        # (a DIFFERENT, smaller sample than `value`: the thread-count probe, batch 8 x 5 chunks — only there to choose `cores`)
-        "by_threads_probe": {"sample": f"batch 8 x {5 * chunk_frames} frames", "samples_per_s": {str(k): round(v, 1) for k, v in by_threads.items()}},
+        "value": t_best["samples_per_s"], "unit": "samples/s", "cores": best, "kind": "port",
+        "sample": f"oracle.ar_loop_batched on the first 8 utterances of the batch `value` ran on: 8 x {T} frames ({T // chunk_frames} chunks of "
+                  f"{chunk_frames}), torch {torch.__version__} CPU fp32, {all_cores} host threads available",
+        "threads_1": t_one, "threads_best": t_best,
+        "per_utterance": {"note": "B = 1, one utterance after the other (predict_wav.py:124-137)", "threads_1": pu_one, "threads_best": pu_best},
+        # (a smaller sample: only there to choose `cores`)
+        "by_threads_probe": {"sample": f"batch 8 x {5 * chunk_frames} frames", "samples_per_s": {str(k): v for k, v in probe.items()}},
     }
 
 
@@ -104,7 +114,7 @@ def make_step(synth, feats, use_dist, world, gather="f32", pcm16=None):
     import torch
     import torch.distributed as dist
 
-    state = {"gathered": None}
+    state = {"gathered": None, "gather_events": [], "gather_s": []}
 
     def step():
         y = synth(feats)
@@ -113,10 +123,23 @@ def make_step(synth, feats, use_dist, world, gather="f32", pcm16=None):
             if state["gathered"] is None:
                 state["gathered"] = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
             out = state["gathered"]
+            # the collective's own time, so that a scaling run separates synthesis from collection: device events on the GPU (the all-gather is
+            # enqueued on the current stream's RCCL work queue), the host clock under gloo
+            on_gpu = send.is_cuda
+            if on_gpu:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            else:
+                t0 = time.perf_counter()
             if send.dtype == torch.int16:
                 dist.all_gather_into_tensor(out.view(torch.uint8), send.contiguous().view(torch.uint8))
             else:
                 dist.all_gather_into_tensor(out, send.contiguous())
+            if on_gpu:
+                e1.record()
+                state["gather_events"].append((e0, e1))
+            else:
+                state["gather_s"].append(time.perf_counter() - t0)
         return y
 
     return step, state
@@ -141,6 +164,12 @@ def timed_steps(step, fence, steps, warmup, use_dist=False, device=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, y
+
+
+def collected_at(traffic_table, table_key):
+    """where and when the PMC table's entry was collected: tools/summarize_profiles.py stamps every leg it rewrites"""
+    c = ((traffic_table or {}).get("_collected") or {}).get(table_key)
+    return f"collected at commit {c['commit']} on {c['date']}, profile tag {c['tag']}" if c else "collection commit not recorded"
 
 
 def roofline_block(stats, precision, wall_s, steps, traffic_table, strict=False, table_key=None):
@@ -179,8 +208,8 @@ def roofline_block(stats, precision, wall_s, steps, traffic_table, strict=False,
         "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
         "frac": round((tflops / peak_tf) if bound == "mfma" else (gbs / PEAK_HBM_GBS), 4),
         "traffic": traffic,
-        "traffic_source": f"profiles/hbm_traffic.json[{table_key}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, per launch)" if traffic else
-                          ("STALE TABLE: no entry for this kernel" if have_table else None),
+        "traffic_source": (f"profiles/hbm_traffic.json[{table_key}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, per launch; "
+                           f"{collected_at(traffic_table, table_key)})") if traffic else ("STALE TABLE: no entry for this kernel" if have_table else None),
         "algorithmic_bytes": round(alg_bytes),
         "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
         "flops_per_byte": round(intensity, 1), "machine_balance_flops_per_byte": round(balance, 1),
@@ -276,12 +305,8 @@ def training_leg(steps=5, traffic_table=None):
     # pass's backward) on side streams, where an event-bracketed launch's duration is an occupancy artefact; a second Trainer with every engine on
     # the caller's stream (HIFICAR_DISC_STREAMS=0, no side-stream overlap in the step) gives launch times that ARE a fraction of something
     del t
-    # ... with the tile shapes of the overlapped run (the engine picks them by workgroup-time when its launches overlap: HIFICAR_DISC_PICK /
-    # HIFICAR_MI1_PENALTY pin those rules here, otherwise the serial engine would choose — and this table would describe — different kernels)
-    # (a user-set HIFICAR_DISC_PICK / HIFICAR_MI1_PENALTY — documented A/B knobs — also shaped the timed run above: keep it, and put every
-    # variable back afterwards)
-    serial_env = {"HIFICAR_DISC_STREAMS": "0", "HIFICAR_DISC_PICK": os.environ.get("HIFICAR_DISC_PICK", "64"),
-                  "HIFICAR_MI1_PENALTY": os.environ.get("HIFICAR_MI1_PENALTY", "1.3")}
+    # (the engine keeps the tile shapes of the overlapped run in that mode, so this table describes the kernels the timed iterations ran)
+    serial_env = {"HIFICAR_DISC_STREAMS": "0"}
     saved_env = {k: os.environ.get(k) for k in serial_env}
     os.environ.update(serial_env)  # (read when the discriminators' native handle is created: at the first forward)
     try:
@@ -342,8 +367,8 @@ def training_leg(steps=5, traffic_table=None):
             "flops_per_iteration": flops, "flops_breakdown": breakdown,
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["f32"], 4),
                          "traffic": table.get(dom["name"]),
-                         "traffic_source": "profiles/hbm_traffic.json[train_gan] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tools/gan_bench.py with "
-                                           "HIFICAR_DISC_STREAMS=0, average per launch of the kernel name)" if table else None,
+                         "traffic_source": ("profiles/hbm_traffic.json[train_gan] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tools/gan_bench.py with "
+                                            f"HIFICAR_DISC_STREAMS=0, average per launch of the kernel name; {collected_at(traffic_table, 'train_gan')})") if table else None,
                          "dominant_kernel": row(dom),
                          "note": "achieved / frac: the whole iteration (overlapped, as timed); dominant_kernel and `kernels`: a serial pass "
                                  "(every engine on one stream), so each row's tflops is that kernel's own rate"},
@@ -377,10 +402,15 @@ def self_launch(gpus, argv):
 
 def _standin_factory():
     """Test hook: HIFICAR_BENCH_STANDIN="path/to/file.py:function" names a stand-in synthesis factory, so that a CPU / gloo test can call
-    `python bench.py --gpus 2` exactly as the driver does (tests/test_distributed_gloo.py).  Never set on a GPU box."""
+    `python bench.py --gpus 2` exactly as the driver does (tests/test_distributed_gloo.py).  REFUSED when a GPU is visible, and a stand-in
+    line says so (`"standin": true`, `dtype: "none"`, its own `metric` string): it can never pass for a measurement."""
     spec = os.environ.get("HIFICAR_BENCH_STANDIN")
     if not spec:
         return None
+    import torch
+
+    if torch.cuda.is_available():
+        raise SystemExit("bench.py: HIFICAR_BENCH_STANDIN is a CPU test hook and a GPU is visible: unset it (a stand-in line is not a measurement)")
     import importlib.util
 
     path, fn = spec.rsplit(":", 1)
@@ -492,6 +522,12 @@ def main(argv=None, synth_factory=None):
 
     with torch.no_grad():
         dt, y = timed_steps(step, fence, args.steps, args.warmup, use_dist, dev)
+    gather_ms = None
+    if use_dist:  # the timed steps' collectives (the warm-up steps' come first in the lists)
+        if gstate["gather_events"]:
+            gather_ms = sum(e0.elapsed_time(e1) for e0, e1 in gstate["gather_events"][-args.steps:]) / args.steps
+        elif gstate["gather_s"]:
+            gather_ms = sum(gstate["gather_s"][-args.steps:]) / args.steps * 1e3
     if use_dist:
         # the gathered block of this rank must be its own waveform (collection only, no arithmetic)
         mine = gstate["gathered"][rank * B:(rank + 1) * B]
@@ -534,7 +570,17 @@ def main(argv=None, synth_factory=None):
         "x_realtime": round(value / SAMPLING_RATE, 1),
         "algorithmic_tflops": round(2.0 * macs_step * world * args.steps / dt / 1e12, 2),
     }
+    if use_dist:
+        # rank 0's average time inside the waveform all-gather per step (device events under RCCL): ms_per_step - gather_ms is synthesis
+        out["gather_ms"] = None if gather_ms is None else round(gather_ms, 3)
+        out["gather_bytes_per_rank"] = int(n_samples * (2 if args.gather == "pcm16" else 4))
     if not on_gpu:
+        # a stand-in synthesis ran (HIFICAR_BENCH_STANDIN / the synth_factory test hook): plumbing only, and the line says so
+        out["standin"] = True
+        out["metric"] = "STAND-IN (no synthesis ran): launcher / rendezvous / gather plumbing of bench.py on CPU"
+        out["dtype"] = "none"
+        out["config"]["arithmetic"] = "none (stand-in synthesis function)"
+        out["config"]["weights"] = "none"
         if rank == 0:
             print(json.dumps(out), flush=True)
         if use_dist:
@@ -664,7 +710,7 @@ def main(argv=None, synth_factory=None):
         out["training"] = training_leg(traffic_table=traffic_table)
 
     if solo and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(params, sd, args.chunk_frames, seed=20260929)
+        out["cpu_baseline"] = cpu_baseline(params, sd, args.chunk_frames, feats[:8].cpu())
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -28,5 +28,25 @@ def factory(params, sd, args):
     return synth, pcm16
 
 
+def factory_light(params, sd, args):
+    """plumbing only (the 8-rank CPU tests): a cheap deterministic function of the features instead of the oracle"""
+    torch.set_num_threads(1)
+
+    def synth(x):  # (B, C, T) -> (B, hop*T)
+        return torch.tanh(x.mean(1)).repeat_interleave(bench.HOP, dim=1).contiguous()
+
+    def pcm16(y):
+        return torch.clamp(torch.round(y.double() * 32767.0), -32768, 32767).to(torch.int16)
+
+    return synth, pcm16
+
+
+def factory_rank5_dies(params, sd, args):
+    """one of eight ranks fails before its first step: the launcher must exit non-zero, no JSON line, no hang"""
+    if int(os.environ.get("RANK", "0")) == 5:
+        raise RuntimeError("rank 5 dies (test)")
+    return factory_light(params, sd, args)
+
+
 if __name__ == "__main__":
     bench.main(synth_factory=factory)

@@ -130,6 +130,105 @@ def test_bench_self_launches_its_ranks_like_the_driver_calls_it():
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["parallelism"] == "utterance-sharded x2" and d["config"]["gather"] == "f32"
     assert abs(d["value"] - 2 * 2 * 50 * 80 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+    # a stand-in line can never pass for a measurement: it is marked, names no arithmetic, and carries its own metric string
+    assert d["standin"] is True and d["dtype"] == "none" and d["metric"].startswith("STAND-IN") and "HiFi-CAR" not in d["metric"]
+    assert d["config"]["arithmetic"].startswith("none") and "roofline" not in d and "cpu_baseline" not in d
+    # the collective's own time is in the N > 1 line (the first real SCALE run separates synthesis from collection with it)
+    assert 0.0 <= d["gather_ms"] <= d["ms_per_step"] and d["gather_bytes_per_rank"] == 2 * 50 * 80 * 4
+
+
+def _bench_env(repo, factory):
+    env = dict(os.environ, HIFICAR_BENCH_STANDIN=os.path.join(repo, "tests", "dev", "bench_gloo_worker.py") + ":" + factory)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_gpus_8_as_the_driver_launches_it():
+    """`python bench.py --gpus 8` exactly as the driver's SCALE run calls it, on CPU / gloo with a stand-in synthesis: the launcher picks a free
+    port and bounds OMP_NUM_THREADS per rank, eight ranks rendezvous on 127.0.0.1, each pins itself to its own eighth of the cores, ONE JSON line
+    comes back with the whole-job aggregate over the max-over-ranks time, the eight-way all-gather checks itself, `gather_ms` is there."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2", "--seconds", "0.25"],
+                       capture_output=True, text=True, timeout=900, env=_bench_env(repo, "factory_light"), cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["standin"] is True
+    assert d["config"]["parallelism"] == "utterance-sharded x8"
+    assert abs(d["value"] - 8 * 2 * 50 * 80 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+    assert d["gather_ms"] is not None and 0.0 <= d["gather_ms"] <= d["ms_per_step"]
+    aff = d["config"]["host_affinity"]
+    if aff is not None and hasattr(os, "sched_getaffinity") and len(os.sched_getaffinity(0)) >= 8:
+        n = len(os.sched_getaffinity(0))
+        assert f"({n // 8} of {n})" in aff  # rank 0's own eighth of the cores
+
+
+def test_bench_gpus_8_propagates_a_failing_rank():
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "1", "--warmup", "0", "--batch", "1", "--seconds", "0.25"],
+                       capture_output=True, text=True, timeout=900, env=_bench_env(repo, "factory_rank5_dies"), cwd=repo)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_refuses_a_stand_in_when_a_gpu_is_visible(monkeypatch):
+    """HIFICAR_BENCH_STANDIN on a box with a GPU must stop bench.py, not produce a line."""
+    import bench
+
+    monkeypatch.setenv("HIFICAR_BENCH_STANDIN", "/nonexistent.py:f")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    with pytest.raises(SystemExit, match="HIFICAR_BENCH_STANDIN"):
+        bench._standin_factory()
+
+
+def test_decode_cli_shards_over_8_ranks_under_torchrun(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 8 articulatory_amd/bin/decode.py ... --dry-run`: every rank takes its own share of the
+    utterance list (lengths from the .npy headers, longest first to the least-loaded rank), the shares are disjoint, cover the list, and are
+    balanced in frames — the file-to-file decode needs no collective at all."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    import numpy as np
+    import yaml
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(0)
+    lens = [int(v) for v in rng.integers(260, 900, size=37)]
+    scp = tmp_path / "feats.scp"
+    with open(scp, "w") as f:
+        for i, n in enumerate(lens):
+            np.save(tmp_path / f"u{i:02d}.npy", np.zeros((n, 13)))
+            f.write(f"u{i:02d} {tmp_path / f'u{i:02d}.npy'}\n")
+    cfg = tmp_path / "config.yml"
+    cfg.write_text(yaml.safe_dump({"format": "npy", "generator_type": "HiFiGANGenerator", "generator_params": {}}))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port",
+                        str(port), os.path.join(repo, "articulatory_amd", "bin", "decode.py"), "--feats-scp", str(scp), "--outdir", str(tmp_path / "out"),
+                        "--checkpoint", str(tmp_path / "ckpt.pkl"), "--config", str(cfg), "--verbose", "0", "--dry-run"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    shares = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert sorted(s["rank"] for s in shares) == list(range(8)) and all(s["world_size"] == 8 and s["local_rank"] == s["rank"] for s in shares)
+    got = sorted(u for s in shares for u in s["utterances"])
+    assert got == [f"u{i:02d}" for i in range(37)]  # disjoint and complete
+    frames = [s["frames"] for s in shares]
+    assert sum(frames) == sum(lens) and max(frames) - min(frames) <= max(lens)
 
 
 def test_bench_self_launch_propagates_a_failing_rank():

@@ -696,71 +696,6 @@ def test_ar_loop_on_two_streams_equals_one_stream(monkeypatch, prec):
         assert torch.equal(g3.ar_synthesis(feats, 25), g4.ar_synthesis(feats, 25))
 
 
-def test_chained_stage_launches_are_bit_identical(monkeypatch):
-    """HIFICAR_CHAIN=1 (off by default: measured 1.8 % slower at batch 64, profiles/r05_chain_launch.txt): the layers of a chainable ResBlock stage as
-    ONE launch with per-tile hand-offs (conv_f32chain_kernel).  Same sums in the same order: every waveform equals the layer-by-layer launches' bit for
-    bit — a batch large enough for multi-tile lists, a ragged batch (tiles past a sequence's end still count), a long non-AR forward, repeated calls
-    (the counters are cumulative), and a profile that shows the chained kernel really ran."""
-    monkeypatch.setenv("HIFICAR_KSPLIT", "0")  # (dense launches at every size: the chained form is built on them)
-    monkeypatch.setenv("HIFICAR_AR_DUAL_MAX", "0")
-    g0, _ = make(dict(E2W_PARAMS), "f32")
-    g0._native_handle()  # (the library reads its switches when the handle is created: at the first use)
-    monkeypatch.setenv("HIFICAR_CHAIN", "1")
-    g1, _ = make(dict(E2W_PARAMS), "f32")
-    g1._native_handle()
-    x = torch.from_numpy(synth_features(24, 60, 13, seed=778)).permute(0, 2, 1).contiguous().cuda()
-    lens = torch.tensor([60 - 2 * (i % 17) for i in range(24)])
-    with torch.no_grad():
-        y0 = g0.ar_synthesis(x, 25)
-        g1.profile_begin()
-        y1 = g1.ar_synthesis(x, 25)
-        names = {s["name"].split("<")[0] for s in g1.profile_end()}
-        assert "conv_f32chain_kernel" in names
-        assert torch.equal(y0, y1) and torch.equal(y1, g1.ar_synthesis(x, 25))
-        assert torch.equal(g0.ar_synthesis(x, 25, lengths=lens), g1.ar_synthesis(x, 25, lengths=lens))
-    pn = dict(E2W_PARAMS, in_channels=12, use_ar=False)
-    monkeypatch.setenv("HIFICAR_CHAIN", "0")
-    n0, _ = make(pn, "f32")
-    n0._native_handle()
-    monkeypatch.setenv("HIFICAR_CHAIN", "1")
-    n1, _ = make(pn, "f32")
-    n1._native_handle()
-    xn = torch.from_numpy(synth_features(3, 700, 12, seed=779)).permute(0, 2, 1).contiguous().cuda()
-    with torch.no_grad():
-        assert torch.equal(n0(xn), n1(xn))
-        assert torch.equal(n0(xn, lengths=torch.tensor([700, 333, 90])), n1(xn, lengths=torch.tensor([700, 333, 90])))
-
-
-def test_convs1_staging_the_fp32_stream_is_bit_identical(monkeypatch):
-    """HIFICAR_ACT_READ=1 (off by default: same speed at batch 64, 1.5 % slower at batch 1 / 8, profiles/r05_epilogue_layouts.txt): in inference the convs1 of
-    a layer-by-layer stage read the fp32 residual stream and the loader waves apply LeakyReLU while staging it (ConvParams::act_in), so no producer writes an
-    activated copy.  The same values reach the same MFMAs: every waveform equals the default path's bit for bit — AR loop incl. a ragged batch, a long
-    non-AR forward, and a wide batch whose stages take the dense multi-tile launches."""
-    monkeypatch.setenv("HIFICAR_ACT_READ", "0")
-    g0, _ = make(dict(E2W_PARAMS), "f32")
-    g0._native_handle()  # (the library reads its switches when the handle is created: at the first use)
-    monkeypatch.setenv("HIFICAR_ACT_READ", "1")
-    g1, _ = make(dict(E2W_PARAMS), "f32")
-    g1._native_handle()
-    x = torch.from_numpy(synth_features(24, 60, 13, seed=780)).permute(0, 2, 1).contiguous().cuda()
-    lens = torch.tensor([60 - 2 * (i % 17) for i in range(24)])
-    with torch.no_grad():
-        y0 = g0.ar_synthesis(x, 25)
-        assert torch.equal(y0, g1.ar_synthesis(x, 25))
-        assert torch.equal(g0.ar_synthesis(x, 25, lengths=lens), g1.ar_synthesis(x, 25, lengths=lens))
-    pn = dict(E2W_PARAMS, in_channels=12, use_ar=False)
-    monkeypatch.setenv("HIFICAR_ACT_READ", "0")
-    n0, _ = make(pn, "f32")
-    n0._native_handle()
-    monkeypatch.setenv("HIFICAR_ACT_READ", "1")
-    n1, _ = make(pn, "f32")
-    n1._native_handle()
-    xn = torch.from_numpy(synth_features(3, 700, 12, seed=781)).permute(0, 2, 1).contiguous().cuda()
-    with torch.no_grad():
-        assert torch.equal(n0(xn), n1(xn))
-        assert torch.equal(n0(xn, lengths=torch.tensor([700, 333, 90])), n1(xn, lengths=torch.tensor([700, 333, 90])))
-
-
 def test_ragged_forward_non_ar(prec):
     """hificar_forward_ragged on the non-AR generator: per utterance identical to a forward of that utterance alone."""
     params = dict(E2W_PARAMS, in_channels=12, use_ar=False)

@@ -29,10 +29,10 @@ done
 rocprofv3 --kernel-trace --stats -f csv -d $out/prof_${tag}_train_stats -- python $root/tools/train_bench.py --steps 5 > $out/prof_${tag}_train_bench.txt 2> $out/prof_${tag}_train_stats.log
 rocprofv3 --kernel-trace --stats -f csv -d $out/prof_${tag}_gan_stats -- python $root/tools/gan_bench.py --steps 5 > $out/prof_${tag}_gan_bench.txt 2> $out/prof_${tag}_gan_stats.log
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -f csv -d $out/prof_${tag}_train_mfma -- python $root/tools/train_bench.py --steps 1 > /dev/null 2> $out/prof_${tag}_train_mfma.log
-HIFICAR_DISC_STREAMS=0 HIFICAR_DISC_PICK=64 HIFICAR_MI1_PENALTY=1.3 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -f csv -d $out/prof_${tag}_gan_mfma -- python $root/tools/gan_bench.py --steps 1 > /dev/null 2> $out/prof_${tag}_gan_mfma.log
+HIFICAR_DISC_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -f csv -d $out/prof_${tag}_gan_mfma -- python $root/tools/gan_bench.py --steps 1 > /dev/null 2> $out/prof_${tag}_gan_mfma.log
 # HBM traffic of the training kernels (round 4): the GAN iteration with the discriminators on the caller's stream (no overlap: per-launch counters;
-# HIFICAR_DISC_PICK / HIFICAR_MI1_PENALTY keep the tile shapes of the overlapped run)
+# the engine keeps the tile shapes of the overlapped run)
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  HIFICAR_DISC_STREAMS=0 HIFICAR_DISC_PICK=64 HIFICAR_MI1_PENALTY=1.3 rocprofv3 --pmc $ctr --kernel-trace -f csv -d $out/prof_${tag}_gan_$ctr -- python $root/tools/gan_bench.py --steps 1 > /dev/null 2> $out/prof_${tag}_gan_$ctr.log
+  HIFICAR_DISC_STREAMS=0 rocprofv3 --pmc $ctr --kernel-trace -f csv -d $out/prof_${tag}_gan_$ctr -- python $root/tools/gan_bench.py --steps 1 > /dev/null 2> $out/prof_${tag}_gan_$ctr.log
 done
 ls $out | grep prof_${tag}

@@ -1,7 +1,7 @@
 // Developer tool: launches the real bf16x3 wave-specialised conv kernel on a stage-shaped problem, times it and
 // dumps one workgroup's timeline (s_memtime stamps).  Not part of the product.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHIFICAR_TRACE tools/conv_bench.hip -o tools/conv_bench.bin
-#include "../articulatory_amd/csrc/hificar_kernels.hip.h"
+#include "r05_kernels/hificar_kernels_r05.hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

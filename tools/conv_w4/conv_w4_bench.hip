@@ -1,7 +1,7 @@
 // Dev tool (round 5): the four-wave conv kernel (conv_f32w4_kernel, csrc/hificar_conv_w4.hip.h) against the shipped direct-output kernel
 // (conv_f32do_kernel) on stage-shaped three-branch launches — same inputs, same LPT tile schedule; outputs compared BIT FOR BIT, both timed.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_w4/conv_w4_bench.hip -o tools/conv_w4/conv_w4_bench.bin
-#include "../../articulatory_amd/csrc/hificar_kernels.hip.h"
+#include "../r05_kernels/hificar_kernels_r05.hip.h"
 #include "hificar_conv_w4.hip.h"
 #include <algorithm>
 #include <cstdio>

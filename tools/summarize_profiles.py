@@ -43,6 +43,21 @@ try:
     allt = json.load(open("profiles/hbm_traffic.json"))
 except Exception:
     allt = {}
+import datetime
+import subprocess
+
+
+def stamp(key):
+    """which library the PMC passes of `key` ran on: the commit checked out when the profiles are summarised (+ "-dirty": uncommitted changes)"""
+    try:
+        head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--", "articulatory_amd", "bench.py", "tools"], capture_output=True, text=True).stdout.strip()
+        head += "-dirty" if dirty else ""
+    except Exception:
+        head = "unknown"
+    allt.setdefault("_collected", {})[key] = {"commit": head, "date": datetime.date.today().isoformat(), "tag": tag}
+
+
 # (file prefix / directory key, key in hbm_traffic.json, the profiled command): the two arithmetics of the headline leg, then the secondary legs
 LEGS = [("f32", "f32", "python bench.py --precision f32 --steps 3 --warmup 1 --no-cpu-baseline --no-fast-leg --no-batch-sweep --no-training --no-nonar --no-gblock"),
         ("bf16x3", "bf16x3", "python bench.py --precision bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-fast-leg --no-batch-sweep --no-training --no-nonar --no-gblock"),
@@ -76,6 +91,7 @@ for prec, tkey, cmd in LEGS:
                 f.write(f"\"{k}\",{n},{v / n:.1f},{v2 / max(n2, 1):.1f},{b:.0f}\n")
                 traffic[short(k)] = round(b)
     allt[tkey] = traffic
+    stamp(tkey)
     mf, dur = counters(base + "_mfma")
     with open(f"profiles/{tag}_{prec}_pmc_mfma.csv", "w") as f:
         f.write(f"# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace "
@@ -156,6 +172,7 @@ for what, cmd in (("train", "python tools/train_bench.py --steps 5"), ("gan", "p
             if "<" not in k:
                 train[k] = round(tot / n)
         allt["train_" + what] = train
+        stamp("train_" + what)
     txt = f"{base}_bench.txt"
     if os.path.exists(txt):
         lines = [ln for ln in open(txt).read().splitlines() if "ms" in ln and ("step" in ln or "iteration" in ln)]
