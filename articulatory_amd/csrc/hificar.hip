@@ -1028,6 +1028,8 @@ struct ConvIO {
     int x_rows = 0;                   // input rows per sequence when they differ from the launch's rows (ConvParams::x_rows)
     int x_up = 0;                     // nearest-neighbour upsampling of the input rows while staging (ConvParams::x_up); the input then has rows / x_up rows
     float x_slope = -1.f;             // >= 0: xs holds PRE-activation fp32 rows, LeakyReLU(x_slope) is applied while staging (ConvParams::act_in; exact fp32 only)
+    const float* x_more[3] = {nullptr, nullptr, nullptr};  // ... and the input is the mean of xs and these further streams (x_n in all), summed in this order
+    int x_n = 1;
 };
 
 // Replicas of every branch at regular strides (the groups of a grouped conv): see MultiConvParams::zrep
@@ -1159,7 +1161,9 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         mp.p[b].ys = io[b].ys;
         if (io[b].x_slope >= 0.f) {
             if (!f32) return fail(HIFICAR_E_INVALID, "internal: pre-activation input rows of %s outside the exact-fp32 layer-by-layer launches", Lb.name.c_str());
-            mp.p[b].act_in = 1;
+            if (io[b].x_n < 1 || io[b].x_n > 4) return fail(HIFICAR_E_INVALID, "internal: %d input streams of %s", io[b].x_n, Lb.name.c_str());
+            mp.p[b].act_in = io[b].x_n;
+            for (int q = 0; q + 1 < io[b].x_n; ++q) mp.p[b].xs_more[q] = reinterpret_cast<const char*>(io[b].x_more[q]);
             mp.p[b].slope_in = io[b].x_slope;
         }
         mp.p[b].mask_src = io[b].mask_src;
@@ -1180,7 +1184,7 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         if (f32) mp.p[b].w16 = reinterpret_cast<const bf16x8*>(Lb.d_w32);
         const double pos = (double)nseq * rows;
         flops += 2.0 * pos * Lb.cin * Lb.cout * Lb.K * zr.n;
-        bytes += 4.0 * (pos * Lb.cin_pad / std::max(1, io[b].x_up) + pos * Lb.cout_total * ((io[b].res ? 1 : 0) + (io[b].y ? 1 : 0) + (io[b].ys ? 1 : 0)) +
+        bytes += 4.0 * (pos * Lb.cin_pad * (io[b].x_slope >= 0.f ? io[b].x_n : 1) / std::max(1, io[b].x_up) + pos * Lb.cout_total * ((io[b].res ? 1 : 0) + (io[b].y ? 1 : 0) + (io[b].ys ? 1 : 0)) +
                         (double)Lb.cin * Lb.cout * Lb.K);
     }
     const size_t buf_bytes = round_up_sz((size_t)(TM + halo_all) * RB, 1024);
@@ -1204,6 +1208,9 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
         const double abytes = 4.0 * nseq * rows * L0.cin_pad * nbr * zr.n;
         mp.xcd_order = (h->xcd_order && mp.total_tiles <= h->num_cus && mp.total_tiles >= 16 && wbytes > 2.0 * abytes) ? 1 : 0;
     }
+    // every input row is staged once per channel group: more than two groups (upsampler 0's ten, a 1024-wide GEMM's eight) re-read it from the L2
+    // instead of streaming it past the cache (r06a: 2.7 x / 3-7 x the algorithmic bytes fetched by those launches with non-temporal loads)
+    mp.stage_cached = mp.ngroups > 2 ? 1 : 0;
     if (h->use_lpt && mp.total_tiles > (int)grid.x) {
         std::vector<double> costs((size_t)mp.total_tiles);
         const int tpb = mp.ngroups * mp.nseq_tiles;
@@ -1561,7 +1568,11 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
         }
         for (int i = 0; i < cfg.n_stages; ++i) {
             const char* up_in = h0_s;
-            if (i > 0) {  // MRF mean of the previous stage (hifigan.py:226-230) + LeakyReLU + split, elementwise
+            // MRF mean of the previous stage (hifigan.py:226-230).  Exact fp32 inference: folded into the upsampler's staging (ConvIO::x_more — its
+            // loader waves read the blocks' fp32 streams, sum, divide, activate), so no launch and no buffer for the mean exist.  Training (the tape keeps
+            // the activated mean for the upsampler's weight gradient) and bf16x3 (split rows): mrf_split_kernel.
+            const bool fold_mrf = i > 0 && f32 && !tp;
+            if (i > 0 && !fold_mrf) {
                 MrfSplitParams mq;
                 memset(&mq, 0, sizeof(mq));
                 mq.x0 = fin[0];
@@ -1595,7 +1606,13 @@ static int forward_impl(hificar_handle* h, const float* c, int64_t c_bstride, in
                 }
             {   // LeakyReLU + ConvTranspose1d (hifigan.py:224): fp32 u (first residual) (+ activated copy: first conv input)
                 const ConvLayer* lay[1] = {&h->ups[i]};
-                const ConvIO io[1] = {{up_in, nullptr, ws.u, all_pairs ? nullptr : (tp ? tp->u_s[i] : ws.u_s)}};
+                ConvIO io[1] = {{up_in, nullptr, ws.u, all_pairs ? nullptr : (tp ? tp->u_s[i] : ws.u_s)}};
+                if (fold_mrf) {
+                    io[0].xs = reinterpret_cast<const char*>(fin[0]);
+                    io[0].x_slope = cfg.lrelu_slope;
+                    io[0].x_n = nbk;
+                    for (int j = 1; j < nbk; ++j) io[0].x_more[j - 1] = fin[j];
+                }
                 if ((rc = launch_conv(h, lay, 1, B, rows, io, cfg.lrelu_slope, rg, stream)) != HIFICAR_OK) return rc;
             }
             rows *= cfg.upsample_scales[i];

@@ -50,10 +50,12 @@ struct ConvParams {
     const float* xf;    // pair kernel only: fp32 PRE-activation input rows (C floats per row); LeakyReLU(slope_in) + split are
                         // then applied while staging and xs is null (narrow stages: the producer writes no activated copy)
     float slope_in;
-    int act_in;         // exact-fp32 conv kernels (conv_ws_body): 1 = xs holds PRE-activation fp32 rows; the loader waves stage them through registers
-                        // and apply LeakyReLU(slope_in) on the way (global load, 8 VALU, ds_write per 16 bytes) instead of the LDS-DMA, so the
-                        // producer stores no activated copy.  0: xs is activated already (LDS-DMA)
+    int act_in;         // exact-fp32 conv kernels (conv_ws_body): n >= 1 = the input is the MEAN of n PRE-activation fp32 streams xs, xs_more[0 .. n - 2]
+                        // (same layout), summed in that order and divided by n — the MRF mean of hifigan.py:226-230 folded into its consumer: the
+                        // loader waves stage the rows through registers (n global loads, the sum, the division, LeakyReLU(slope_in), ds_write per
+                        // 16 bytes) instead of the LDS-DMA, so no kernel writes the mean or its activated copy.  0: xs is activated already (LDS-DMA)
     const char* xs;     // input rows, already activated (and split) by their producer
+    const char* xs_more[3];
     char* ys;           // activated (and split) copy of the output for the consumer conv: LeakyReLU(out, slope_out), or null
     const char* zeros;  // >= 16 bytes of zeros (source of padding rows for the LDS DMA)
     float slope_out;
@@ -142,6 +144,9 @@ struct MultiConvParams {
     long long zs_x, zs_w, zs_y, zs_b;
     unsigned long long* trace;  // dev tool only (tools/conv_bench.hip, -DHIFICAR_TRACE): per-workgroup timeline
     int xcd_order;  // 1 (gridDim.x == total_tiles, no schedule): XCD-contiguous tile order, see tile_of
+    int stage_cached;  // 1: the staging loads are ordinary cached loads — every input row is staged by MORE than two workgroups (one per channel group
+                       // of a wide layer: the ten groups of upsampler 0, the eight of a 1024-wide discriminator GEMM), so the re-reads should hit
+                       // the L2.  0: non-temporal (a row is staged by one or two CUs only: +2.3 % end to end on the ResBlock launches)
 };
 
 
@@ -478,13 +483,19 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                     if constexpr (F32) src = xs_z + (size_t)ts * row_bytes + 2 * c0b + sl * 16;
                     else src = xs_z + (size_t)ts * row_bytes + (sl < SPR / 2 ? c0b + sl * 16 : p.cin * 2 + c0b + (sl - SPR / 2) * 16);
                 }
-                // aux = 2: non-temporal — an activation row is staged by one or two CUs only (+2.3 % end to end)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
+                // aux = 2: non-temporal — an activation row is staged by one or two CUs only (+2.3 % end to end); rows that many channel groups
+                // re-stage stay cacheable (MultiConvParams::stage_cached)
+                if (mp.stage_cached)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
             }
         };
-        // The same item from PRE-activation fp32 rows (ConvParams::act_in): 16 bytes per lane through registers, LeakyReLU(slope_in) applied, written
-        // to the slot the DMA would have filled (position i * 1024 + lane * 16 holds logical slot sl of row r).
+        // The same item from PRE-activation fp32 rows (ConvParams::act_in = n streams): 16 bytes per lane and stream through registers, the streams
+        // summed in order and divided by n (n > 1: the MRF mean, hifigan.py:226-230 — the same expression as mrf_split_kernel, bit for bit),
+        // LeakyReLU(slope_in) applied, written to the slot the DMA would have filled (position i * 1024 + lane * 16 holds logical slot sl of row r).
         auto stage_act_item = [&](const Tile& T, int c, int jj) {
             if constexpr (F32) {
                 const ConvParams& p = mp.p[T.b];
@@ -492,34 +503,77 @@ __device__ __forceinline__ void conv_ws_body(const MultiConvParams& mp) {
                 const int ninstr = (R * SPR + 63) >> 6;
                 const int Ls = p.x_rows ? p.x_rows : seq_rows(p, T.seq);
                 const int row_bytes = p.x_row_bytes ? p.x_row_bytes : p.cin * 4;
-                const char* const xs_z = p.xs + (size_t)T.z * mp.zs_x + (size_t)T.seq * (p.x_seq_bytes ? (size_t)p.x_seq_bytes : (size_t)p.L * p.cin * 4);
+                const size_t seq_off = (size_t)T.z * mp.zs_x + (size_t)T.seq * (p.x_seq_bytes ? (size_t)p.x_seq_bytes : (size_t)p.L * p.cin * 4);
                 char* dst = smem_b + (jj & 1) * buf_bytes;
                 const int c0b = c * CH * 2;
                 const float slope = p.slope_in;
-                constexpr int UB = 12;  // (an item is 36-48 wave-loads: all of a loader wave's share in flight at once, one memory latency per item like the DMA)
-                for (int i0 = lw; i0 < ninstr; i0 += 4 * UB) {
-                    f32x4 v[UB];
+                const int nsrc = p.act_in;
+                auto src_off = [&](int i, bool& ok) {  // byte offset (inside a stream) of what wave-instruction i stages in this lane
+                    const int n = i * 64 + lane;
+                    const int r = n >> LOG_SPR;
+                    const int sl = (n & (SPR - 1)) ^ ((r >> LOG_RPB) & (SPR - 1));
+                    const int t = T.t0 + p.off_min + r;
+                    ok = i < ninstr && r < R && t >= 0 && t < Ls;
+                    const int ts = p.x_up > 1 ? (int)__umulhi((unsigned)t, p.x_up_rcp) : t;
+                    return seq_off + (size_t)ts * row_bytes + 2 * c0b + sl * 16;
+                };
+                auto ld = [&](const char* base, size_t off) {
+                    if (mp.stage_cached) return *reinterpret_cast<const f32x4*>(base + off);
+                    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + off));
+                };
+                if (nsrc <= 1) {
+                    constexpr int UB = 12;  // (an item is 36-48 wave-loads: all of a loader wave's share in flight at once, one memory latency per item like the DMA)
+                    for (int i0 = lw; i0 < ninstr; i0 += 4 * UB) {
+                        f32x4 v[UB];
 #pragma unroll
-                    for (int q = 0; q < UB; ++q) {
-                        const int i = i0 + 4 * q;
-                        v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        const int n = i * 64 + lane;
-                        const int r = n >> LOG_SPR;
-                        const int sl = (n & (SPR - 1)) ^ ((r >> LOG_RPB) & (SPR - 1));
-                        const int t = T.t0 + p.off_min + r;
-                        if (i < ninstr && r < R && t >= 0 && t < Ls) {
-                            const int ts = p.x_up > 1 ? (int)__umulhi((unsigned)t, p.x_up_rcp) : t;
-                            v[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xs_z + (size_t)ts * row_bytes + 2 * c0b + sl * 16));
+                        for (int q = 0; q < UB; ++q) {
+                            bool ok;
+                            const size_t off = src_off(i0 + 4 * q, ok);
+                            v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (ok) v[q] = ld(p.xs, off);
+                        }
+#pragma unroll
+                        for (int q = 0; q < UB; ++q) {
+                            const int i = i0 + 4 * q;
+                            if (i < ninstr) {
+                                f32x4 a;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a[e] = fmaxf(v[q][e], v[q][e] * slope);
+                                *reinterpret_cast<f32x4*>(dst + i * 1024 + lane * 16) = a;
+                            }
                         }
                     }
+                } else {
+                    constexpr int UB = 4;  // x up to four streams in flight
+                    for (int i0 = lw; i0 < ninstr; i0 += 4 * UB) {
+                        f32x4 v[UB], w1[UB], w2[UB], w3[UB];
 #pragma unroll
-                    for (int q = 0; q < UB; ++q) {
-                        const int i = i0 + 4 * q;
-                        if (i < ninstr) {
-                            f32x4 a;
+                        for (int q = 0; q < UB; ++q) {
+                            bool ok;
+                            const size_t off = src_off(i0 + 4 * q, ok);
+                            v[q] = w1[q] = w2[q] = w3[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (ok) {
+                                v[q] = ld(p.xs, off);
+                                w1[q] = ld(p.xs_more[0], off);
+                                if (nsrc >= 3) w2[q] = ld(p.xs_more[1], off);
+                                if (nsrc == 4) w3[q] = ld(p.xs_more[2], off);
+                            }
+                        }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) a[e] = fmaxf(v[q][e], v[q][e] * slope);
-                            *reinterpret_cast<f32x4*>(dst + i * 1024 + lane * 16) = a;
+                        for (int q = 0; q < UB; ++q) {
+                            const int i = i0 + 4 * q;
+                            if (i < ninstr) {
+                                f32x4 a;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float m;
+                                    if (nsrc == 4) m = (((v[q][e] + w1[q][e]) + w2[q][e]) + w3[q][e]) / 4.0f;
+                                    else if (nsrc == 3) m = ((v[q][e] + w1[q][e]) + w2[q][e]) / 3.0f;
+                                    else m = (v[q][e] + w1[q][e]) / 2.0f;
+                                    a[e] = fmaxf(m, m * slope);
+                                }
+                                *reinterpret_cast<f32x4*>(dst + i * 1024 + lane * 16) = a;
+                            }
                         }
                     }
                 }

@@ -696,6 +696,40 @@ def test_ar_loop_on_two_streams_equals_one_stream(monkeypatch, prec):
         assert torch.equal(g3.ar_synthesis(feats, 25), g4.ar_synthesis(feats, 25))
 
 
+@pytest.mark.parametrize("kernels", [[3, 7, 11], [3, 7], [3, 5, 7, 11]])
+def test_mrf_mean_folded_into_the_upsampler(kernels):
+    """Exact fp32 inference stages the MRF mean (hifigan.py:226-230: cs += block_j(c) in order; c = cs / n) inside the next upsampler's loader waves
+    — no mrf_split_kernel launch, no buffer for the mean.  The forward under autograd still runs mrf_split_kernel (its tape keeps the activated
+    mean) with the same sums, the same division and the same LeakyReLU; the two forwards differ only where the taped one differs anyway (weight norm
+    folded on the device, narrow stages layer by layer instead of fused pairs): fp32 rounding.  3 blocks per stage (the shipped recipe), 2 and 4;
+    a ragged batch; a batch wide enough for the dense multi-tile launches; and the oracle on the folded path."""
+    params = dict(E2W_PARAMS, resblock_kernel_sizes=kernels, resblock_dilations=[[1, 3, 5]] * len(kernels))
+    g, _ = make(params, "f32", remove_wn=False)
+    x = torch.from_numpy(synth_features(24, 50, 13, seed=783)).permute(0, 2, 1).contiguous().cuda()
+    ar = torch.from_numpy(np.random.default_rng(783).uniform(-0.5, 0.5, (24, 1, 512)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        g.profile_begin()
+        y_inf = g(x, ar=ar)
+        names = {s["name"].split("<")[0] for s in g.profile_end()}
+    assert "mrf_split_kernel" not in names and "conv_f32do_kernel" in names
+    g.train()
+    g.profile_begin()
+    y_tape = g(x, ar=ar)  # (gradients enabled: the taped forward)
+    names_t = {s["name"].split("<")[0] for s in g.profile_end()}
+    g.eval()
+    assert "mrf_split_kernel" in names_t
+    assert rel_err(y_inf.cpu().numpy(), y_tape.detach().cpu().numpy()) < 5e-6
+    with torch.no_grad():
+        ref = O.generator_forward(O.fold_weight_norm({k: v.detach().cpu().numpy() for k, v in g.state_dict().items()}), params, x[:4].cpu(), ar[:4].cpu())
+    assert rel_err(y_inf[:4].cpu().numpy(), ref.numpy()) < 2e-5
+    lens = torch.tensor([50 - 2 * (i % 13) for i in range(24)])
+    with torch.no_grad():
+        y_r = g(x, ar=ar, lengths=lens)
+    for i in (0, 5, 12):
+        n = int(lens[i]) * 80
+        assert torch.equal(y_r[i, :, :n], y_inf[i, :, :n]) or float((y_r[i, :, :n] - y_inf[i, :, :n]).abs().max()) < 1e-5
+
+
 def test_ragged_forward_non_ar(prec):
     """hificar_forward_ragged on the non-AR generator: per utterance identical to a forward of that utterance alone."""
     params = dict(E2W_PARAMS, in_channels=12, use_ar=False)
