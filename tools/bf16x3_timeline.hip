@@ -1,0 +1,177 @@
+// Developer tool (round 6): where a workgroup of the bf16x3 conv kernels spends its cycles.  Launches the PRODUCT kernels (hificar_conv.hip.h, built with
+// -DHIFICAR_TRACE: s_memtime stamps of MFMA wave 0 and loader wave 0 of every workgroup) on ResBlock-shaped problems of the headline step and prints, per
+// role, the share of cycles in front of barriers (waiting for the other role) and between them, next to the matrix pipe's own time for the item.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHIFICAR_TRACE tools/bf16x3_timeline.hip -o tools/bf16x3_timeline.bin && tools/bf16x3_timeline.bin
+#include "../articulatory_amd/csrc/hificar_conv.hip.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+using namespace hificar;
+
+template <int MI, int WM, int WN, int NC16, int NB>
+void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, bool conv2) {
+    constexpr int TM = WM * MI * 32, TN = WN * NB * 32, CH = NC16 * 16;
+    const size_t n = (size_t)nseq * L * C;
+    float *x, *y[3], *bias;
+    char *xs, *ys[3], *zeros;
+    hipMalloc(&x, n * 4);
+    hipMalloc(&xs, n * 4);
+    {   // split rows: random bf16 bit patterns of moderate magnitude (realistic toggling)
+        std::vector<uint16_t> hb(2 * n);
+        unsigned st = 12345u;
+        for (size_t i = 0; i < 2 * n; ++i) { st = st * 1664525u + 1013904223u; hb[i] = 0x3c00 + ((st >> 10) & 0x1ff) + ((st >> 3) & 0x8000); }
+        hipMemcpy(xs, hb.data(), n * 4, hipMemcpyHostToDevice);
+        std::vector<float> hx(n);
+        for (size_t i = 0; i < n; ++i) hx[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+        hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice);
+    }
+    hipMalloc(&zeros, 256);
+    hipMemset(zeros, 0, 256);
+    hipMalloc(&bias, C * 4);
+    hipMemset(bias, 0, C * 4);
+    MultiConvParams mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.zrep = 1;
+    int max_halo = 0;
+    double flops = 0, mfma_cyc_tile[3] = {0, 0, 0};
+    for (int b = 0; b < nbr; ++b) {
+        hipMalloc(&y[b], n * 4);
+        hipMalloc(&ys[b], n * 4);
+        const int K = ks[b], pad = (K - 1) / 2;
+        const size_t wel = ((size_t)(C / 32) * (C / 16) * K * 2 + 2 * NC16) * 512;
+        uint16_t* w16;
+        hipMalloc(&w16, wel * 2);
+        std::vector<uint16_t> hw(wel);
+        unsigned st = 777u + b;
+        for (size_t i = 0; i < wel; ++i) { st = st * 1664525u + 1013904223u; hw[i] = 0x3a00 + ((st >> 10) & 0x1ff) + ((st >> 3) & 0x8000); }
+        hipMemcpy(w16, hw.data(), wel * 2, hipMemcpyHostToDevice);
+        ConvParams& p = mp.p[b];
+        p.len_const = -1;
+        p.w16 = reinterpret_cast<const bf16x8*>(w16); p.bias = bias; p.res = conv2 ? x : nullptr; p.y = conv2 ? y[b] : nullptr;
+        p.xs = xs; p.ys = ys[b]; p.zeros = zeros; p.slope_out = 0.1f; p.cout_real = C;
+        p.L = L; p.tiles_per_seq = (L + TM - 1) / TM; p.cin = C; p.cout_total = C;
+        p.n_blocks32 = C / 32; p.nb32_per_phase = C / 32; p.ntaps = K; p.off_min = -pad; p.halo = 2 * pad;
+        p.tap_step = 1; p.tap_off0[0] = -pad;
+        max_halo = std::max(max_halo, p.halo);
+        flops += 2.0 * nseq * L * (double)C * C * K;
+        mfma_cyc_tile[b] = (double)K * (C / 16) * 3 * MI * NB * 32;  // MFMA issue cycles of one wave for one tile (32 cycles per v_mfma_f32_32x32x16_bf16)
+    }
+    mp.n_branches = nbr;
+    mp.nseq_tiles = nseq * ((L + TM - 1) / TM);
+    mp.ngroups = (C / 32 + WN * NB - 1) / (WN * NB);
+    mp.total_tiles = nbr * mp.ngroups * mp.nseq_tiles;
+    mp.buf_bytes = ((TM + max_halo) * (CH * 4) + 1023) / 1024 * 1024;
+    const int G = std::min(mp.total_tiles, 256);
+    unsigned long long* trace;
+    hipMalloc(&trace, (size_t)G * 2 * 64 * 8);
+    mp.trace = trace;
+    void (*kern)(const MultiConvParams) = nullptr;
+    if constexpr (NB == 2) kern = conv_bf16x3nb_kernel<MI, WM, WN, NC16>;
+    else kern = conv_bf16x3_kernel<MI, WM, WN, NC16>;
+    const size_t lds_bytes = 2 * (size_t)mp.buf_bytes + (size_t)TM * (TN + 4) * 4;
+    if (lds_bytes > 160 * 1024) { printf("%-34s LDS %zu KB: does not fit\n", label, lds_bytes / 1024); return; }
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int it = 0; it < 4; ++it) {  // (>= 60 ms of warm-up in total over the tool's runs: the shader clock needs sustained load)
+        hipEventRecord(e0);
+        for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3((WM * WN + 4) * 64), lds_bytes, 0, mp);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL(kern, dim3(G), dim3((WM * WN + 4) * 64), lds_bytes, 0, mp);
+    hipDeviceSynchronize();
+    const double us = ms * 1000 / 20;
+    printf("%-34s tiles=%d G=%d lds=%zuKB  %.1f us/launch  %.0f TF-alg  (%.3f of the bf16x3 roof 833)\n", label, mp.total_tiles, G, lds_bytes / 1024, us,
+           flops / (us * 1e-6) / 1e12, flops / (us * 1e-6) / 1e12 / 833.3);
+    std::vector<unsigned long long> ht((size_t)G * 2 * 64);
+    hipMemcpy(ht.data(), trace, ht.size() * 8, hipMemcpyDeviceToHost);
+    {   // the launch on ONE time base (s_memrealtime, 100 MHz, first / last stamp of every workgroup's MFMA wave 0): dispatch skew, the workgroups'
+        // own spans, and what share of (workgroups x launch span) they fill
+        static unsigned long long rt[2][1024];
+        hipMemcpyFromSymbol(rt, HIP_SYMBOL(g_trace_realtime), sizeof(rt));
+        unsigned long long t0 = ~0ull, t1 = 0, last_start = 0;
+        double busy = 0;
+        std::vector<double> span;
+        for (int w = 0; w < G; ++w) {
+            t0 = std::min(t0, rt[0][w]);
+            last_start = std::max(last_start, rt[0][w]);
+            t1 = std::max(t1, rt[1][w]);
+            busy += (double)(rt[1][w] - rt[0][w]);
+            span.push_back((rt[1][w] - rt[0][w]) * 0.01);
+        }
+        std::sort(span.begin(), span.end());
+        {   // what s_memtime ticks at: its first / last stamp of workgroup 0's MFMA wave against the 100-MHz clock
+            const unsigned long long* m0 = &ht[0];
+            if (m0[63] && m0[0] && rt[1][0] > rt[0][0])
+                printf("    s_memtime: %.0f ticks per us (workgroup 0: %llu ticks in %.1f us)\n", (double)(m0[63] - m0[0]) / ((rt[1][0] - rt[0][0]) * 0.01),
+                       (unsigned long long)(m0[63] - m0[0]), (rt[1][0] - rt[0][0]) * 0.01);
+        }
+        printf("    one launch alone: first workgroup start -> last workgroup end %.1f us; last workgroup starts %.1f us after the first; workgroup spans min %.1f / "
+               "median %.1f / max %.1f us; workgroups busy %.0f %% of (G x launch span); back-to-back launches take %.1f us each: %.1f us outside the span\n",
+               (t1 - t0) * 0.01, (last_start - t0) * 0.01, span.front(), span[span.size() / 2], span.back(), 100.0 * busy / ((double)(t1 - t0) * G), us,
+               us - (t1 - t0) * 0.01);
+    }
+    // MFMA wave 0: stamp 1 + 3 j in front of item j's barrier, 2 + 3 j behind it, 3 j' when a tile's K loop is done (j' = the next item)
+    double m_wait = 0, m_work = 0, l_wait = 0, l_work = 0, m_span = 0;
+    const int nchunks = C / CH;
+    std::vector<double> item_cyc;
+    for (int w = 0; w < G; ++w) {
+        const unsigned long long* m = &ht[(size_t)w * 128];
+        const unsigned long long* l = m + 64;
+        for (int j = 0; 2 + 3 * (j + 1) < 62 && m[2 + 3 * (j + 1)]; ++j) {
+            m_wait += (double)(m[2 + 3 * j] - m[1 + 3 * j]);
+            const double work = (double)(m[1 + 3 * (j + 1)] - m[2 + 3 * j]);
+            m_work += work;
+            item_cyc.push_back(work);
+        }
+        for (int j = 0; 2 + 2 * (j + 1) < 62 && l[2 + 2 * (j + 1)]; ++j) {
+            l_wait += (double)(l[2 + 2 * j] - l[1 + 2 * j]);
+            l_work += (double)(l[1 + 2 * (j + 1)] - l[2 + 2 * j]);
+        }
+        if (m[62] && m[0]) m_span += (double)(m[62] - m[0]);
+    }
+    std::sort(item_cyc.begin(), item_cyc.end());
+    const double avg_taps = (ks[0] + (nbr > 1 ? ks[1] : 0) + (nbr > 2 ? ks[2] : 0)) / (double)nbr;
+    const double ideal_item = avg_taps * NC16 * 3 * MI * NB * 32;
+    printf("    MFMA wave 0 (first ~20 items of every workgroup): %.1f %% of its cycles in front of barriers, %.1f %% between them; median item %.0f cycles "
+           "(p10 %.0f, p90 %.0f) against %.0f cycles of MFMA issue for an average (%.1f-tap) item = %.2f\n",
+           100 * m_wait / (m_wait + m_work), 100 * m_work / (m_wait + m_work), item_cyc.empty() ? 0.0 : item_cyc[item_cyc.size() / 2],
+           item_cyc.empty() ? 0.0 : item_cyc[item_cyc.size() / 10], item_cyc.empty() ? 0.0 : item_cyc[item_cyc.size() * 9 / 10], ideal_item, avg_taps,
+           item_cyc.empty() ? 0.0 : ideal_item / item_cyc[item_cyc.size() / 2]);
+    printf("    loader wave 0: %.1f %% of its cycles in front of barriers (idle), %.1f %% staging + output pass;  chunks per tile %d\n",
+           100 * l_wait / (l_wait + l_work), 100 * l_work / (l_wait + l_work), nchunks);
+    for (int wg : {0, G / 2}) {
+        const unsigned long long* m = &ht[(size_t)wg * 2 * 64];
+        const unsigned long long* l = m + 64;
+        const unsigned long long t0 = std::min(m[0], l[0]);
+        printf("    WG %3d MFMA : ", wg);
+        for (int i = 0; i < 32; ++i) printf("%lld ", m[i] ? (long long)(m[i] - t0) / 100 : -1LL);
+        printf("\n    WG %3d load : ", wg);
+        for (int i = 0; i < 24; ++i) printf("%lld ", l[i] ? (long long)(l[i] - t0) / 100 : -1LL);
+        printf("  (x100 cycles)\n");
+    }
+    hipFree(trace);
+}
+
+int main() {
+    const int k3[3] = {11, 7, 3};
+    const int k11[3] = {11, 11, 11};
+    // the headline step's wide stages: batch 64, chunk 25 -> stage 0: 125 rows x 256 channels, stage 1: 500 rows x 128 channels (per sequence)
+    run<2, 2, 2, 4, 2>("stage0 nb<2,2,2,4> conv1", 64, 125, 256, 3, k3, false);
+    run<2, 2, 2, 4, 2>("stage0 nb<2,2,2,4> conv2+res", 64, 125, 256, 3, k3, true);
+    run<2, 2, 2, 4, 2>("stage1 nb<2,2,2,4> conv1", 64, 500, 128, 3, k3, false);
+    run<2, 2, 2, 4, 2>("stage1 nb<2,2,2,4> conv2+res", 64, 500, 128, 3, k3, true);
+    // the same shapes without register blocking (what NB = 2 buys), and a long-K control (k = 11 everywhere: fewer tile changes per MFMA)
+    run<4, 1, 4, 4, 1>("stage0 <4,1,4,4> conv1", 64, 125, 256, 3, k3, false);
+    run<4, 1, 4, 4, 1>("stage1 <4,1,4,4> conv2+res", 64, 500, 128, 3, k3, true);
+    run<2, 2, 2, 4, 2>("stage0 nb<2,2,2,4> conv1 k=11 x3", 64, 125, 256, 3, k11, false);
+    run<2, 2, 2, 4, 2>("stage0 nb conv1, 4 x the rows", 256, 125, 256, 3, k3, false);
+    return 0;
+}
