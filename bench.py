@@ -306,7 +306,8 @@ def training_leg(steps=5, traffic_table=None):
     # the caller's stream (HIFICAR_DISC_STREAMS=0, no side-stream overlap in the step) gives launch times that ARE a fraction of something
     del t
     # (the engine keeps the tile shapes of the overlapped run in that mode, so this table describes the kernels the timed iterations ran)
-    serial_env = {"HIFICAR_DISC_STREAMS": "0"}
+    # (HIFICAR_PROFILE_DETAIL: the serial pass's profile rows carry the layer, so the table below can be split by engine as well as by kernel name)
+    serial_env = {"HIFICAR_DISC_STREAMS": "0", "HIFICAR_PROFILE_DETAIL": "1"}
     saved_env = {k: os.environ.get(k) for k in serial_env}
     os.environ.update(serial_env)  # (read when the discriminators' native handle is created: at the first forward)
     try:
@@ -333,13 +334,32 @@ def training_leg(steps=5, traffic_table=None):
         serial_iteration()
     torch.cuda.synchronize()
     serial_dt = (time.perf_counter() - t1) / steps
-    stats = {}
+    import re
+
+    def group_of(base, layer):  # (the grouping of tools/pmc_by_layer.py, whose PMC totals sit in profiles/gan_traffic_by_group.json)
+        if layer.startswith(("blocks.", "upsamples.", "input_conv")):
+            return "generator convs (forward x2, data gradients)"
+        if "mpd." in layer:
+            return "period discriminators (convs, im2col / col2im)"
+        if "msd." in layer:
+            return "scale discriminators (convs, im2col / col2im)"
+        if base.startswith("wgrad"):
+            return "weight gradients"
+        return "other (reductions, packs, losses, element-wise)"
+
+    stats, groups = {}, {}
     for s in ts.G.profile_end() + ts.D.profile_end():
-        a = stats.setdefault(s["name"], dict(name=s["name"], launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
-        a["launches"] += s["launches"]
-        a["total_ms"] += s["total_ms"]
-        a["flops"] += s["flops"]
-        a["bytes"] += s["bytes"]
+        full = s["name"]
+        name = re.split(r"[| ]", full, maxsplit=1)[0]  # rows carry "kernel|layer xN" / "kernel shape ...": the per-name table strips that
+        layer = full.split("|", 1)[1] if "|" in full else ""
+        fam = re.sub(r"\d+_kernel$", "_kernel", name.split("<")[0]).replace("wreduce_gemm_kernel", "wreduce_kernel")
+        g = group_of(fam, layer)
+        for table, key in ((stats, name), (groups, g), (groups, fam + " @ " + g)):
+            a = table.setdefault(key, dict(name=key, launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += s["launches"]
+            a["total_ms"] += s["total_ms"]
+            a["flops"] += s["flops"]
+            a["bytes"] += s["bytes"]
     stats = sorted(stats.values(), key=lambda s: -s["total_ms"])
     total_ms = sum(s["total_ms"] for s in stats)
     dom = stats[0]
@@ -354,6 +374,24 @@ def training_leg(steps=5, traffic_table=None):
                 "ms_per_iteration": round(s["total_ms"] / steps, 3), "tflops": round(tfk, 2), "frac_of_fp32_mfma_peak": round(tfk / PEAK_TFLOPS["f32"], 4),
                 "kernel_time_share": round(s["total_ms"] / total_ms, 4), "algorithmic_bytes": round(alg), "traffic": tr,
                 "traffic_over_algorithmic": round(tr / alg, 3) if (tr and alg > 0) else None}
+
+    gtable = {}
+    gpath = os.path.join(REPO, "profiles", "gan_traffic_by_group.json")
+    if os.path.exists(gpath):
+        with open(gpath) as f:
+            gtable = json.load(f)
+
+    def group_row(gk):
+        s = groups[gk]
+        tfk = s["flops"] / (s["total_ms"] * 1e-3) / 1e12 if s["total_ms"] else 0.0
+        pm = gtable.get(gk) or {}
+        return {"group": gk, "launches_per_iteration": round(s["launches"] / steps, 1), "ms_per_iteration": round(s["total_ms"] / steps, 3),
+                "tflops": round(tfk, 2), "frac_of_fp32_mfma_peak": round(tfk / PEAK_TFLOPS["f32"], 4), "kernel_time_share": round(s["total_ms"] / total_ms, 4),
+                "algorithmic_MB_per_iteration": round(s["bytes"] / steps / 1e6, 1), "traffic_over_algorithmic": pm.get("traffic_over_algorithmic")}
+
+    dom_gen = dom["name"].split("<")[0] + " @ generator convs (forward x2, data gradients)"
+    by_group = [group_row(k) for k in sorted((k for k in groups if " @ " not in k), key=lambda k: -groups[k]["total_ms"])]
+    dom_split = [group_row(k) for k in sorted((k for k in groups if k.startswith(dom["name"].split("<")[0] + " @ ")), key=lambda k: -groups[k]["total_ms"])]
 
     return {"note": "BASELINE config 5's recipe on ONE GPU, exact fp32 (the reference has no bf16 path); losses gated against the reference's "
                     "own _train_step fixture before timing",
@@ -375,6 +413,12 @@ def training_leg(steps=5, traffic_table=None):
             "serial_iteration_ms": round(serial_dt * 1e3, 2),
             "kernel_ms_per_iteration_sum": round(total_ms / steps, 2),
             "kernels": [row(s) for s in stats[:14]],
+            # the same serial pass split by ENGINE (layer names from HIFICAR_PROFILE_DETAIL): one kernel name covers the generator's ResBlock launches and
+            # the discriminators' GEMM-form launches, whose rates and traffic differ by 2-3 x; traffic_over_algorithmic per group from the per-launch-shape
+            # PMC join (tools/pmc_by_layer.py -> profiles/gan_traffic_by_group.json, profiles/r06_gan_pmc_hbm_by_layer.csv)
+            "by_group": by_group,
+            "dominant_kernel_family_by_group": dom_split,
+            "dominant_kernel_on_generator_layers": group_row(dom_gen) if dom_gen in groups else None,
             "first_losses": {k.split("/")[1]: float(v) for k, v in sorted(log.items())}}
 
 

@@ -40,6 +40,20 @@ def family(name):
     return base.replace("wreduce_gemm_kernel", "wreduce_kernel")
 
 
+def group_of(kernel, layer):
+    """the engine / role a launch belongs to (bench.py's training leg aggregates its live event pass the same way)"""
+    base = family(kernel)
+    if layer.startswith(("blocks.", "upsamples.", "input_conv")):
+        return "generator convs (forward x2, data gradients)"
+    if "mpd." in layer:
+        return "period discriminators (convs, im2col / col2im)"
+    if "msd." in layer:
+        return "scale discriminators (convs, im2col / col2im)"
+    if base.startswith("wgrad"):
+        return "weight gradients"
+    return "other (reductions, packs, losses, element-wise)"
+
+
 def dispatches(path, counter):
     """[(dispatch id, kernel, counter value, duration ns)] of the hificar kernels, in dispatch order"""
     rows = {}
@@ -85,6 +99,7 @@ def main():
     ap.add_argument("--markers-per-iteration", type=int, default=2)
     ap.add_argument("--out", required=True)
     ap.add_argument("--command", default="")
+    ap.add_argument("--groups-json", default=None, help="also write the per-group and per-(kernel, group) totals as JSON (bench.py's training leg reads it)")
     a = ap.parse_args()
 
     per = {}
@@ -116,6 +131,7 @@ def main():
             f.write("# " + n + "\n")
         f.write("Kernel,Layer,Launches,avg_duration_us,GFLOP_per_launch,algorithmic_MB,FETCH_KiB_raw,WRITE_KiB,HBM_MB_corrected,traffic_over_algorithmic,TFLOP_s\n")
         tot = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+        grp = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0, 0.0])  # launches, HBM bytes, algorithmic bytes, ns, flops
         for key in keys:
             k, label = key
             n, fv, dur, ab, fl = per["fetch"][key]
@@ -131,9 +147,25 @@ def main():
             t[1] += hbm * n
             t[2] += ab * n
             t[3] += dur
+            for gk in (group_of(k, layer), family(k) + " @ " + group_of(k, layer)):
+                g = grp[gk]
+                g[0] += n
+                g[1] += hbm * n
+                g[2] += ab * n
+                g[3] += dur
+                g[4] += fl * n
         f.write("# per kernel name (launch-weighted): kernel, launches, HBM MB, algorithmic MB, ratio, total ms\n")
         for k, (n, hb, ab, dur) in sorted(tot.items(), key=lambda kv: -kv[1][3]):
             f.write(f"# {k},{n},{hb / n / 1e6:.2f},{ab / n / 1e6:.2f},{hb / ab if ab else 0:.2f},{dur / 1e6:.3f}\n")
+    if a.groups_json:
+        import json
+
+        out = {"_comment": "HBM bytes (2*FETCH + WRITE, rocprofv3 PMC) against the library's algorithmic bytes, summed per group of launches of ONE serial GAN "
+                           "iteration (tools/pmc_by_layer.sh); keys 'family @ group' restrict a kernel family to one group", "_source": os.path.basename(a.out)}
+        for gk, (n, hb, ab, dur, fl) in grp.items():
+            out[gk] = {"launches": n, "hbm_MB": round(hb / 1e6, 1), "algorithmic_MB": round(ab / 1e6, 1), "traffic_over_algorithmic": round(hb / ab, 3) if ab else None,
+                       "ms": round(dur / 1e6, 3), "tflops": round(fl / (dur * 1e-9) / 1e12, 1) if dur else 0.0}
+        json.dump(out, open(a.groups_json, "w"), indent=1, sort_keys=True)
     print(open(a.out).read()[:6000])
     for n in notes:
         print(n, file=sys.stderr)

@@ -11,7 +11,7 @@ cd /tmp
 if [ "$what" = gan ]; then
   cmd="python $root/tools/gan_bench.py --steps 1"
   export HIFICAR_DISC_STREAMS=0
-  extra="--last-iterations 1 --markers-per-iteration 2"
+  extra="--last-iterations 1 --markers-per-iteration 2 --groups-json $root/gpurun_out/${tag}_gan_traffic_by_group.json"
 else
   cmd="python $root/bench.py --precision f32 --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --no-fast-leg --no-batch-sweep --no-training --no-nonar --no-gblock"
   extra=""
