@@ -565,6 +565,14 @@ def main(argv=None):
             raise SystemExit(f"{len(cond.spks)} speakers in {a.utt2spk} but generator_params.num_spk = {gp['num_spk']}")
         if a.dev_dumpdir:
             dev_cond = Conditioning((a.dev_utt2spk or a.utt2spk) if use_spk_id else None, (a.dev_ph_scp or a.ph_scp) if use_ph else None, spks=cond.spks)
+    if (use_spk_id or use_ph) and a.synthetic and a.dev_dumpdir:
+        # synthetic training data carries its own speaker / phoneme ids; a real dev set still needs its side tables (its speaker list defines the ids)
+        if (use_spk_id and not (a.dev_utt2spk or a.utt2spk)) or (use_ph and not (a.dev_ph_scp or a.ph_scp)):
+            raise SystemExit("a conditioned generator with --dev-dumpdir needs the dev set's side tables: --dev-utt2spk (use_spk_id) / --dev-ph-scp "
+                             "(use_ph, use_ph_loss), also with --synthetic training data")
+        dev_cond = Conditioning((a.dev_utt2spk or a.utt2spk) if use_spk_id else None, (a.dev_ph_scp or a.ph_scp) if use_ph else None)
+        if use_spk_id and len(dev_cond.spks) != gp["num_spk"]:
+            raise SystemExit(f"{len(dev_cond.spks)} speakers in the dev set's utt2spk but generator_params.num_spk = {gp['num_spk']}")
     if a.synthetic:
         data = SyntheticPairs(a.synthetic, 4 * frames, feature_dims(config), hop, seed=rank, num_spk=gp.get("num_spk") if use_spk_id else 0,
                               num_ph=gp.get("num_ph") if use_ph else 0)

@@ -731,6 +731,33 @@ def test_mrf_mean_folded_into_the_upsampler(kernels):
             assert rel_err(y_r[i:i + 1, :, :n * 80].cpu().numpy(), y_1.cpu().numpy()) < 5e-6
 
 
+def test_two_handles_on_one_device_run_concurrently_on_two_streams(prec):
+    """One handle per module: two generators on one device own separate native state (schedule arenas, tile-pick caches, workspaces), so their
+    calls may be in flight at the same time on different streams.  Interleaved AR syntheses and forwards of two models (different widths, so every
+    launch shape and schedule differs) on two streams equal each model's own serial results bit for bit, over repeated rounds."""
+    pa = dict(E2W_PARAMS)
+    pb = dict(E2W_PARAMS, channels=256)
+    ga, _ = make(pa, prec, seed=11)
+    gb, _ = make(pb, prec, seed=12)
+    xa = torch.from_numpy(synth_features(9, 60, 13, seed=91)).permute(0, 2, 1).contiguous().cuda()
+    xb = torch.from_numpy(synth_features(5, 85, 13, seed=92)).permute(0, 2, 1).contiguous().cuda()
+    with torch.no_grad():
+        ya0, yb0 = ga.ar_synthesis(xa, 25), gb.ar_synthesis(xb, 25)
+        torch.cuda.synchronize()
+        assert ga._native_handle().value != gb._native_handle().value
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        for _ in range(3):
+            outs = []
+            for _ in range(2):  # enqueue alternately: both handles' launches are in flight together
+                with torch.cuda.stream(sa):
+                    outs.append(("a", ga.ar_synthesis(xa, 25)))
+                with torch.cuda.stream(sb):
+                    outs.append(("b", gb.ar_synthesis(xb, 25)))
+            torch.cuda.synchronize()
+            for tag, y in outs:
+                assert torch.equal(y, ya0 if tag == "a" else yb0)
+
+
 def test_ragged_forward_non_ar(prec):
     """hificar_forward_ragged on the non-AR generator: per utterance identical to a forward of that utterance alone."""
     params = dict(E2W_PARAMS, in_channels=12, use_ar=False)
