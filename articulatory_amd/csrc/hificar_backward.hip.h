@@ -1148,6 +1148,89 @@ struct PackParams {
 template <typename I>
 __device__ __forceinline__ void pack_w32_body_t(const PackParams& p, I first, I step) {
     const I total = (I)p.total;
+    // Taps inside the thread (round 6).  The generic loop below reads ONE float per packed element, and the K taps of a (co, ci) pair — K adjacent floats
+    // of the source — belong to K packed blocks thousands of elements apart: other workgroups, other XCDs, so every source sector was fetched by up to
+    // K (x 8 L2s) readers (r06a: 1.58 GB moved per launch for 161 MB).  Here a thread walks the packed layout WITHOUT its tap axis, reads its pair's K
+    // adjacent floats once and writes the K packed elements (each store still one contiguous run per wave).  Pure copies: the same packed tensor.
+    //   modes 0 / 2 (Conv1d forward / data gradient) and 10 / 11 (polyphase-input forms: a thread's taps are every stride-th float of its pair's K):
+    //   the tap axis of the packed layout;  modes 8 / 9 (GEMM forms): the taps are groups of cin / chunk K-chunks (8) resp. cin / 32 channel blocks
+    //   (9) — when those divide evenly; everything else (transposed convs, odd shapes) takes the generic loop.
+    {
+        const bool one_phase = p.nb32_per_phase == p.n_blocks32;
+        const bool conv_in = (p.mode == 0 || p.mode == 2) && p.ntaps == p.K && p.K > 1 && one_phase;
+        const bool poly_in = (p.mode == 10 || p.mode == 11) && p.ntaps > 1 && one_phase && p.stride >= 1;
+        const bool gemm_f = p.mode == 8 && p.ntaps == 1 && p.K > 1 && one_phase && p.cin % p.chunk == 0 && p.nchunk * p.chunk == p.K * p.cin &&
+                            p.cin_pack == p.K * p.cin;
+        const bool gemm_d = p.mode == 9 && p.ntaps == 1 && p.K > 1 && one_phase && p.cin % 32 == 0 && p.n_blocks32 * 32 == p.K * p.cin &&
+                            p.cout_pack == p.K * p.cin;
+        if (conv_in || poly_in || gemm_f || gemm_d) {
+            const int K = p.K;
+            const int T = poly_in ? p.ntaps : K;  // taps the thread writes
+            const int nchunk_i = gemm_f ? p.cin / p.chunk : p.nchunk;  // chunks / channel blocks the thread index walks (a tap's share in the GEMM forms)
+            const int nblk_i = gemm_d ? p.cin / 32 : p.n_blocks32;
+            const I sub_total = (I)nblk_i * nchunk_i * p.nc16 * 512;
+            for (I i = first; i < sub_total; i += step) {
+                I r = i;
+                const int j = (int)(r & 3);
+                r >>= 2;
+                const int lane = (int)(r & 63);
+                r >>= 6;
+                const int v = (int)(r & 1);
+                r >>= 1;
+                const int u = (int)(r % p.nc16);
+                r /= p.nc16;
+                const int c = (int)(r % nchunk_i);
+                const int nb = (int)(r / nchunk_i);
+                const int g = lane >> 5, n = lane & 31;
+                const int co = nb * 32 + n;                          // (within a tap's share for mode 9)
+                const int ci = c * p.chunk + u * 16 + 8 * v + 4 * g + j;  // (within a tap's share for mode 8)
+                const int in_lane = ((u * 2 + v) * 64 + lane) * 4 + j;   // offset inside a (block, chunk, tap) fragment group of nc16 * 512 floats
+                const float* sp = nullptr;
+                int rr = 0;  // polyphase forms: this thread's position inside a row of `stride` inputs
+                if (conv_in) {
+                    if (co < p.cout_pack && ci < p.cin_pack) sp = p.mode == 0 ? p.src + ((size_t)co * p.cin + ci) * K : p.src + ((size_t)ci * p.cin + co) * K;
+                } else if (poly_in) {
+                    if (co < p.cout_pack && ci < p.cin_pack) {
+                        if (p.mode == 10) {
+                            rr = ci / p.cin;
+                            sp = p.src + ((size_t)co * p.cin + (ci - rr * p.cin)) * K;
+                        } else {
+                            rr = co / p.cin;
+                            sp = p.src + ((size_t)ci * p.cin + (co - rr * p.cin)) * K;
+                        }
+                    }
+                } else if (gemm_f) {
+                    if (co < p.cout_pack) sp = p.src + ((size_t)co * p.cin + ci) * K;  // ci < cin: the tap's own channel
+                } else {
+                    if (ci < p.cin_pack) sp = p.src + ((size_t)ci * p.cin + co) * K;   // co < cin
+                }
+                for (int t0 = 0; t0 < T; t0 += kMaxTaps) {  // (the scale discriminators' k = 41: three groups of taps)
+                    float w[kMaxTaps];  // w[q]: the value of packed tap t0 + q (mode 2 packs the taps reversed, 10 / 11 every stride-th kernel index)
+#pragma unroll
+                    for (int q = 0; q < kMaxTaps; ++q) {
+                        const int t = t0 + q;
+                        int k = t;
+                        if (p.mode == 2) k = K - 1 - t;
+                        else if (p.mode == 10) k = p.stride * t + rr;
+                        else if (p.mode == 11) k = p.stride * (T - 1 - t) + rr;
+                        w[q] = (sp && t < T && k >= 0 && k < K) ? sp[k] : 0.f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < kMaxTaps; ++q) {
+                        const int t = t0 + q;
+                        if (t < T) {
+                            size_t d;
+                            if (conv_in || poly_in) d = (((size_t)nb * p.nchunk + c) * T + t) * p.nc16 * 512 + in_lane;
+                            else if (gemm_f) d = ((size_t)nb * p.nchunk + (size_t)t * nchunk_i + c) * p.nc16 * 512 + in_lane;
+                            else d = (((size_t)t * nblk_i + nb) * p.nchunk + c) * p.nc16 * 512 + in_lane;
+                            p.dst[d] = w[q];
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
     for (I i = first; i < total; i += step) {
         if (p.mode >= 4 && p.mode <= 7) {
             if (p.mode == 4) {

@@ -119,8 +119,8 @@ def main():
             e[0] += 1
             e[1] += v
             e[2] += dur
-            e[3] = abytes
-            e[4] = flops
+            e[3] += abytes  # (launches that share a label may differ in size: the two engines' pack_all_kernel launches)
+            e[4] += flops
         per[what] = agg
     keys = list(per["fetch"].keys())
     with open(a.out, "w") as f:
@@ -135,6 +135,7 @@ def main():
         for key in keys:
             k, label = key
             n, fv, dur, ab, fl = per["fetch"][key]
+            ab, fl = ab / n, fl / n  # per launch
             wn, wv = per["write"].get(key, [1, 0.0])[:2]
             fe, wr = fv / n, wv / max(wn, 1)
             hbm = (2 * fe + wr) * 1024
