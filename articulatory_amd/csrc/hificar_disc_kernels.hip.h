@@ -305,11 +305,9 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossEntry* entries, con
     const long long n4 = e.total >> 2;
     const long long lo = n4 * blockIdx.x / kLossChunks, hi = n4 * (blockIdx.x + 1) / kLossChunks;
     float s_adv = 0.f, s_fm = 0.f;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const f32x4 av = reinterpret_cast<const f32x4*>(a)[i];
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (b && e.c_fm != 0.f) bv = reinterpret_cast<const f32x4*>(b)[i];
-        const int col = (int)((i * 4) % e.pitch);
+    const bool use_b = b && e.c_fm != 0.f;
+    // one element quad: the same arithmetic, in the same order per thread, as ever (the partial sums — and with them every logged loss — do not move)
+    auto quad = [&](long long i, int col, const f32x4& av, const f32x4& bv) {
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -333,6 +331,46 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossEntry* entries, con
             g[u] = e.w_adv * ga + e.w_fm * gf;
         }
         reinterpret_cast<f32x4*>(d)[i] = g;
+    };
+    if ((e.pitch & 3) == 0) {
+        // Round 6: the column of a quad is carried along instead of a 64-bit `%` per quad (the loop was bound by that division: 2 TB/s on a pure
+        // streaming pass), and four quads are in flight per thread.
+        const int p4 = e.pitch >> 2, step4 = 256 % p4;
+        int col4 = (int)((lo + threadIdx.x) % p4);
+        auto advance = [&](int c) {
+            c += step4;
+            return c >= p4 ? c - p4 : c;
+        };
+        constexpr int UQ = 4;
+        long long i = lo + threadIdx.x;
+        for (; i + (UQ - 1) * 256 < hi; i += UQ * 256) {
+            f32x4 av[UQ], bv[UQ];
+            int cols[UQ];
+#pragma unroll
+            for (int q = 0; q < UQ; ++q) {
+                av[q] = reinterpret_cast<const f32x4*>(a)[i + q * 256];
+                bv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (use_b) bv[q] = reinterpret_cast<const f32x4*>(b)[i + q * 256];
+                cols[q] = col4 * 4;
+                col4 = advance(col4);
+            }
+#pragma unroll
+            for (int q = 0; q < UQ; ++q) quad(i + q * 256, cols[q], av[q], bv[q]);
+        }
+        for (; i < hi; i += 256) {
+            const f32x4 av = reinterpret_cast<const f32x4*>(a)[i];
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (use_b) bv = reinterpret_cast<const f32x4*>(b)[i];
+            quad(i, col4 * 4, av, bv);
+            col4 = advance(col4);
+        }
+    } else {
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+            const f32x4 av = reinterpret_cast<const f32x4*>(a)[i];
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (use_b) bv = reinterpret_cast<const f32x4*>(b)[i];
+            quad(i, (int)((i * 4) % e.pitch), av, bv);
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
