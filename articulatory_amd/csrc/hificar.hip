@@ -936,6 +936,9 @@ static int arena_take(hificar_handle* h, size_t bytes, char** d, char** hm) {
 // Longest-processing-time-first assignment of `costs.size()` tiles to G workgroups; each workgroup's list is then
 // ordered light -> heavy (the kernel walks it in that order).  Built once per launch shape, uploaded asynchronously on the
 // launch stream (the launch that follows is ordered behind the copy) and cached.
+static int put_schedule(hificar_handle* h, const std::string& key, const std::vector<std::vector<int>>& lists, int n, hipStream_t stream,
+                        const int** d_start, const int** d_tiles);
+
 static int get_schedule(hificar_handle* h, const std::string& key, const std::vector<double>& costs, int G, hipStream_t stream,
                         const int** d_start, const int** d_tiles) {
     auto it = h->scheds.find(key);
@@ -959,6 +962,20 @@ static int get_schedule(hificar_handle* h, const std::string& key, const std::ve
             top.first += costs[t];
             std::push_heap(heap.begin(), heap.end(), cmp);
         }
+        for (auto& l : lists) std::reverse(l.begin(), l.end());  // heavy-first insertion order -> light first
+        return put_schedule(h, key, lists, n, stream, d_start, d_tiles);
+    }
+    *d_start = it->second.d_start;
+    *d_tiles = it->second.d_tiles;
+    return HIFICAR_OK;
+}
+
+// An explicit tile list per workgroup (walked in the order given), uploaded asynchronously on the launch stream and cached under `key`.
+static int put_schedule(hificar_handle* h, const std::string& key, const std::vector<std::vector<int>>& lists, int n, hipStream_t stream,
+                        const int** d_start, const int** d_tiles) {
+    auto it = h->scheds.find(key);
+    if (it == h->scheds.end()) {
+        const int G = (int)lists.size();
         const size_t n_start = (size_t)G + 1;
         const size_t bytes = (round_up_sz(n_start, 4) + (size_t)std::max(n, 1)) * sizeof(int);
         char *dp = nullptr, *hp = nullptr;
@@ -969,7 +986,7 @@ static int get_schedule(hificar_handle* h, const std::string& key, const std::ve
         int pos = 0;
         for (int w = 0; w < G; ++w) {
             start[w] = pos;
-            for (auto r = lists[w].rbegin(); r != lists[w].rend(); ++r) tiles[pos++] = *r;  // heavy-first insertion order -> light first
+            for (int t : lists[w]) tiles[pos++] = t;
         }
         start[G] = pos;
         HIP_TRY(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, stream));  // pinned source, never rewritten while cached
@@ -1211,7 +1228,46 @@ static int launch_conv(hificar_handle* h, const ConvLayer* const* layers, int nb
     // every input row is staged once per channel group: more than two groups (upsampler 0's ten, a 1024-wide GEMM's eight) re-read it from the L2
     // instead of streaming it past the cache (r06a: 2.7 x / 3-7 x the algorithmic bytes fetched by those launches with non-temporal loads)
     mp.stage_cached = mp.ngroups > 2 ? 1 : 0;
-    if (h->use_lpt && mp.total_tiles > (int)grid.x) {
+    // One round of tiles of ONE layer whose weights do not fit an XCD's 4-MB L2 (the discriminators' 1024-wide GEMM-form layers: 21 MB of weights,
+    // 17 row tiles x 8 channel groups): dealt out round-robin every XCD streams ALL the weights through its L2 (335 MB per launch); here every XCD
+    // gets a BLOCK of (row tiles x channel groups), so that both operands are re-used inside the XCD by workgroups that run in lock step — the
+    // split of the 8 XCDs into (pr x pg) that minimises row tiles / pr + channel groups / pg.  Workgroup w is dispatched to XCD w % 8
+    // (MI355X_MICROARCH.md: round-robin; an assumption for speed only — any mapping is correct).
+    if (mp.total_tiles <= h->num_cus && nbr == 1 && zr.n == 1 && mp.ngroups >= 2 && mp.nseq_tiles >= 8 && !h->shared_chip) {
+        const double wbytes1 = 4.0 * L0.cin_pad * L0.cout_total * L0.ntaps;
+        if (wbytes1 > 6.0e6) {
+            const int R = mp.nseq_tiles, Gc = mp.ngroups;
+            int bpr = 1, bpg = 8;
+            double bcost = 1e300;
+            for (int pr = 1; pr <= 8; pr *= 2) {
+                const int pg = 8 / pr;
+                if (pr > R || pg > Gc) continue;
+                const double c = (double)((R + pr - 1) / pr) + (double)((Gc + pg - 1) / pg);
+                if (c < bcost) bcost = c, bpr = pr, bpg = pg;
+            }
+            std::vector<std::vector<int>> per_xcd(8);
+            size_t maxblock = 0;
+            for (int x = 0; x < 8; ++x) {
+                const int xr = x / bpg, xg = x % bpg;
+                const int r0 = R * xr / bpr, r1 = R * (xr + 1) / bpr, g0 = Gc * xg / bpg, g1 = Gc * (xg + 1) / bpg;
+                for (int g2 = g0; g2 < g1; ++g2)
+                    for (int r2 = r0; r2 < r1; ++r2) per_xcd[(size_t)x].push_back(g2 * R + r2);  // tile id = channel group * row tiles + row tile
+                maxblock = std::max(maxblock, per_xcd[(size_t)x].size());
+            }
+            if (maxblock * 8 <= (size_t)h->num_cus && bcost < (double)(R + 1)) {
+                std::vector<std::vector<int>> lists(maxblock * 8);
+                for (int x = 0; x < 8; ++x)
+                    for (size_t l = 0; l < per_xcd[(size_t)x].size(); ++l) lists[l * 8 + (size_t)x].push_back(per_xcd[(size_t)x][l]);
+                const std::string key = std::string(f32 ? "f" : "c") + "|x2d|" + L0.name + "|" + std::to_string(R) + "x" + std::to_string(Gc) + "t" + std::to_string(TM) +
+                                        "w" + std::to_string(tc.WN) + "k" + std::to_string(tc.KS) + (tc.NB == 2 ? "b" : "");
+                grid = dim3((unsigned)lists.size(), 1, 1);
+                mp.xcd_order = 0;
+                int rc2 = put_schedule(h, key, lists, mp.total_tiles, stream, &mp.sched_start, &mp.sched_tiles);
+                if (rc2 != HIFICAR_OK) return rc2;
+            }
+        }
+    }
+    if (!mp.sched_start && h->use_lpt && mp.total_tiles > (int)grid.x) {
         std::vector<double> costs((size_t)mp.total_tiles);
         const int tpb = mp.ngroups * mp.nseq_tiles;
         std::string key = f32 ? "f" : "c";
