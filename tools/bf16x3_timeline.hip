@@ -160,7 +160,128 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, bool
     hipFree(trace);
 }
 
-int main() {
+// exact-fp32 direct-output kernel on a GEMM-form launch of the discriminators (one tap, K = Cin): rows x Cin -> Cout, one "sequence"
+template <int MI, int WM, int WN, int NC16>
+void run_f32_gemm(const char* label, int rows, int Cin, int Cout, int pitch = 0) {
+    if (!pitch) pitch = Cin;
+    constexpr int TM = WM * MI * 32, CH = NC16 * 16;
+    float *x, *y, *bias;
+    char* zeros;
+    const size_t nx = (size_t)rows * pitch, ny = (size_t)rows * Cout;
+    hipMalloc(&x, nx * 4);
+    hipMalloc(&y, ny * 4);
+    {
+        std::vector<float> hx(nx);
+        unsigned st = 4242u;
+        for (size_t i = 0; i < nx; ++i) { st = st * 1664525u + 1013904223u; hx[i] = ((st >> 8) & 0xffff) / 32768.f - 1.f; }
+        hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice);
+    }
+    hipMalloc(&zeros, 256);
+    hipMemset(zeros, 0, 256);
+    hipMalloc(&bias, Cout * 4);
+    hipMemset(bias, 0, Cout * 4);
+    const size_t wfl = ((size_t)(Cout / 32) * (Cin / 16) * 2 + 2 * NC16) * 256;  // floats
+    float* w;
+    hipMalloc(&w, wfl * 4);
+    {
+        std::vector<float> hw(wfl);
+        unsigned st = 99u;
+        for (size_t i = 0; i < wfl; ++i) { st = st * 1664525u + 1013904223u; hw[i] = (((st >> 8) & 0xffff) / 32768.f - 1.f) * 0.02f; }
+        hipMemcpy(w, hw.data(), wfl * 4, hipMemcpyHostToDevice);
+    }
+    MultiConvParams mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.zrep = 1;
+    ConvParams& p = mp.p[0];
+    p.len_const = -1;
+    p.w16 = reinterpret_cast<const bf16x8*>(w); p.bias = bias; p.y = y; p.ys = nullptr; p.xs = reinterpret_cast<const char*>(x); p.zeros = zeros;
+    p.slope_out = 0.1f; p.cout_real = Cout; p.L = rows; p.tiles_per_seq = (rows + TM - 1) / TM; p.cin = Cin; p.cout_total = Cout;
+    p.n_blocks32 = Cout / 32; p.nb32_per_phase = Cout / 32; p.ntaps = 1; p.off_min = 0; p.halo = 0; p.tap_step = 0; p.tap_off0[0] = 0;
+    if (pitch != Cin) { p.x_row_bytes = pitch * 4; p.x_seq_bytes = (long long)rows * pitch * 4; }
+    mp.n_branches = 1;
+    mp.nseq_tiles = (rows + TM - 1) / TM;
+    mp.ngroups = (Cout / 32 + WN - 1) / WN;
+    mp.total_tiles = mp.ngroups * mp.nseq_tiles;
+    mp.buf_bytes = (TM * (CH * 4) + 1023) / 1024 * 1024;
+    mp.stage_cached = 1;
+    const int G = std::min(mp.total_tiles, 256);
+    unsigned long long* trace;
+    hipMalloc(&trace, (size_t)G * 2 * 64 * 8);
+    mp.trace = trace;
+    void (*kern)(const MultiConvParams) = conv_f32do_kernel<MI, WM, WN, NC16>;
+    const size_t lds_bytes = 2 * (size_t)mp.buf_bytes;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int it = 0; it < 4; ++it) {
+        hipEventRecord(e0);
+        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(G), dim3((WM * WN + 4) * 64), lds_bytes, 0, mp);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    hipMemset(trace, 0, (size_t)G * 2 * 64 * 8);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL(kern, dim3(G), dim3((WM * WN + 4) * 64), lds_bytes, 0, mp);
+    hipDeviceSynchronize();
+    const double us = ms * 1000 / 10, flops = 2.0 * rows * (double)Cin * Cout;
+    printf("%-40s tiles=%d G=%d lds=%zuKB  %.1f us/launch  %.1f TF-alg (%.3f of 157.3; per busy workgroup %.3f)\n", label, mp.total_tiles, G, lds_bytes / 1024, us,
+           flops / (us * 1e-6) / 1e12, flops / (us * 1e-6) / 1e12 / 157.3, flops / (us * 1e-6) / 1e12 / 157.3 * 256.0 / G);
+    std::vector<unsigned long long> ht((size_t)G * 2 * 64);
+    hipMemcpy(ht.data(), trace, ht.size() * 8, hipMemcpyDeviceToHost);
+    static unsigned long long rt[2][1024];
+    hipMemcpyFromSymbol(rt, HIP_SYMBOL(g_trace_realtime), sizeof(rt));
+    const unsigned long long* m0 = &ht[0];
+    const double mhz = (m0[63] && rt[1][0] > rt[0][0]) ? (double)(m0[63] - m0[0]) / ((rt[1][0] - rt[0][0]) * 0.01) : 0.0;
+    double m_wait = 0, m_work = 0, l_wait = 0, l_work = 0;
+    std::vector<double> item_cyc;
+    for (int wg = 0; wg < G; ++wg) {
+        const unsigned long long* m = &ht[(size_t)wg * 128];
+        const unsigned long long* l = m + 64;
+        for (int j = 0; 2 + 3 * (j + 1) < 62 && m[2 + 3 * (j + 1)]; ++j) {
+            m_wait += (double)(m[2 + 3 * j] - m[1 + 3 * j]);
+            const double work = (double)(m[1 + 3 * (j + 1)] - m[2 + 3 * j]);
+            m_work += work;
+            item_cyc.push_back(work);
+        }
+        for (int j = 0; 2 + 2 * (j + 1) < 62 && l[2 + 2 * (j + 1)]; ++j) {
+            l_wait += (double)(l[2 + 2 * j] - l[1 + 2 * j]);
+            l_work += (double)(l[1 + 2 * (j + 1)] - l[2 + 2 * j]);
+        }
+    }
+    std::sort(item_cyc.begin(), item_cyc.end());
+    const double ideal = (double)NC16 * 8 * MI * 64;  // one tap: NC16 slabs x 8 MFMAs x MI blocks x 64 cycles
+    printf("    s_memtime %.0f ticks / us; MFMA wave 0: %.1f %% of its ticks in front of barriers; median item (64 channels of K) %.0f ticks (p10 %.0f, p90 %.0f) against "
+           "%.0f of MFMA issue = %.2f; loader wave 0 idle %.1f %%; items per tile %d\n", mhz, 100 * m_wait / (m_wait + m_work),
+           item_cyc.empty() ? 0.0 : item_cyc[item_cyc.size() / 2], item_cyc.empty() ? 0.0 : item_cyc[item_cyc.size() / 10],
+           item_cyc.empty() ? 0.0 : item_cyc[item_cyc.size() * 9 / 10], ideal, item_cyc.empty() ? 0.0 : ideal / item_cyc[item_cyc.size() / 2],
+           100 * l_wait / (l_wait + l_work), Cin / CH);
+    const unsigned long long* m = &ht[0];
+    const unsigned long long* l = m + 64;
+    const unsigned long long t0 = std::min(m[0], l[0]);
+    printf("    WG 0 MFMA : ");
+    for (int i = 0; i < 32; ++i) printf("%lld ", m[i] ? (long long)(m[i] - t0) / 100 : -1LL);
+    printf("\n    WG 0 load : ");
+    for (int i = 0; i < 24; ++i) printf("%lld ", l[i] ? (long long)(l[i] - t0) / 100 : -1LL);
+    printf("  (x100 ticks)\n");
+    hipFree(trace); hipFree(x); hipFree(y); hipFree(w);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "gemm")) {  // the period discriminators' convs.4 / convs.3 as the training step launches them (forward)
+        run_f32_gemm<4, 1, 4, 4>("MPD convs.4 fwd 2112 x 5120 -> 1024 <4,1,4,4>", 2112, 5120, 1024);
+        run_f32_gemm<4, 1, 4, 4>("MPD convs.3 fwd 2112 x 2560 -> 1024 <4,1,4,4>", 2112, 2560, 1024);
+        run_f32_gemm<2, 1, 4, 4>("MPD convs.4 fwd <2,1,4,4> (272 tiles)", 2112, 5120, 1024);
+        run_f32_gemm<4, 1, 4, 4>("4 x the rows: 8448 x 5120 -> 1024", 8448, 5120, 1024);
+        // the same GEMMs with the A matrix's row pitch padded by 64 floats: rows no longer 4096-byte multiples apart
+        run_f32_gemm<4, 1, 4, 4>("MPD convs.4 fwd, pitch 5120 + 64", 2112, 5120, 1024, 5120 + 64);
+        run_f32_gemm<4, 1, 4, 4>("MPD convs.3 fwd, pitch 2560 + 64", 2112, 2560, 1024, 2560 + 64);
+        run_f32_gemm<4, 1, 4, 4>("MPD convs.4 fwd, pitch 5120 + 32", 2112, 5120, 1024, 5120 + 32);
+        // (a chunk-major A matrix — every staged item one contiguous 32-KB block — was measured with a ConvParams::x_chunk_bytes stride: 400 -> 389 us; not kept)
+        return 0;
+    }
+
     const int k3[3] = {11, 7, 3};
     const int k11[3] = {11, 11, 11};
     // the headline step's wide stages: batch 64, chunk 25 -> stage 0: 125 rows x 256 channels, stage 1: 500 rows x 128 channels (per sequence)
