@@ -162,7 +162,7 @@ void run(const char* label, int nseq, int L, int C, int nbr, const int* ks, bool
 
 // exact-fp32 direct-output kernel on a GEMM-form launch of the discriminators (one tap, K = Cin): rows x Cin -> Cout, one "sequence"
 template <int MI, int WM, int WN, int NC16>
-void run_f32_gemm(const char* label, int rows, int Cin, int Cout, int pitch = 0) {
+void run_f32_gemm(const char* label, int rows, int Cin, int Cout, int pitch = 0, bool reg_stage = false) {
     if (!pitch) pitch = Cin;
     constexpr int TM = WM * MI * 32, CH = NC16 * 16;
     float *x, *y, *bias;
@@ -198,6 +198,7 @@ void run_f32_gemm(const char* label, int rows, int Cin, int Cout, int pitch = 0)
     p.slope_out = 0.1f; p.cout_real = Cout; p.L = rows; p.tiles_per_seq = (rows + TM - 1) / TM; p.cin = Cin; p.cout_total = Cout;
     p.n_blocks32 = Cout / 32; p.nb32_per_phase = Cout / 32; p.ntaps = 1; p.off_min = 0; p.halo = 0; p.tap_step = 0; p.tap_off0[0] = 0;
     if (pitch != Cin) { p.x_row_bytes = pitch * 4; p.x_seq_bytes = (long long)rows * pitch * 4; }
+    if (reg_stage) { p.act_in = 1; p.slope_in = 1.0f; }  // the loaders stage through registers (global load + ds_write) instead of the LDS-DMA
     mp.n_branches = 1;
     mp.nseq_tiles = (rows + TM - 1) / TM;
     mp.ngroups = (Cout / 32 + WN - 1) / WN;
@@ -278,6 +279,8 @@ int main(int argc, char** argv) {
         run_f32_gemm<4, 1, 4, 4>("MPD convs.4 fwd, pitch 5120 + 64", 2112, 5120, 1024, 5120 + 64);
         run_f32_gemm<4, 1, 4, 4>("MPD convs.3 fwd, pitch 2560 + 64", 2112, 2560, 1024, 2560 + 64);
         run_f32_gemm<4, 1, 4, 4>("MPD convs.4 fwd, pitch 5120 + 32", 2112, 5120, 1024, 5120 + 32);
+        run_f32_gemm<4, 1, 4, 4>("MPD convs.4 fwd, register staging", 2112, 5120, 1024, 0, true);
+        run_f32_gemm<4, 1, 4, 4>("MPD convs.3 fwd, register staging", 2112, 2560, 1024, 0, true);
         // (a chunk-major A matrix — every staged item one contiguous 32-KB block — was measured with a ConvParams::x_chunk_bytes stride: 400 -> 389 us; not kept)
         return 0;
     }
