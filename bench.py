@@ -228,7 +228,7 @@ def roofline_block(stats, precision, wall_s, steps, traffic_table, strict=False,
     return blk
 
 
-def training_leg(steps=5, traffic_table=None):
+def training_leg(steps=10, traffic_table=None):
     """Secondary leg: BASELINE config 5's train step on this GPU — the whole GAN iteration of
     articulatory_amd/bin/train.py::Trainer on the shipped recipe e2w_hifigan_car.yaml (full generator + multi-scale / multi-period
     discriminators, mel + adversarial + feature-matching losses, both Adam updates) at the recipe's batch (64 windows of 2000 samples +
@@ -278,7 +278,9 @@ def training_leg(steps=5, traffic_table=None):
     # ---- the recipe's batch
     B = 64
     t, cfg = build(B, 1234, 4321)
-    batch = {k: torch.from_numpy(v) for k, v in synth_train_batch(cfg, 20260929, B).items()}
+    # (pinned, as the recipe's DataLoader delivers it — pin_memory: true — so that the copies to the device are asynchronous; a pageable batch drains
+    #  the stream at every .to(device): about 1 ms per iteration)
+    batch = {k: torch.from_numpy(v).pin_memory() for k, v in synth_train_batch(cfg, 20260929, B).items()}
     frames = cfg["batch_max_steps"] // HOP
     T_disc = cfg["generator_params"]["ar_input"] + cfg["batch_max_steps"]
 
